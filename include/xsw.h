@@ -1,0 +1,136 @@
+/* libxsw -- MI355X (gfx950) wind-inversion hot path of xsarsea, flat C ABI.
+ *
+ * The reference (umr-lops/xsarsea) is pure Python; its "native" layer for this path is what numba
+ * JIT-compiles at run time.  This header is the boundary a maintainer binds with ctypes in place of
+ * those JIT kernels.  Each entry point names the reference interface it
+ * replaces (paths relative to the reference's src/xsarsea/).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative XSW_E* code otherwise; the message is
+ *     available from xsw_last_error(ctx);  no exception crosses the ABI;
+ *   - pointers are caller-owned; `mem` says whether raster buffers are host or device pointers
+ *     (device pointers must belong to the context's device);  LUT/axis pointers are always host;
+ *   - rasters are flat, C-contiguous, `lines*samples` pixels; pixels are independent
+ *     (the reference's gufunc core dimension "(n)" is only a loop, windspeed/windspeed.py:190);
+ *   - complex values are interleaved (re, im);
+ *   - a context is bound to one device and one stream; calls on one context are not thread-safe,
+ *     different contexts are independent (one process per GPU uses one context).
+ */
+#ifndef XSW_H
+#define XSW_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XSW_VERSION 1
+
+enum { XSW_F32 = 0, XSW_F64 = 1 };           /* raster element type (complex rasters: c64 / c128) */
+enum { XSW_MEM_HOST = 0, XSW_MEM_DEVICE = 1 };
+enum {
+    XSW_ALGO_AUTO = 0,       /* pruned when the LUT axes are uniform and finite, else exact        */
+    XSW_ALGO_PRUNED = 1,     /* exact branch-and-bound search (production kernel)                   */
+    XSW_ALGO_EXHAUSTIVE = 2, /* full (wspd x phi) sweep, LUT slice tiled through LDS                */
+    XSW_ALGO_EXACT = 3       /* full sweep in the reference's operation order (slow, any LUT)       */
+};
+enum {
+    XSW_OK = 0,
+    XSW_EINVAL = -1,   /* bad argument */
+    XSW_EHIP = -2,     /* HIP runtime error */
+    XSW_ENOLUT = -3,   /* required LUT not uploaded */
+    XSW_ENOMEM = -4
+};
+
+typedef struct xsw_ctx xsw_ctx;
+
+/* A model LUT in dB, as produced by the reference's Model.to_lut(units="dB") (windspeed/models.py:186-230)
+ * but kept incidence-major: co-pol db[n_inc][n_wspd][n_phi], cross-pol db[n_inc][n_wspd] (n_phi = 0).
+ * Replaces the closure arrays of _invert_from_model_numpy (windspeed/windspeed.py:144-181).
+ *
+ * The remaining tables are OPTIONAL (NULL = filled by the library with the host libm).  They exist so
+ * that a caller can hand over the values ITS math library produces for the handful of transcendental
+ * expressions of the reference whose last bit is platform dependent (numpy dispatches SIMD variants
+ * of cos/sin/arctan2/abs), making the device results bit-identical to that caller's CPU path:
+ *   cos_phi, sin_phi [n_phi]        cos/sin(radians(phi)) of the candidate vectors (windspeed.py:167-168)
+ *   out_dir [2][n_phi][2]           exp(1j*deg2rad(+phi)) and exp(1j*deg2rad(-phi)) as (re, im) (:235-236, :247)
+ *   abs_co  [n_wspd][n_phi]         abs(wspd*exp(1j*deg2rad(phi)))  (np.abs(wind_co), :257-274)
+ *   dual_dir [2][n_wspd][n_phi][2]  exp(1j*angle(sol)), exp(1j*angle(sol_2)) as (re, im) (:270-276)     */
+typedef struct {
+    const double *db;
+    const double *inc;
+    const double *wspd;
+    const double *phi;
+    const double *cos_phi;
+    const double *sin_phi;
+    const double *out_dir;
+    const double *abs_co;
+    const double *dual_dir;
+    int32_t n_inc, n_wspd, n_phi;
+} xsw_lut;
+
+/* Arguments of one inversion call == the five gufunc inputs and two outputs of
+ * __invert_from_model_1d (windspeed/windspeed.py:183-282, wrapper :306-323), plus the sigma0->dB
+ * conversion of invert_from_model (:126-130) and the dual-pol select (:426-428) fused on request. */
+typedef struct {
+    int64_t lines, samples;
+    int32_t dtype;          /* XSW_F32 / XSW_F64: inc, sigma0_co, sigma0_cr, dsig_cr; anc is complex of it */
+    int32_t out_dtype;      /* XSW_F32 -> complex64 outputs, XSW_F64 -> complex128 (reference)      */
+    int32_t mem;            /* XSW_MEM_HOST / XSW_MEM_DEVICE, applies to every raster pointer below   */
+    int32_t sigma0_is_db;   /* 0: linear sigma0, converted as 10*log10(x + 1e-15) in `dtype` arithmetic
+                               (:126-130);  1: already dB                                             */
+    int32_t algo;           /* XSW_ALGO_*                                                             */
+    int32_t dual_select;    /* 1: out_cr receives where(|co|<5 or |dual|<5, co, dual) (:426-428)      */
+    const void *inc;        /* incidence, degrees                                                     */
+    const void *sigma0_co;  /* NULL: no co-pol search (cross-pol only)                                */
+    const void *sigma0_cr;  /* NULL: no cross-pol search                                              */
+    const void *dsig_cr;    /* NULL: use dsig_cr_scalar (:122-123)                                    */
+    const void *anc;        /* ancillary wind, complex, antenna convention; NULL: all NaN             */
+    double dsig_co;         /* :24 default 0.1                                                        */
+    double dsig_cr_scalar;
+    void *out_co;           /* complex; NULL allowed when sigma0_co is NULL                           */
+    void *out_cr;           /* complex; NULL: not written                                             */
+    int32_t *out_idx;       /* optional int32[n][3] = (i_wspd, i_phi, i_wspd_cr), -1 where no search  */
+} xsw_invert_args;
+
+/* Evaluated-work counters of the last xsw_invert call with stats enabled. */
+typedef struct {
+    uint64_t pixels_co;        /* pixels that ran a co-pol search                   */
+    uint64_t cand_co;          /* co-pol candidates actually scored                 */
+    uint64_t pixels_exact;     /* pixels that took the exact full-scan path         */
+    uint64_t pixels_cr;        /* pixels that ran a cross-pol search                */
+} xsw_stats;
+
+int xsw_version(void);
+int xsw_device_count(void);
+
+int xsw_ctx_create(int device, xsw_ctx **ctx);
+int xsw_ctx_destroy(xsw_ctx *ctx);
+const char *xsw_last_error(const xsw_ctx *ctx); /* ctx may be NULL: last creation error */
+
+/* Launch on a caller-provided hipStream_t (e.g. torch's current stream); NULL = the context's own. */
+int xsw_set_stream(xsw_ctx *ctx, void *hip_stream);
+int xsw_synchronize(xsw_ctx *ctx);
+
+/* Replaces Model.to_lut(...) -> closure arrays (windspeed.py:144-181).  Either may be NULL (kept). */
+int xsw_lut_upload(xsw_ctx *ctx, const xsw_lut *co, const xsw_lut *cr);
+
+/* Replaces _invert_from_model_numpy (windspeed.py:132-331).  Asynchronous on the context's stream
+ * when mem == XSW_MEM_DEVICE; synchronous (returns with outputs filled) for host memory. */
+int xsw_invert(xsw_ctx *ctx, const xsw_invert_args *args);
+
+/* Enable (1) / disable (0) device-side work counters; read them after synchronising. */
+int xsw_stats_enable(xsw_ctx *ctx, int on);
+int xsw_stats_read(xsw_ctx *ctx, xsw_stats *out);
+
+/* Replaces the per-pixel part of sigma0_detrend (detrend.py:63-64):
+ * out[l][s] = sigma0[l][s] / ratio_row[s], ratio_row = g / nanmean(g) (float64, host pointer).
+ * out is float64 (the reference's result dtype) when out_dtype == XSW_F64. */
+int xsw_detrend(xsw_ctx *ctx, int64_t lines, int64_t samples, int32_t dtype, int32_t out_dtype, int32_t mem,
+                const void *sigma0, const double *ratio_row, void *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XSW_H */

@@ -1,0 +1,236 @@
+"""ctypes binding of libxsw.so (include/xsw.h).  There is no CPU fallback: if the library is missing
+or no GPU is present the calls raise."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _build
+
+XSW_F32, XSW_F64 = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+ALGO_AUTO, ALGO_PRUNED, ALGO_EXHAUSTIVE, ALGO_EXACT = 0, 1, 2, 3
+ALGOS = {"auto": ALGO_AUTO, "pruned": ALGO_PRUNED, "exhaustive": ALGO_EXHAUSTIVE, "exact": ALGO_EXACT}
+
+EXPORTS = (
+    "xsw_version", "xsw_device_count", "xsw_ctx_create", "xsw_ctx_destroy", "xsw_last_error", "xsw_set_stream",
+    "xsw_synchronize", "xsw_lut_upload", "xsw_invert", "xsw_stats_enable", "xsw_stats_read", "xsw_detrend",
+)
+
+
+class XswError(RuntimeError):
+    pass
+
+
+class LutStruct(ctypes.Structure):
+    _fields_ = [("db", ctypes.c_void_p), ("inc", ctypes.c_void_p), ("wspd", ctypes.c_void_p),
+                ("phi", ctypes.c_void_p), ("cos_phi", ctypes.c_void_p), ("sin_phi", ctypes.c_void_p),
+                ("out_dir", ctypes.c_void_p), ("abs_co", ctypes.c_void_p), ("dual_dir", ctypes.c_void_p),
+                ("n_inc", ctypes.c_int32), ("n_wspd", ctypes.c_int32), ("n_phi", ctypes.c_int32)]
+
+
+class InvertArgs(ctypes.Structure):
+    _fields_ = [("lines", ctypes.c_int64), ("samples", ctypes.c_int64), ("dtype", ctypes.c_int32),
+                ("out_dtype", ctypes.c_int32), ("mem", ctypes.c_int32), ("sigma0_is_db", ctypes.c_int32),
+                ("algo", ctypes.c_int32), ("dual_select", ctypes.c_int32),
+                ("inc", ctypes.c_void_p), ("sigma0_co", ctypes.c_void_p), ("sigma0_cr", ctypes.c_void_p),
+                ("dsig_cr", ctypes.c_void_p), ("anc", ctypes.c_void_p),
+                ("dsig_co", ctypes.c_double), ("dsig_cr_scalar", ctypes.c_double),
+                ("out_co", ctypes.c_void_p), ("out_cr", ctypes.c_void_p), ("out_idx", ctypes.c_void_p)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("pixels_co", ctypes.c_uint64), ("cand_co", ctypes.c_uint64), ("pixels_exact", ctypes.c_uint64),
+                ("pixels_cr", ctypes.c_uint64)]
+
+
+_cdll = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def load():
+    """Load libxsw.so (raises if it has not been built: run `python -m xsarsea_amd._build`)."""
+    global _cdll
+    if _cdll is None:
+        if not os.path.exists(_build.LIB):
+            raise XswError(f"{_build.LIB} is missing: build it with `python -m xsarsea_amd._build` "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        lib = ctypes.CDLL(_build.LIB)
+        lib.xsw_last_error.restype = ctypes.c_char_p
+        lib.xsw_last_error.argtypes = [ctypes.c_void_p]
+        lib.xsw_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        lib.xsw_ctx_destroy.argtypes = [ctypes.c_void_p]
+        lib.xsw_set_stream.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.xsw_synchronize.argtypes = [ctypes.c_void_p]
+        lib.xsw_lut_upload.argtypes = [ctypes.c_void_p, ctypes.POINTER(LutStruct), ctypes.POINTER(LutStruct)]
+        lib.xsw_invert.argtypes = [ctypes.c_void_p, ctypes.POINTER(InvertArgs)]
+        lib.xsw_stats_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.xsw_stats_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(Stats)]
+        lib.xsw_detrend.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                    ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        _cdll = lib
+    return _cdll
+
+
+def device_count():
+    return load().xsw_device_count()
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return ctypes.c_void_p(a)
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+class Context:
+    """One device, one stream (include/xsw.h: xsw_ctx)."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        h = ctypes.c_void_p()
+        rc = self._lib.xsw_ctx_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise XswError(f"xsw_ctx_create failed ({rc}): {self._lib.xsw_last_error(None).decode()}")
+        self._h = h
+        self.device = int(device)
+        self.lut_key = (None, None)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.xsw_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise XswError(f"{what} failed ({rc}): {self._lib.xsw_last_error(self._h).decode()}")
+
+    def set_stream(self, stream_handle):
+        self._check(self._lib.xsw_set_stream(self._h, ctypes.c_void_p(stream_handle or 0)), "xsw_set_stream")
+
+    def synchronize(self):
+        self._check(self._lib.xsw_synchronize(self._h), "xsw_synchronize")
+
+    @staticmethod
+    def _lut_struct(db, inc, wspd, phi=None, cos_phi=None, sin_phi=None, out_dir=None, abs_co=None, dual_dir=None):
+        keep = [_f64(db), _f64(inc), _f64(wspd)] + [None if v is None else _f64(v) for v in
+                                                    (phi, cos_phi, sin_phi, out_dir, abs_co, dual_dir)]
+        n_phi = 0 if phi is None else len(keep[3])
+        n_w = len(keep[2])
+        expect = (len(keep[1]), n_w) + ((n_phi,) if phi is not None else ())
+        if keep[0].shape != expect:
+            raise ValueError(f"LUT shape {keep[0].shape} does not match axes {expect}")
+        for a, shp, nm in ((keep[4], (n_phi,), "cos_phi"), (keep[5], (n_phi,), "sin_phi"),
+                           (keep[6], (2, n_phi, 2), "out_dir"), (keep[7], (n_w, n_phi), "abs_co"),
+                           (keep[8], (2, n_w, n_phi, 2), "dual_dir")):
+            if a is not None and a.shape != shp:
+                raise ValueError(f"{nm} has shape {a.shape}, expected {shp}")
+        s = LutStruct(*[_ptr(k) for k in keep], len(keep[1]), n_w, n_phi)
+        return s, keep
+
+    def upload_luts(self, co=None, cr=None):
+        """co = dict(db[inc,wspd,phi], inc, wspd, phi[, cos_phi, sin_phi]); cr = dict(db[inc,wspd], inc, wspd)."""
+        sco = scr = None
+        keep = []
+        if co is not None:
+            sco, k = self._lut_struct(**co)
+            keep.append(k)
+        if cr is not None:
+            scr, k = self._lut_struct(**cr)
+            keep.append(k)
+        self._check(self._lib.xsw_lut_upload(self._h, ctypes.byref(sco) if sco else None,
+                                             ctypes.byref(scr) if scr else None), "xsw_lut_upload")
+
+    def stats_enable(self, on=True):
+        self._check(self._lib.xsw_stats_enable(self._h, int(bool(on))), "xsw_stats_enable")
+
+    def stats(self):
+        s = Stats()
+        self._check(self._lib.xsw_stats_read(self._h, ctypes.byref(s)), "xsw_stats_read")
+        return {k: int(getattr(s, k)) for k, _ in Stats._fields_}
+
+    def invert_raw(self, lines, samples, dtype, out_dtype, mem, inc, sigma0_co, sigma0_cr, dsig_cr, anc, out_co,
+                   out_cr, out_idx=None, dsig_co=0.1, dsig_cr_scalar=0.1, sigma0_is_db=False, algo=ALGO_AUTO,
+                   dual_select=False):
+        """Thin call of xsw_invert; pointer arguments are ints (device or host addresses) or None."""
+        a = InvertArgs(int(lines), int(samples), dtype, out_dtype, mem, int(bool(sigma0_is_db)), int(algo),
+                       int(bool(dual_select)), inc, sigma0_co, sigma0_cr, dsig_cr, anc, float(dsig_co),
+                       float(dsig_cr_scalar), out_co, out_cr, out_idx)
+        self._check(self._lib.xsw_invert(self._h, ctypes.byref(a)), "xsw_invert")
+
+    def invert_host(self, inc, sigma0_co=None, sigma0_cr=None, dsig_cr=None, anc=None, dsig_co=0.1,
+                    sigma0_is_db=False, algo="auto", dual_select=False, out_dtype=np.complex128, want_idx=False):
+        """numpy-in / numpy-out wrapper of xsw_invert for host rasters of one dtype (float32 or float64)."""
+        inc = np.ascontiguousarray(inc)
+        dt = inc.dtype
+        if dt not in (np.float32, np.float64):
+            raise TypeError("raster dtype must be float32 or float64")
+        cdt = np.complex64 if dt == np.float32 else np.complex128
+        shape = inc.shape
+        n = inc.size
+        lines, samples = (int(np.prod(shape[:-1])), shape[-1]) if inc.ndim >= 1 and n else (0, 0)
+        if inc.ndim == 0:
+            lines, samples = 1, 1
+
+        def prep(a, t):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(np.broadcast_to(np.asarray(a), shape), dtype=t)
+            return a
+
+        s_co, s_cr, anc_ = prep(sigma0_co, dt), prep(sigma0_cr, dt), prep(anc, cdt)
+        dsig_scalar = 0.1
+        dsig_arr = None
+        if dsig_cr is not None:
+            if np.isscalar(dsig_cr):
+                dsig_scalar = float(dsig_cr)
+            else:
+                dsig_arr = prep(dsig_cr, dt)
+        out_dtype = np.dtype(out_dtype)
+        out_co = np.empty(shape, dtype=out_dtype) if s_co is not None else None
+        out_cr = np.empty(shape, dtype=out_dtype) if s_cr is not None else None
+        idx = np.empty(shape + (3,), dtype=np.int32) if want_idx else None
+        if n:
+            self.invert_raw(lines, samples, XSW_F32 if dt == np.float32 else XSW_F64,
+                            XSW_F32 if out_dtype == np.complex64 else XSW_F64, MEM_HOST,
+                            _ptr(inc), _ptr(s_co), _ptr(s_cr), _ptr(dsig_arr), _ptr(anc_), _ptr(out_co), _ptr(out_cr),
+                            _ptr(idx), dsig_co, dsig_scalar, sigma0_is_db, ALGOS.get(algo, algo), dual_select)
+        return out_co, out_cr, idx
+
+    def detrend_host(self, sigma0, ratio_row, out_dtype=np.float64):
+        sigma0 = np.ascontiguousarray(sigma0)
+        if sigma0.dtype not in (np.float32, np.float64):
+            sigma0 = sigma0.astype(np.float64)
+        ratio_row = _f64(ratio_row)
+        lines, samples = int(np.prod(sigma0.shape[:-1])), sigma0.shape[-1]
+        if ratio_row.shape != (samples,):
+            raise ValueError("ratio_row must have one value per sample")
+        out = np.empty(sigma0.shape, dtype=out_dtype)
+        self._check(self._lib.xsw_detrend(self._h, lines, samples, XSW_F32 if sigma0.dtype == np.float32 else XSW_F64,
+                                          XSW_F32 if out.dtype == np.float32 else XSW_F64, MEM_HOST,
+                                          _ptr(sigma0), _ptr(ratio_row), _ptr(out)), "xsw_detrend")
+        return out
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    """Process-wide context per device (created on first use)."""
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

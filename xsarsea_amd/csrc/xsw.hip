@@ -1,0 +1,446 @@
+// libxsw host side: context, LUT upload, launch logic behind the C ABI of include/xsw.h.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "xsw.h"
+#include "xsw_device.hpp"
+#include "xsw_exhaustive.hpp"
+
+using namespace xsw;
+
+struct xsw_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    DevTables T{};
+    std::vector<void *> co_allocs, cr_allocs;
+    bool have_co = false, have_cr = false;
+    unsigned long long *d_stats = nullptr;
+    bool stats_on = false;
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(xsw_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_err = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail((c), e_ == hipErrorOutOfMemory ? XSW_ENOMEM : XSW_EHIP, "%s: %s (%s:%d)", \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);                       \
+    } while (0)
+
+extern "C" int xsw_version(void) { return XSW_VERSION; }
+
+extern "C" int xsw_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char *xsw_last_error(const xsw_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int xsw_ctx_create(int device, xsw_ctx **out)
+{
+    if (!out) return fail(nullptr, XSW_EINVAL, "ctx out pointer is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(nullptr, XSW_EHIP, "no HIP device available (%s)", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(nullptr, XSW_EINVAL, "device %d out of range [0,%d)", device, n);
+    xsw_ctx *c = new xsw_ctx;
+    c->device = device;
+    HIPCHK(nullptr, hipSetDevice(device));
+    HIPCHK(nullptr, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIPCHK(nullptr, hipMalloc((void **)&c->d_stats, 4 * sizeof(unsigned long long)));
+    HIPCHK(nullptr, hipMemset(c->d_stats, 0, 4 * sizeof(unsigned long long)));
+    *out = c;
+    return XSW_OK;
+}
+
+static void free_all(std::vector<void *> &v)
+{
+    for (void *p : v) (void)hipFree(p);
+    v.clear();
+}
+
+extern "C" int xsw_ctx_destroy(xsw_ctx *c)
+{
+    if (!c) return XSW_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_all(c->co_allocs);
+    free_all(c->cr_allocs);
+    if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return XSW_OK;
+}
+
+extern "C" int xsw_set_stream(xsw_ctx *c, void *s)
+{
+    if (!c) return XSW_EINVAL;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return XSW_OK;
+}
+
+extern "C" int xsw_synchronize(xsw_ctx *c)
+{
+    if (!c) return XSW_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return XSW_OK;
+}
+
+extern "C" int xsw_stats_enable(xsw_ctx *c, int on)
+{
+    if (!c) return XSW_EINVAL;
+    c->stats_on = on != 0;
+    return XSW_OK;
+}
+
+extern "C" int xsw_stats_read(xsw_ctx *c, xsw_stats *out)
+{
+    if (!c || !out) return XSW_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    unsigned long long h[4];
+    HIPCHK(c, hipMemcpy(h, c->d_stats, sizeof h, hipMemcpyDeviceToHost));
+    out->pixels_co = h[0];
+    out->cand_co = h[1];
+    out->pixels_exact = h[2];
+    out->pixels_cr = h[3];
+    return XSW_OK;
+}
+
+// ---------------------------------------------------------------------------------------- LUT upload
+static bool strictly_ascending(const double *a, int n)
+{
+    for (int i = 1; i < n; ++i)
+        if (!(a[i] > a[i - 1])) return false;
+    return true;
+}
+static bool uniform_axis(const double *a, int n)
+{
+    if (n < 2) return false;
+    const double step = (a[n - 1] - a[0]) / (n - 1);
+    if (!(step > 0) || !std::isfinite(step)) return false;
+    for (int i = 0; i < n; ++i)
+        if (std::fabs(a[i] - (a[0] + i * step)) > 1e-6 * step) return false;
+    return true;
+}
+static bool all_finite(const double *a, size_t n)
+{
+    for (size_t i = 0; i < n; ++i)
+        if (!std::isfinite(a[i])) return false;
+    return true;
+}
+
+template <typename V>
+static int upload(xsw_ctx *c, std::vector<void *> &owner, const V *host, size_t count, const V **dev)
+{
+    void *p = nullptr;
+    HIPCHK(c, hipMalloc(&p, count * sizeof(V) + 64));
+    owner.push_back(p);
+    HIPCHK(c, hipMemcpyAsync(p, host, count * sizeof(V), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *dev = (const V *)p;
+    return XSW_OK;
+}
+
+static int upload_co(xsw_ctx *c, const xsw_lut *l)
+{
+    if (!l->db || !l->inc || !l->wspd || !l->phi || l->n_inc < 1 || l->n_wspd < 1 || l->n_phi < 1)
+        return fail(c, XSW_EINVAL, "co-pol LUT: null pointer or empty axis");
+    if (!strictly_ascending(l->inc, l->n_inc) || !strictly_ascending(l->wspd, l->n_wspd) ||
+        !strictly_ascending(l->phi, l->n_phi))
+        return fail(c, XSW_EINVAL, "co-pol LUT: axes must be strictly ascending");
+    if ((int64_t)l->n_wspd * l->n_phi >= (int64_t)1 << 30) return fail(c, XSW_EINVAL, "co-pol LUT too large");
+    free_all(c->co_allocs);
+    c->have_co = false;
+    DevTables &T = c->T;
+    const int nI = l->n_inc, nW = l->n_wspd, nP = l->n_phi;
+    const int ppad = (nP + 3) & ~3, wpad = (nW + 3) & ~3;
+    // padded incidence-major copy
+    std::vector<double> pad((size_t)nI * nW * ppad, 0.0);
+    for (size_t r = 0; r < (size_t)nI * nW; ++r) memcpy(&pad[r * ppad], l->db + r * nP, nP * sizeof(double));
+    int rc;
+    if ((rc = upload(c, c->co_allocs, pad.data(), pad.size(), &T.co))) return rc;
+    std::vector<double>().swap(pad);
+    std::vector<double> wh(nW), cp(nP), sp(nP);
+    for (int i = 0; i < nW; ++i) wh[i] = 0.5 * l->wspd[i];
+    bool trig_ok = true;
+    for (int i = 0; i < nP; ++i) {
+        const double r = l->phi[i] * (M_PI / 180.0);
+        cp[i] = l->cos_phi ? l->cos_phi[i] : std::cos(r);
+        sp[i] = l->sin_phi ? l->sin_phi[i] : std::sin(r);
+        if (std::fabs(cp[i] - std::cos(r)) > 1e-12 || std::fabs(sp[i] - std::sin(r)) > 1e-12) trig_ok = false;
+    }
+    if ((rc = upload(c, c->co_allocs, l->inc, nI, &T.inc))) return rc;
+    if ((rc = upload(c, c->co_allocs, l->wspd, nW, &T.w))) return rc;
+    if ((rc = upload(c, c->co_allocs, wh.data(), nW, &T.wh))) return rc;
+    if ((rc = upload(c, c->co_allocs, l->phi, nP, &T.phi))) return rc;
+    if ((rc = upload(c, c->co_allocs, cp.data(), nP, &T.cphi))) return rc;
+    if ((rc = upload(c, c->co_allocs, sp.data(), nP, &T.sphi))) return rc;
+    // output-side tables: caller's values, or the host libm's (see xsw.h)
+    {
+        std::vector<double> od((size_t)4 * nP), ab((size_t)nW * nP), dd((size_t)4 * nW * nP);
+        for (int k = 0; k < 2; ++k)
+            for (int i = 0; i < nP; ++i) {
+                const double r = (k ? -l->phi[i] : l->phi[i]) * (M_PI / 180.0);
+                od[((size_t)k * nP + i) * 2 + 0] = l->out_dir ? l->out_dir[((size_t)k * nP + i) * 2 + 0] : std::cos(r);
+                od[((size_t)k * nP + i) * 2 + 1] = l->out_dir ? l->out_dir[((size_t)k * nP + i) * 2 + 1] : std::sin(r);
+            }
+        for (int iw = 0; iw < nW; ++iw)
+            for (int i = 0; i < nP; ++i) {
+                const double w = l->wspd[iw];
+                for (int k = 0; k < 2; ++k) {
+                    const double er = od[((size_t)k * nP + i) * 2], ei = od[((size_t)k * nP + i) * 2 + 1];
+                    const double re = w * er, im = w * ei + 0.0 * er;
+                    const size_t o = (((size_t)k * nW + iw) * nP + i) * 2;
+                    if (l->dual_dir) { dd[o] = l->dual_dir[o]; dd[o + 1] = l->dual_dir[o + 1]; }
+                    else { const double ph = std::atan2(im, re); dd[o] = std::cos(ph); dd[o + 1] = std::sin(ph); }
+                    if (k == 0) ab[(size_t)iw * nP + i] = l->abs_co ? l->abs_co[(size_t)iw * nP + i] : std::hypot(re, im);
+                }
+            }
+        if ((rc = upload(c, c->co_allocs, od.data(), od.size(), &T.out_dir))) return rc;
+        if ((rc = upload(c, c->co_allocs, ab.data(), ab.size(), &T.abs_co))) return rc;
+        if ((rc = upload(c, c->co_allocs, dd.data(), dd.size(), &T.dual_dir))) return rc;
+    }
+    T.n_inc = nI; T.n_w = nW; T.n_phi = nP; T.phi_pad = ppad; T.w_pad = wpad;
+    T.phi_180 = (180.0 - (l->phi[nP - 1] - l->phi[0])) < 2.0 ? 1 : 0;  // windspeed.py:152-156
+    T.w0 = l->wspd[0];
+    T.phi0 = l->phi[0];
+    T.phi_last = l->phi[nP - 1];
+    T.inv_wstep = nW > 1 ? (nW - 1) / (l->wspd[nW - 1] - l->wspd[0]) : 0.0;
+    T.inv_dphi = nP > 1 ? (nP - 1) / (l->phi[nP - 1] - l->phi[0]) : 0.0;
+    T.prunable = (nW >= 2 && nP >= 2 && uniform_axis(l->wspd, nW) && uniform_axis(l->phi, nP) && trig_ok &&
+                  (l->phi[nP - 1] - l->phi[0]) <= 360.0 + 1e-9 && all_finite(l->db, (size_t)nI * nW * nP))
+                     ? 1 : 0;
+    // transposed slices for the ray scan
+    double *dT = nullptr;
+    HIPCHK(c, hipMalloc((void **)&dT, (size_t)nI * nP * wpad * sizeof(double) + 64));
+    c->co_allocs.push_back(dT);
+    HIPCHK(c, hipMemsetAsync(dT, 0, (size_t)nI * nP * wpad * sizeof(double), c->stream));
+    dim3 grid((nP + 31) / 32, (nW + 31) / 32, nI);
+    hipLaunchKernelGGL(k_transpose_slices, grid, dim3(256), 0, c->stream, T.co, dT, nW, nP, ppad, wpad);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    T.coT = dT;
+    c->have_co = true;
+    return XSW_OK;
+}
+
+static int upload_cr(xsw_ctx *c, const xsw_lut *l)
+{
+    if (!l->db || !l->inc || !l->wspd || l->n_inc < 1 || l->n_wspd < 1)
+        return fail(c, XSW_EINVAL, "cross-pol LUT: null pointer or empty axis");
+    if (!strictly_ascending(l->inc, l->n_inc) || !strictly_ascending(l->wspd, l->n_wspd))
+        return fail(c, XSW_EINVAL, "cross-pol LUT: axes must be strictly ascending");
+    free_all(c->cr_allocs);
+    c->have_cr = false;
+    DevTables &T = c->T;
+    const int nI = l->n_inc, nW = l->n_wspd, wpad = (nW + 3) & ~3;
+    std::vector<double> pad((size_t)nI * wpad, 0.0), wh(nW);
+    for (int r = 0; r < nI; ++r) memcpy(&pad[(size_t)r * wpad], l->db + (size_t)r * nW, nW * sizeof(double));
+    for (int i = 0; i < nW; ++i) wh[i] = 0.5 * l->wspd[i];
+    int rc;
+    if ((rc = upload(c, c->cr_allocs, pad.data(), pad.size(), &T.cr))) return rc;
+    if ((rc = upload(c, c->cr_allocs, l->inc, nI, &T.inc_cr))) return rc;
+    if ((rc = upload(c, c->cr_allocs, l->wspd, nW, &T.wcr))) return rc;
+    if ((rc = upload(c, c->cr_allocs, wh.data(), nW, &T.wcrh))) return rc;
+    T.n_inc_cr = nI; T.n_wcr = nW; T.wcr_pad = wpad;
+    T.cr_finite = all_finite(l->db, (size_t)nI * nW) ? 1 : 0;
+    c->have_cr = true;
+    return XSW_OK;
+}
+
+extern "C" int xsw_lut_upload(xsw_ctx *c, const xsw_lut *co, const xsw_lut *cr)
+{
+    if (!c) return XSW_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if (co && (rc = upload_co(c, co))) return rc;
+    if (cr && (rc = upload_cr(c, cr))) return rc;
+    return XSW_OK;
+}
+
+// ---------------------------------------------------------------------------------------- invert
+template <typename T, typename TO>
+static int launch_invert(xsw_ctx *c, const KArgs &A, int algo)
+{
+    const long long nstrips = (A.n + 63) / 64;
+    const long long nblocks = (nstrips + 3) / 4;
+    if (nblocks > 0x7fffffffLL) return fail(c, XSW_EINVAL, "raster too large for one launch");
+    if (algo == XSW_ALGO_EXHAUSTIVE) return launch_exhaustive<T, TO>(c->T, A, c->stream) == hipSuccess
+                                                ? XSW_OK : fail(c, XSW_EHIP, "exhaustive launch failed: %s", hipGetErrorString(hipGetLastError()));
+    if (algo == XSW_ALGO_PRUNED)
+        hipLaunchKernelGGL((k_invert<T, TO, 1>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, A);
+    else
+        hipLaunchKernelGGL((k_invert<T, TO, 3>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, A);
+    HIPCHK(c, hipGetLastError());
+    return XSW_OK;
+}
+
+static int dispatch_invert(xsw_ctx *c, const KArgs &A, int dtype, int out_dtype, int algo)
+{
+    if (dtype == XSW_F32 && out_dtype == XSW_F32) return launch_invert<float, float>(c, A, algo);
+    if (dtype == XSW_F32 && out_dtype == XSW_F64) return launch_invert<float, double>(c, A, algo);
+    if (dtype == XSW_F64 && out_dtype == XSW_F32) return launch_invert<double, float>(c, A, algo);
+    return launch_invert<double, double>(c, A, algo);
+}
+
+extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
+{
+    if (!c || !a) return XSW_EINVAL;
+    if (a->lines < 0 || a->samples < 0) return fail(c, XSW_EINVAL, "negative raster shape");
+    if ((a->dtype != XSW_F32 && a->dtype != XSW_F64) || (a->out_dtype != XSW_F32 && a->out_dtype != XSW_F64))
+        return fail(c, XSW_EINVAL, "dtype/out_dtype must be XSW_F32 or XSW_F64");
+    if (a->mem != XSW_MEM_HOST && a->mem != XSW_MEM_DEVICE) return fail(c, XSW_EINVAL, "bad mem kind");
+    if (!a->inc) return fail(c, XSW_EINVAL, "inc is NULL");
+    if (!a->sigma0_co && !a->sigma0_cr) return fail(c, XSW_EINVAL, "neither sigma0_co nor sigma0_cr given");
+    if (a->sigma0_co && !c->have_co) return fail(c, XSW_ENOLUT, "sigma0_co given but no co-pol LUT uploaded");
+    if (a->sigma0_cr && !c->have_cr) return fail(c, XSW_ENOLUT, "sigma0_cr given but no cross-pol LUT uploaded");
+    if (a->sigma0_co && !a->out_co) return fail(c, XSW_EINVAL, "out_co is NULL");
+    if (a->algo < XSW_ALGO_AUTO || a->algo > XSW_ALGO_EXACT) return fail(c, XSW_EINVAL, "unknown algo %d", a->algo);
+    const long long n = (long long)a->lines * a->samples;
+    if (n == 0) return XSW_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+
+    int algo = a->algo == XSW_ALGO_AUTO ? XSW_ALGO_PRUNED : a->algo;
+    if (algo == XSW_ALGO_EXHAUSTIVE && !(a->sigma0_co && c->T.prunable && !a->sigma0_cr))
+        return fail(c, XSW_EINVAL, "XSW_ALGO_EXHAUSTIVE handles mono co-pol on a uniform finite LUT only");
+
+    KArgs A{};
+    A.n = n;
+    A.lines = a->lines;
+    A.samples = a->samples;
+    A.dsig_co = a->dsig_co;
+    A.inv_dsig_co = 1.0 / a->dsig_co;
+    A.dsig_cr_scalar = a->dsig_cr_scalar;
+    A.is_db = a->sigma0_is_db;
+    A.dual_select = a->dual_select;
+    if (!(std::isfinite(A.inv_dsig_co) && A.inv_dsig_co != 0.0) && algo != XSW_ALGO_EXACT) algo = XSW_ALGO_EXACT;
+    if (c->stats_on) {
+        HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 4 * sizeof(unsigned long long), c->stream));
+        A.stats = c->d_stats;
+    }
+
+    if (a->mem == XSW_MEM_DEVICE) {
+        A.inc = a->inc; A.s_co = a->sigma0_co; A.s_cr = a->sigma0_cr; A.dsig_cr = a->dsig_cr; A.anc = a->anc;
+        A.out_co = a->out_co; A.out_cr = a->out_cr; A.out_idx = a->out_idx;
+        return dispatch_invert(c, A, a->dtype, a->out_dtype, algo);
+    }
+
+    // host rasters: stage through device buffers (synchronous)
+    const size_t es = a->dtype == XSW_F32 ? 4 : 8, os = a->out_dtype == XSW_F32 ? 8 : 16;
+    std::vector<void *> tmp;
+    auto stage_in = [&](const void *h, size_t bytes, const void **d) -> int {
+        *d = nullptr;
+        if (!h) return XSW_OK;
+        void *p = nullptr;
+        HIPCHK(c, hipMalloc(&p, bytes));
+        tmp.push_back(p);
+        HIPCHK(c, hipMemcpyAsync(p, h, bytes, hipMemcpyHostToDevice, c->stream));
+        *d = p;
+        return XSW_OK;
+    };
+    auto stage_out = [&](void *h, size_t bytes, void **d) -> int {
+        *d = nullptr;
+        if (!h) return XSW_OK;
+        HIPCHK(c, hipMalloc(d, bytes));
+        tmp.push_back(*d);
+        return XSW_OK;
+    };
+    int rc = XSW_OK;
+    void *d_idx = nullptr;
+    if (!rc) rc = stage_in(a->inc, n * es, &A.inc);
+    if (!rc) rc = stage_in(a->sigma0_co, n * es, &A.s_co);
+    if (!rc) rc = stage_in(a->sigma0_cr, n * es, &A.s_cr);
+    if (!rc) rc = stage_in(a->dsig_cr, n * es, &A.dsig_cr);
+    if (!rc) rc = stage_in(a->anc, n * es * 2, &A.anc);
+    if (!rc) rc = stage_out(a->out_co, n * os, &A.out_co);
+    if (!rc) rc = stage_out(a->out_cr, n * os, &A.out_cr);
+    if (!rc) rc = stage_out(a->out_idx, n * 12, &d_idx);
+    A.out_idx = (int *)d_idx;
+    if (!rc) rc = dispatch_invert(c, A, a->dtype, a->out_dtype, algo);
+    if (!rc && a->out_co && hipMemcpyAsync(a->out_co, A.out_co, n * os, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+        rc = fail(c, XSW_EHIP, "D2H out_co failed");
+    if (!rc && a->out_cr && hipMemcpyAsync(a->out_cr, A.out_cr, n * os, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+        rc = fail(c, XSW_EHIP, "D2H out_cr failed");
+    if (!rc && a->out_idx && hipMemcpyAsync(a->out_idx, d_idx, n * 12, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+        rc = fail(c, XSW_EHIP, "D2H out_idx failed");
+    hipError_t se = hipStreamSynchronize(c->stream);
+    if (!rc && se != hipSuccess) rc = fail(c, XSW_EHIP, "kernel execution failed: %s", hipGetErrorString(se));
+    for (void *p : tmp) (void)hipFree(p);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------- detrend
+template <typename T, typename TO>
+static void launch_detrend(hipStream_t s, const void *in, const double *ratio, void *out, long long lines, long long samples)
+{
+    const long long n = lines * samples;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL((k_detrend<T, TO>), dim3((unsigned)blocks), dim3(256), 0, s, (const T *)in, ratio, (TO *)out, lines, samples);
+}
+
+extern "C" int xsw_detrend(xsw_ctx *c, int64_t lines, int64_t samples, int32_t dtype, int32_t out_dtype, int32_t mem,
+                           const void *sigma0, const double *ratio_row, void *out)
+{
+    if (!c) return XSW_EINVAL;
+    if (lines < 0 || samples < 0 || !sigma0 || !ratio_row || !out) return fail(c, XSW_EINVAL, "bad detrend argument");
+    const long long n = (long long)lines * samples;
+    if (n == 0) return XSW_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t es = dtype == XSW_F32 ? 4 : 8, os = out_dtype == XSW_F32 ? 4 : 8;
+    double *d_ratio = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_ratio, samples * sizeof(double)));
+    hipError_t e = hipMemcpyAsync(d_ratio, ratio_row, samples * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    const void *d_in = sigma0;
+    void *d_out = out, *t_in = nullptr, *t_out = nullptr;
+    if (e == hipSuccess && mem == XSW_MEM_HOST) {
+        e = hipMalloc(&t_in, n * es);
+        if (e == hipSuccess) e = hipMalloc(&t_out, n * os);
+        if (e == hipSuccess) e = hipMemcpyAsync(t_in, sigma0, n * es, hipMemcpyHostToDevice, c->stream);
+        d_in = t_in;
+        d_out = t_out;
+    }
+    if (e == hipSuccess) {
+        if (dtype == XSW_F32 && out_dtype == XSW_F32) launch_detrend<float, float>(c->stream, d_in, d_ratio, d_out, lines, samples);
+        else if (dtype == XSW_F32) launch_detrend<float, double>(c->stream, d_in, d_ratio, d_out, lines, samples);
+        else if (out_dtype == XSW_F32) launch_detrend<double, float>(c->stream, d_in, d_ratio, d_out, lines, samples);
+        else launch_detrend<double, double>(c->stream, d_in, d_ratio, d_out, lines, samples);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && mem == XSW_MEM_HOST) e = hipMemcpyAsync(out, t_out, n * os, hipMemcpyDeviceToHost, c->stream);
+    // the ratio row is a temporary: the call is synchronous in both memory modes
+    hipError_t se = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = se;
+    (void)hipFree(d_ratio);
+    if (t_in) (void)hipFree(t_in);
+    if (t_out) (void)hipFree(t_out);
+    if (e != hipSuccess) return fail(c, XSW_EHIP, "detrend failed: %s", hipGetErrorString(e));
+    return XSW_OK;
+}

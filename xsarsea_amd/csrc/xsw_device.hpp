@@ -1,0 +1,582 @@
+// Device code of libxsw: per-pixel GMF wind inversion for gfx950 (wave64).
+//
+// Work decomposition:
+//   * one wavefront owns a strip of 64 consecutive pixels; lane i loads pixel i (coalesced),
+//     converts sigma0 to dB and finds its incidence bin;
+//   * the wave then walks its pixels one at a time with the pixel's parameters held wave-uniform
+//     (readlane -> SGPRs); the 64 lanes sweep that pixel's candidates and a wave-level argmin
+//     reduction picks the winner; lane i keeps the winner of pixel i;
+//   * lane i finally forms pixel i's complex winds and stores them (coalesced).
+//
+// All decisions are taken in float64.  The reference's argmin (windspeed/windspeed.py:220-232) is
+// reproduced exactly: candidates are screened with a cheap fused form, every candidate within a
+// conservative eps of the screening minimum is re-scored in the reference's operation order
+// (`exact_J_co`), and ties go to the lowest flat index.  This file is compiled with
+// -ffp-contract=off; fused multiply-adds appear only where written explicitly (`fma`).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace xsw {
+
+struct DevTables {
+    // co-pol LUT, dB
+    const double *co;    // [n_inc][n_w][phi_pad]   incidence-major slices (722 KB each at default size)
+    const double *coT;   // [n_inc][n_phi][w_pad]   same slices transposed: one direction, all speeds
+    const double *inc, *w, *wh, *phi, *cphi, *sphi;  // axes; wh = w/2; cphi/sphi = cos/sin(radians(phi))
+    const double *out_dir;   // [2][n_phi][2]       exp(1j*deg2rad(+-phi))
+    const double *abs_co;    // [n_w][n_phi]        |w*exp(1j*deg2rad(phi))|
+    const double *dual_dir;  // [2][n_w][n_phi][2]  exp(1j*angle(sol / sol_2))
+    int n_inc, n_w, n_phi, phi_pad, w_pad;
+    int phi_180;   // windspeed.py:152-156
+    int prunable;  // uniform axes, finite LUT: branch-and-bound allowed
+    double w0, inv_wstep, phi0, phi_last, inv_dphi;
+    // cross-pol LUT, dB
+    const double *cr;    // [n_inc_cr][wcr_pad]
+    const double *inc_cr, *wcr, *wcrh;
+    int n_inc_cr, n_wcr, wcr_pad, cr_finite;
+};
+
+struct KArgs {
+    const void *inc, *s_co, *s_cr, *dsig_cr, *anc;
+    void *out_co, *out_cr;
+    int *out_idx;
+    unsigned long long *stats;  // [4]: pixels_co, cand_co, pixels_exact, pixels_cr (nullable)
+    long long n, lines, samples;
+    double dsig_co, inv_dsig_co, dsig_cr_scalar;
+    int is_db, dual_select;
+};
+
+enum : int { F_NEED_CO = 1, F_NEED_CR = 2, F_EARLY_NAN = 4, F_CO_FINITE = 8 };
+
+// ------------------------------------------------------------------------------------------------
+// wave64 helpers
+__device__ __forceinline__ int rd_lane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ double rd_lane_d(double v, int l)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_min_d(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+    return v;
+}
+// lexicographic (J, idx) minimum over the wave; J never NaN here
+__device__ __forceinline__ void wave_argmin(double &J, int &idx)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        double oJ = __shfl_xor(J, off);
+        int oI = __shfl_xor(idx, off);
+        bool take = (oJ < J) || (oJ == J && oI < idx);
+        J = take ? oJ : J;
+        idx = take ? oI : idx;
+    }
+}
+__device__ __forceinline__ int wave_min_i(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sigma0 -> dB exactly as invert_from_model does on the host (windspeed.py:126-130): the arithmetic
+// runs in the raster's dtype; log10 itself is evaluated in float64 and rounded once.
+__device__ __forceinline__ double to_db(float x, int is_db)
+{
+    if (is_db) return (double)x;
+    float y = x + 1e-15f;
+    float l = (float)log10((double)y);
+    return (double)(10.0f * l);
+}
+__device__ __forceinline__ double to_db(double x, int is_db)
+{
+    if (is_db) return x;
+    return 10.0 * log10(x + 1e-15);
+}
+
+// np.argmin(np.abs(dim - x)) for a strictly ascending axis (windspeed.py:212, :254): first minimum.
+__device__ __forceinline__ int nearest_index(const double *__restrict__ dim, int n, double x)
+{
+    if (isinf(x)) return 0;  // every |dim - x| is inf: argmin returns 0
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (dim[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    if (lo == 0) return 0;
+    if (lo == n) return n - 1;
+    double dl = fabs(dim[lo - 1] - x), dh = fabs(dim[lo] - x);
+    return (dh < dl) ? lo : lo - 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact scoring, reference operation order
+__device__ __forceinline__ double exact_J_co(double w, double c, double s_, double lutv, double s, double a,
+                                             double b, double dsig)
+{
+    double t1 = (w * c - a) * 0.5;   // (x)/2 == x*0.5 exactly
+    double t2 = (w * s_ - b) * 0.5;
+    double jw = t1 * t1 + t2 * t2;
+    double d = (lutv - s) / dsig;
+    return jw + d * d;
+}
+__device__ __forceinline__ double exact_J_cr(double wc, double lutv, double s, double dsig, bool have_co,
+                                             double aco)
+{
+    double d = (lutv - s) / dsig;
+    double J = d * d;                // Jsig_cr
+    if (have_co) {
+        double t = (wc - aco) * 0.5;
+        J = J + t * t;               // Jsig_cr + Jwind_cr  (windspeed.py:261)
+    }
+    return J;
+}
+
+// Full (wspd x phi) sweep in the reference's arithmetic with numpy.argmin semantics (first minimum;
+// a NaN anywhere wins, first NaN).  Wave-cooperative, every argument wave-uniform.  Any LUT.
+__device__ __forceinline__ int exact_scan_co(const DevTables &L, int i_inc, double s, double a, double b,
+                                          double dsig, int lane)
+{
+    const double *__restrict__ slice = L.co + (size_t)i_inc * L.n_w * L.phi_pad;
+    double bestJ = __builtin_inf();
+    int bestI = 0x7fffffff, nanI = 0x7fffffff;
+    for (int iw = 0; iw < L.n_w; ++iw) {
+        const double w = L.w[iw];
+        for (int ip = lane; ip < L.n_phi; ip += 64) {
+            double J = exact_J_co(w, L.cphi[ip], L.sphi[ip], slice[(size_t)iw * L.phi_pad + ip], s, a, b, dsig);
+            int flat = iw * L.n_phi + ip;
+            if (J != J) nanI = min(nanI, flat);
+            else if (J < bestJ || bestI == 0x7fffffff) { bestJ = J; bestI = flat; }
+        }
+    }
+    nanI = wave_min_i(nanI);
+    if (nanI != 0x7fffffff) return nanI;
+    wave_argmin(bestJ, bestI);
+    return bestI;
+}
+
+__device__ __forceinline__ int exact_scan_cr(const DevTables &L, int i_inc, double s, double dsig, bool have_co,
+                                          double aco, int lane)
+{
+    const double *__restrict__ row = L.cr + (size_t)i_inc * L.wcr_pad;
+    double bestJ = __builtin_inf();
+    int bestI = 0x7fffffff, nanI = 0x7fffffff;
+    for (int k = lane; k < L.n_wcr; k += 64) {
+        double J = exact_J_cr(L.wcr[k], row[k], s, dsig, have_co, aco);
+        if (J != J) nanI = min(nanI, k);
+        else if (J < bestJ || bestI == 0x7fffffff) { bestJ = J; bestI = k; }
+    }
+    nanI = wave_min_i(nanI);
+    if (nanI != 0x7fffffff) return nanI;
+    wave_argmin(bestJ, bestI);
+    return bestI;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Branch-and-bound co-pol search (tests/prune_model.py is the executable specification).
+// Preconditions (caller): L.prunable, s/a/b finite, b already |b| when phi_180.
+// Returns the flat index iw*n_phi+ip (wave-uniform).  `cand` accumulates scored candidates.
+__device__ __forceinline__ int pruned_search_co(const DevTables &L, int i_inc, double s, double a, double b,
+                                                double dsig, double inv_dsig, int lane, unsigned &cand,
+                                                bool &went_exact)
+{
+    const double ah = 0.5 * a, bh = 0.5 * b;
+    const double m2 = ah * ah + bh * bh;
+    const double sn = -s * inv_dsig;
+    const double mag = sqrt(a * a + b * b);
+    double theta = atan2(b, a) * 57.295779513082320877;  // degrees
+    if (theta < L.phi0) theta += 360.0;
+
+    // 1. upper bound along the direction nearest to the ancillary wind (transposed slice: contiguous)
+    int ipr = (int)rint(fmin(fmax((theta - L.phi0) * L.inv_dphi, 0.0), (double)(L.n_phi - 1)));
+    const double ur = 2.0 * (ah * L.cphi[ipr] + bh * L.sphi[ipr]);
+    const double *__restrict__ ray = L.coT + ((size_t)i_inc * L.n_phi + ipr) * L.w_pad;
+    double rbest = __builtin_inf();
+    for (int iw = lane; iw < L.n_w; iw += 64) {
+        double wh = L.wh[iw];
+        double dd = fma(ray[iw], inv_dsig, sn);
+        double J = fma(dd, dd, wh * (wh - ur));
+        rbest = fmin(rbest, J);
+    }
+    rbest = wave_min_d(rbest);
+    cand += (unsigned)L.n_w;
+    double jub = (rbest + m2) * (1.0 + 1e-9) + 1e-9;
+
+    // 2. polar bounding box of the disc |c - m| <= R
+    const double R = 2.0 * sqrt(jub);
+    const double nwd = (double)L.n_w;
+    int w_lo = (int)floor(fmin(fmax((mag - R - L.w0) * L.inv_wstep, -4.0), nwd + 4.0)) - 1;
+    int w_hi = (int)ceil(fmin(fmax((mag + R - L.w0) * L.inv_wstep, -4.0), nwd + 4.0)) + 1;
+    w_lo = max(w_lo, 0);
+    w_hi = min(w_hi, L.n_w - 1);
+    int ip_lo = 0, ip_hi = L.n_phi - 1;
+    if (R < mag * (1.0 - 1e-12)) {
+        const double half = asin(R / mag) * 57.295779513082320877;
+        const double nphd = (double)L.n_phi;
+        int plo = (int)floor(fmin(fmax((theta - half - L.phi0) * L.inv_dphi, -4.0), nphd + 4.0)) - 1;
+        int phi_i = (int)ceil(fmin(fmax((theta + half - L.phi0) * L.inv_dphi, -4.0), nphd + 4.0)) + 1;
+        if (L.phi_last - theta <= 180.0 && theta - L.phi0 <= 180.0) {
+            ip_lo = max(plo, 0);
+            ip_hi = min(phi_i, L.n_phi - 1);
+        } else if (plo >= 0 && phi_i <= L.n_phi - 1) {
+            ip_lo = plo;
+            ip_hi = phi_i;
+        }
+    }
+    const int nrows = w_hi - w_lo + 1, ncols = ip_hi - ip_lo + 1;
+    if (nrows <= 0 || ncols <= 0) {  // cannot happen in exact arithmetic; stay safe
+        went_exact = true;
+        return exact_scan_co(L, i_inc, s, a, b, dsig, lane);
+    }
+    cand += (unsigned)(nrows * ncols);
+
+    // 3. screen the box: lanes = directions (<= 64 per chunk), narrow chunks fold several speed rows
+    const double *__restrict__ slice = L.co + (size_t)i_inc * L.n_w * L.phi_pad;
+    double best = __builtin_inf(), second = __builtin_inf();
+    int bidx = 0x7fffffff;
+    for (int c0 = 0; c0 < ncols; c0 += 64) {
+        const int width = min(64, ncols - c0);
+        const int sh = (width <= 1) ? 0 : (32 - __clz(width - 1));  // log2(pow2ceil(width))
+        const int G = 64 >> sh;
+        const int col = lane & ((1 << sh) - 1), grp = lane >> sh;
+        const bool act = col < width;
+        const int ip = ip_lo + c0 + (act ? col : 0);
+        const double U = 2.0 * (ah * L.cphi[ip] + bh * L.sphi[ip]);
+        const double *__restrict__ colp = slice + ip;
+        for (int r0 = 0; r0 < nrows; r0 += G) {
+            const int r = r0 + grp;
+            const bool ok = act && (r < nrows);
+            const int iw = w_lo + (ok ? r : 0);
+            const double wh = L.wh[iw];
+            const double dd = fma(colp[(size_t)iw * L.phi_pad], inv_dsig, sn);
+            double J = fma(dd, dd, wh * (wh - U));
+            J = ok ? J : __builtin_inf();
+            second = fmin(second, fmax(J, best));
+            if (J < best) { best = J; bidx = iw * L.n_phi + ip; }
+        }
+    }
+
+    // 4. exact re-scoring of everything within eps of the screening minimum
+    const double gmin = wave_min_d(best);
+    const double T = gmin + 1e-9 * (1.0 + fabs(gmin) + m2);
+    if (__ballot(second <= T) != 0ULL || !(gmin < __builtin_inf())) {
+        // two near-minimal candidates met in one lane (or nothing finite): settle it the slow way
+        went_exact = true;
+        return exact_scan_co(L, i_inc, s, a, b, dsig, lane);
+    }
+    unsigned long long surv = __ballot(best <= T);
+    double eJ = __builtin_inf();
+    int eI = 0x7fffffff;
+    while (surv) {
+        const int l = __ffsll((long long)surv) - 1;
+        surv &= surv - 1;
+        const int flat = rd_lane_i(bidx, l);
+        const int iw = flat / L.n_phi, ip = flat - iw * L.n_phi;
+        const double J = exact_J_co(L.w[iw], L.cphi[ip], L.sphi[ip], slice[(size_t)iw * L.phi_pad + ip], s, a, b, dsig);
+        if (J < eJ || (J == eJ && flat < eI)) { eJ = J; eI = flat; }
+    }
+    return eI;
+}
+
+// Cross-pol 1-D search (windspeed.py:252-269): screening + exact refine, full speed axis.
+__device__ __forceinline__ int search_cr(const DevTables &L, int i_inc, double s, double dsig, bool have_co,
+                                         double aco, int lane, bool fast_ok)
+{
+    const double inv = 1.0 / dsig;
+    if (!fast_ok || !isfinite(inv) || !isfinite(s) || (have_co && !isfinite(aco)))
+        return exact_scan_cr(L, i_inc, s, dsig, have_co, aco, lane);
+    const double *__restrict__ row = L.cr + (size_t)i_inc * L.wcr_pad;
+    const double sn = -s * inv;
+    const double ach = 0.5 * aco;
+    double best = __builtin_inf(), second = __builtin_inf();
+    int bidx = 0x7fffffff;
+    for (int k0 = 0; k0 < L.n_wcr; k0 += 64) {
+        const int k = k0 + lane;
+        const bool ok = k < L.n_wcr;
+        const int kk = ok ? k : 0;
+        const double dd = fma(row[kk], inv, sn);
+        double J = dd * dd;
+        if (have_co) {
+            const double t = L.wcrh[kk] - ach;
+            J = fma(t, t, J);
+        }
+        J = ok ? J : __builtin_inf();
+        second = fmin(second, fmax(J, best));
+        if (J < best) { best = J; bidx = kk; }
+    }
+    const double gmin = wave_min_d(best);
+    const double T = gmin + 1e-9 * (1.0 + fabs(gmin));
+    if (__ballot(second <= T) != 0ULL || !(gmin < __builtin_inf()))
+        return exact_scan_cr(L, i_inc, s, dsig, have_co, aco, lane);
+    unsigned long long surv = __ballot(best <= T);
+    double eJ = __builtin_inf();
+    int eI = 0x7fffffff;
+    while (surv) {
+        const int l = __ffsll((long long)surv) - 1;
+        surv &= surv - 1;
+        const int k = rd_lane_i(bidx, l);
+        const double J = exact_J_cr(L.wcr[k], row[k], s, dsig, have_co, aco);
+        if (J < eJ || (J == eJ && k < eI)) { eJ = J; eI = k; }
+    }
+    return eI;
+}
+
+// hypot as glibc >= 2.35 computes it without FMA (sysdeps/ieee754/dbl-64/e_hypot.c, after C. Borges,
+// "An improved algorithm for hypot(a,b)"): correctly rounded in all but very rare cases.  Verified
+// bit-identical to numpy.hypot on 2e6 random pairs (tests/test_oracle.py).  Used for |wind_dual| in
+// the fused dual-pol select.
+__device__ __forceinline__ double hypot_glibc(double x, double y)
+{
+    if (!isfinite(x) || !isfinite(y)) return (isinf(x) || isinf(y)) ? __builtin_inf() : x + y;
+    x = fabs(x); y = fabs(y);
+    const double ax = x < y ? y : x, ay = x < y ? x : y;
+    if (ax >= ay * 0x1p54) return ax + ay;
+    if (ax > 0x1p511 || ay < 0x1p-459) return hypot(ax, ay);  // far outside any wind value
+    double h = sqrt(ax * ax + ay * ay), t1, t2;
+    if (h <= 2.0 * ay) {
+        const double delta = h - ay;
+        t1 = ax * (2.0 * delta - ax);
+        t2 = (delta - 2.0 * (ax - ay)) * delta;
+    } else {
+        const double delta = h - ax;
+        t1 = 2.0 * delta * (ax - 2.0 * ay);
+        t2 = (4.0 * delta - ay) * ay + delta * delta;
+    }
+    h -= (t1 + t2) / (2.0 * h);
+    return h;
+}
+
+// numpy's complex128 true-divide (Smith) followed by np.angle, for the +phi / -phi choice
+// (windspeed.py:236-242).
+__device__ __forceinline__ double angle_of_quotient(double ar, double ai, double br, double bi)
+{
+    double qr, qi;
+    const double abr = fabs(br), abi = fabs(bi);
+    if (abr >= abi) {
+        if (abr == 0.0 && abi == 0.0) { qr = ar / abr; qi = ai / abi; }
+        else {
+            const double rat = bi / br, scl = 1.0 / (br + bi * rat);
+            qr = (ar + ai * rat) * scl;
+            qi = (ai - ar * rat) * scl;
+        }
+    } else {
+        const double rat = br / bi, scl = 1.0 / (bi + br * rat);
+        qr = (ar * rat + ai) * scl;
+        qi = (ai * rat - ar) * scl;
+    }
+    return atan2(qi, qr);
+}
+
+template <typename T> struct Cx;
+template <> struct Cx<float> { typedef float2 type; };
+template <> struct Cx<double> { typedef double2 type; };
+
+template <typename T> __device__ __forceinline__ double ld(const void *p, long long i) { return (double)((const T *)p)[i]; }
+
+// ------------------------------------------------------------------------------------------------
+// Per-lane pixel state shared by the kernels.
+struct Pixel {
+    double s_co, s_cr, dsig, a_re, a_im, b_eff;
+    int flags, i_inc, i_inc_cr;
+};
+
+// Loads pixel `il` (already clamped in range), converts to dB, classifies it (windspeed.py:198-209,
+// :252) and finds its incidence bins (:212, :254).
+template <typename T>
+__device__ __forceinline__ void load_pixel(const DevTables &L, const KArgs &A, long long il, bool in, Pixel &P)
+{
+    const double nan = __builtin_nan("");
+    const double inc = ld<T>(A.inc, il);
+    P.s_co = nan; P.s_cr = nan; P.dsig = nan; P.a_re = nan; P.a_im = nan;
+    if (A.s_co) P.s_co = to_db(((const T *)A.s_co)[il], A.is_db);
+    if (A.s_cr) {
+        const T x = ((const T *)A.s_cr)[il];
+        P.s_cr = to_db(x, A.is_db);
+        // scalar dsig_cr is broadcast as sigma0_cr*0 + dsig_cr in the raster dtype (windspeed.py:122-123)
+        P.dsig = A.dsig_cr ? (double)((const T *)A.dsig_cr)[il] : (double)(T)(x * (T)0 + (T)A.dsig_cr_scalar);
+    }
+    if (A.anc) {
+        typename Cx<T>::type z = ((const typename Cx<T>::type *)A.anc)[il];
+        P.a_re = (double)z.x;
+        P.a_im = (double)z.y;
+    }
+    P.flags = 0; P.i_inc = 0; P.i_inc_cr = 0;
+    if (in) {
+        const bool anc_nan = (P.a_re != P.a_re || P.a_im != P.a_im) && !(isinf(P.a_re) || isinf(P.a_im));  // isnan(hypot)
+        if (inc != inc || (P.s_co == P.s_co && anc_nan)) P.flags = F_EARLY_NAN;   // windspeed.py:198-207
+        else {
+            if (P.s_co == P.s_co) {
+                P.flags |= F_NEED_CO;
+                P.i_inc = nearest_index(L.inc, L.n_inc, inc);
+                if (isfinite(P.s_co) && isfinite(P.a_re) && isfinite(P.a_im)) P.flags |= F_CO_FINITE;
+            }
+            if (P.s_cr == P.s_cr && P.dsig == P.dsig) {
+                P.flags |= F_NEED_CR;
+                P.i_inc_cr = nearest_index(L.inc_cr, L.n_inc_cr, inc);
+            }
+        }
+    }
+    P.b_eff = L.phi_180 ? fabs(P.a_im) : P.a_im;  // windspeed.py:218-219
+}
+
+// Forms pixel i's complex winds from the winning indices and stores them (windspeed.py:231-250,
+// :269-281, dual select :426-428).
+template <typename TO>
+__device__ __forceinline__ void store_pixel(const DevTables &L, const KArgs &A, long long i, const Pixel &P,
+                                            int my_flat, int my_icr)
+{
+    const double nan = __builtin_nan("");
+    double co_re, co_im, cr_re, cr_im;
+    int o_iw = -1, o_ip = -1;
+    if (P.flags & F_EARLY_NAN) {
+        co_re = nan; co_im = 0.0; cr_re = nan; cr_im = 0.0;  // out[i] = np.nan -> (nan + 0j)
+    } else {
+        int sgn = 0;
+        if (P.flags & F_NEED_CO) {
+            o_iw = my_flat / L.n_phi;
+            o_ip = my_flat - o_iw * L.n_phi;
+            const double w = L.w[o_iw];
+            const double2 e1 = ((const double2 *)L.out_dir)[o_ip];
+            const double s1r = w * e1.x, s1i = w * e1.y + 0.0 * e1.x;  // float * complex (:235)
+            co_re = s1r; co_im = s1i;
+            if (L.phi_180) {
+                const double2 e2 = ((const double2 *)L.out_dir)[L.n_phi + o_ip];
+                const double s2r = w * e2.x, s2i = w * e2.y + 0.0 * e2.x;
+                const double d1 = angle_of_quotient(P.a_re, P.a_im, s1r, s1i);
+                const double d2 = angle_of_quotient(P.a_re, P.a_im, s2r, s2i);
+                if (!(fabs(d1) <= fabs(d2))) { co_re = s2r; co_im = s2i; sgn = 1; }
+            }
+        } else {
+            co_re = nan; co_im = nan;  // np.nan * 1j
+        }
+        if (P.flags & F_NEED_CR) {
+            const double wd = L.wcr[my_icr];
+            if (P.flags & F_NEED_CO) {  // |wind_co| is never NaN once a co-pol search ran
+                const double2 u = ((const double2 *)L.dual_dir)[((size_t)sgn * L.n_w + o_iw) * L.n_phi + o_ip];
+                cr_re = wd * u.x;
+                cr_im = wd * u.y + 0.0 * u.x;
+            } else {
+                cr_re = wd; cr_im = 0.0;  // exp(1j*0)
+            }
+        } else {
+            cr_re = nan; cr_im = nan;
+        }
+    }
+    typedef typename Cx<TO>::type cx_t;
+    if (A.out_co) {
+        cx_t z; z.x = (TO)co_re; z.y = (TO)co_im;
+        ((cx_t *)A.out_co)[i] = z;
+    }
+    if (A.out_cr) {
+        if (A.dual_select) {  // xr.where((|co| < 5) | (|dual| < 5), co, dual)  (windspeed.py:426-428)
+            const double aco = (P.flags & F_NEED_CO) ? L.abs_co[(size_t)o_iw * L.n_phi + o_ip] : hypot_glibc(co_re, co_im);
+            if (aco < 5.0 || hypot_glibc(cr_re, cr_im) < 5.0) { cr_re = co_re; cr_im = co_im; }
+        }
+        cx_t z; z.x = (TO)cr_re; z.y = (TO)cr_im;
+        ((cx_t *)A.out_cr)[i] = z;
+    }
+    if (A.out_idx) {
+        A.out_idx[3 * i + 0] = o_iw;
+        A.out_idx[3 * i + 1] = o_ip;
+        A.out_idx[3 * i + 2] = (P.flags & F_NEED_CR) ? my_icr : -1;
+    }
+}
+
+// Production kernel.  ALGO: 1 = branch-and-bound, 3 = exact full sweep for every pixel.
+template <typename T, typename TO, int ALGO>
+__global__ __launch_bounds__(256) void k_invert(DevTables L, KArgs A)
+{
+    const int lane = threadIdx.x & 63;
+    const long long strip = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long i = strip * 64 + lane;
+    if (strip * 64 >= A.n) return;  // whole wave out of range
+    const bool in = i < A.n;
+    const double nan = __builtin_nan("");
+
+    Pixel P;
+    load_pixel<T>(L, A, in ? i : (A.n - 1), in, P);
+
+    // ---- wave-cooperative searches, one pixel at a time, parameters wave-uniform
+    int my_flat = -1, my_icr = -1;
+    unsigned cand = 0, n_exact = 0, n_co = 0, n_cr = 0;
+    unsigned long long todo = __ballot((P.flags & (F_NEED_CO | F_NEED_CR)) != 0);
+    while (todo) {
+        const int p = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int uf = rd_lane_i(P.flags, p);
+        double aco = nan;
+        bool have_co = false;
+        if (uf & F_NEED_CO) {
+            const int u_iinc = rd_lane_i(P.i_inc, p);
+            const double us = rd_lane_d(P.s_co, p), ua = rd_lane_d(P.a_re, p), ub = rd_lane_d(P.b_eff, p);
+            int flat;
+            bool went_exact = false;
+            if (ALGO == 1 && L.prunable && (uf & F_CO_FINITE))
+                flat = pruned_search_co(L, u_iinc, us, ua, ub, A.dsig_co, A.inv_dsig_co, lane, cand, went_exact);
+            else {
+                flat = exact_scan_co(L, u_iinc, us, ua, ub, A.dsig_co, lane);
+                went_exact = true;
+                cand += (unsigned)(L.n_w * L.n_phi);
+            }
+            n_exact += went_exact ? 1u : 0u;
+            n_co += 1u;
+            if (lane == p) my_flat = flat;
+            aco = L.abs_co[flat];  // np.abs(wind_co): table [n_w][n_phi], flat = iw*n_phi + ip
+            have_co = aco == aco;
+        }
+        if (uf & F_NEED_CR) {
+            const int u_iinc = rd_lane_i(P.i_inc_cr, p);
+            const double us = rd_lane_d(P.s_cr, p), ud = rd_lane_d(P.dsig, p);
+            const int k = search_cr(L, u_iinc, us, ud, have_co, aco, lane, ALGO == 1 && L.cr_finite);
+            n_cr += 1u;
+            if (lane == p) my_icr = k;
+        }
+    }
+    if (A.stats && lane == 0) {
+        atomicAdd(&A.stats[0], (unsigned long long)n_co);
+        atomicAdd(&A.stats[1], (unsigned long long)cand);
+        atomicAdd(&A.stats[2], (unsigned long long)n_exact);
+        atomicAdd(&A.stats[3], (unsigned long long)n_cr);
+    }
+    if (in) store_pixel<TO>(L, A, i, P, my_flat, my_icr);
+}
+
+// [n_inc][n_w][phi_pad] -> [n_inc][n_phi][w_pad], 32x32 LDS tiles
+__global__ __launch_bounds__(256) void k_transpose_slices(const double *__restrict__ src, double *__restrict__ dst,
+                                                           int n_w, int n_phi, int phi_pad, int w_pad)
+{
+    __shared__ double tile[32][33];
+    const int s = blockIdx.z;
+    const double *in = src + (size_t)s * n_w * phi_pad;
+    double *out = dst + (size_t)s * n_phi * w_pad;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int p0 = blockIdx.x * 32, w0 = blockIdx.y * 32;
+    for (int j = ty; j < 32; j += 8) {
+        int w = w0 + j, p = p0 + tx;
+        tile[j][tx] = (w < n_w && p < n_phi) ? in[(size_t)w * phi_pad + p] : 0.0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        int p = p0 + j, w = w0 + tx;
+        if (p < n_phi && w < n_w) out[(size_t)p * w_pad + w] = tile[tx][j];
+    }
+}
+
+// sigma0_detrend's per-pixel work (detrend.py:64): out = sigma0 / ratio[sample]
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void k_detrend(const T *__restrict__ sigma0, const double *__restrict__ ratio,
+                                                 TO *__restrict__ out, long long lines, long long samples)
+{
+    const long long n = lines * samples;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long sidx = i % samples;
+        out[i] = (TO)((double)sigma0[i] / ratio[sidx]);
+    }
+}
+
+}  // namespace xsw
