@@ -109,8 +109,10 @@ int xsw_ctx_create(int device, xsw_ctx **ctx);
 int xsw_ctx_destroy(xsw_ctx *ctx);
 const char *xsw_last_error(const xsw_ctx *ctx); /* ctx may be NULL: last creation error */
 
-/* Launch on a caller-provided hipStream_t (e.g. torch's current stream); NULL = the context's own. */
+/* Launch on a caller-provided hipStream_t (e.g. torch's current stream; NULL = the default stream).
+ * A new context launches on a private non-blocking stream; xsw_use_own_stream() returns to it. */
 int xsw_set_stream(xsw_ctx *ctx, void *hip_stream);
+int xsw_use_own_stream(xsw_ctx *ctx);
 int xsw_synchronize(xsw_ctx *ctx);
 
 /* Replaces Model.to_lut(...) -> closure arrays (windspeed.py:144-181).  Either may be NULL (kept). */

@@ -1,2 +1,11 @@
-"""xsarsea_amd: MI355X-native wind-inversion hot path of xsarsea."""
+"""xsarsea_amd: MI355X-native (gfx950) wind-inversion hot path of xsarsea.
+
+Drop-in for `xsarsea.windspeed.invert_from_model` and `xsarsea.sigma0_detrend`: same signatures,
+same container conventions, results identical to the reference's CPU path; the per-pixel work runs
+in hand-written HIP kernels behind the C ABI of include/xsw.h (no CPU fallback).  See DESIGN.md.
+"""
 __version__ = "0.1.0"
+__all__ = ["sigma0_detrend", "windspeed", "options"]
+
+from . import options, windspeed
+from .detrend import sigma0_detrend

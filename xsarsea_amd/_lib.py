@@ -13,7 +13,7 @@ ALGO_AUTO, ALGO_PRUNED, ALGO_EXHAUSTIVE, ALGO_EXACT = 0, 1, 2, 3
 ALGOS = {"auto": ALGO_AUTO, "pruned": ALGO_PRUNED, "exhaustive": ALGO_EXHAUSTIVE, "exact": ALGO_EXACT}
 
 EXPORTS = (
-    "xsw_version", "xsw_device_count", "xsw_ctx_create", "xsw_ctx_destroy", "xsw_last_error", "xsw_set_stream",
+    "xsw_version", "xsw_device_count", "xsw_ctx_create", "xsw_ctx_destroy", "xsw_last_error", "xsw_set_stream", "xsw_use_own_stream",
     "xsw_synchronize", "xsw_lut_upload", "xsw_invert", "xsw_stats_enable", "xsw_stats_read", "xsw_detrend",
 )
 
@@ -64,6 +64,7 @@ def load():
         lib.xsw_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         lib.xsw_ctx_destroy.argtypes = [ctypes.c_void_p]
         lib.xsw_set_stream.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.xsw_use_own_stream.argtypes = [ctypes.c_void_p]
         lib.xsw_synchronize.argtypes = [ctypes.c_void_p]
         lib.xsw_lut_upload.argtypes = [ctypes.c_void_p, ctypes.POINTER(LutStruct), ctypes.POINTER(LutStruct)]
         lib.xsw_invert.argtypes = [ctypes.c_void_p, ctypes.POINTER(InvertArgs)]
@@ -120,7 +121,11 @@ class Context:
             raise XswError(f"{what} failed ({rc}): {self._lib.xsw_last_error(self._h).decode()}")
 
     def set_stream(self, stream_handle):
+        """Launch on this hipStream_t handle (int; 0 = the device's default stream)."""
         self._check(self._lib.xsw_set_stream(self._h, ctypes.c_void_p(stream_handle or 0)), "xsw_set_stream")
+
+    def use_own_stream(self):
+        self._check(self._lib.xsw_use_own_stream(self._h), "xsw_use_own_stream")
 
     def synchronize(self):
         self._check(self._lib.xsw_synchronize(self._h), "xsw_synchronize")

@@ -100,7 +100,14 @@ extern "C" int xsw_ctx_destroy(xsw_ctx *c)
 extern "C" int xsw_set_stream(xsw_ctx *c, void *s)
 {
     if (!c) return XSW_EINVAL;
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->stream = (hipStream_t)s;  // NULL is a valid handle: the device's default stream
+    return XSW_OK;
+}
+
+extern "C" int xsw_use_own_stream(xsw_ctx *c)
+{
+    if (!c) return XSW_EINVAL;
+    c->stream = c->own_stream;
     return XSW_OK;
 }
 

@@ -1,0 +1,66 @@
+"""`sigma0_detrend`: drop-in for `xsarsea.sigma0_detrend` (reference: src/xsarsea/detrend.py:8-68).
+
+out[l, s] = sigma0[l, s] / (g[s] / nanmean(g)),   g[s] = GMF(inc[line 0, s], wind_speed_gmf, wind_dir_gmf)
+
+The GMF row (one value per sample) is evaluated on the host by the model; the per-pixel divide --
+the only per-pixel work, purely HBM-bound -- runs on the device (`xsw_detrend`, include/xsw.h).
+"""
+import logging
+import time
+
+import numpy as np
+
+from . import _lib, options
+from .windspeed.lut import xr
+from .windspeed.models import get_model
+
+logger = logging.getLogger("xsarsea")
+
+
+def sigma0_detrend(sigma0, inc_angle, wind_speed_gmf=np.array([10.0]), wind_dir_gmf=np.array([45.0]),
+                   model="gmf_cmod5n"):
+    """Remove the incidence-angle trend of `sigma0` with a GMF evaluated at a fixed wind.
+
+    Parameters
+    ----------
+    sigma0 : array (line, sample)
+        linear sigma0 (xarray.DataArray or numpy)
+    inc_angle : array (line, sample)
+        incidence angle in degrees, same shape
+    wind_speed_gmf, wind_dir_gmf : 0-D or size-1 arrays
+        wind speed (m/s) and direction (deg, relative to antenna) fed to the GMF
+    model : str | Model
+
+    Returns
+    -------
+    detrended sigma0 (float64), same container type as `sigma0`
+    """
+    t0 = time.time()
+    model = get_model(model)
+    wind_speed_gmf, wind_dir_gmf = np.asarray(wind_speed_gmf), np.asarray(wind_dir_gmf)
+    if wind_speed_gmf.ndim > 1 or wind_dir_gmf.ndim > 1:
+        raise ValueError("wind_speed_gmf and wind_dir_gmf must be 0D or 1D")
+    for var in (wind_speed_gmf, wind_dir_gmf):
+        if var.ndim == 1 and var.size > 1:
+            raise ValueError("wind_speed_gmf and wind_dir_gmf size must be 1 or 0")
+
+    is_xr = xr is not None and isinstance(inc_angle, xr.DataArray)
+    inc_row = np.asarray(inc_angle.isel(line=0) if is_xr else np.asarray(inc_angle)[0], dtype=np.float64)
+    if hasattr(model, "_gmf_pyfunc_scalar"):
+        g = np.asarray(model(inc_row, np.broadcast_to(wind_speed_gmf.reshape(-1)[:1], inc_row.shape),
+                             np.broadcast_to(wind_dir_gmf.reshape(-1)[:1], inc_row.shape), broadcast=True),
+                       dtype=np.float64)
+    else:  # table model: (sample, 1, 1) grid, squeezed (detrend.py:57-61)
+        g = np.asarray(model(inc_row, wind_speed_gmf.reshape(-1)[:1].astype(np.float64),
+                             wind_dir_gmf.reshape(-1)[:1].astype(np.float64)), dtype=np.float64).reshape(inc_row.shape)
+    ratio = g / np.nanmean(g)
+
+    values = np.asarray(sigma0)
+    ctx = _lib.default_context(options.device)
+    out = ctx.detrend_host(values.reshape(-1, values.shape[-1]), ratio).reshape(values.shape)
+    logger.info("timing sigma0_detrend : %.2fs.", time.time() - t0)
+    if xr is not None and isinstance(sigma0, xr.DataArray):
+        res = sigma0.copy(data=out) if sigma0.dtype == out.dtype else sigma0.astype(np.float64).copy(data=out)
+        res.attrs["comment"] = f"detrended with model {model.name}"
+        return res
+    return out

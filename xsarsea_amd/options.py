@@ -1,0 +1,15 @@
+"""Run-time switches of the device path (module attributes; set them before calling the API)."""
+
+#: HIP device index used by the drop-in API (one process per GPU: set it to LOCAL_RANK).
+device = 0
+
+#: sigma0 -> dB conversion (windspeed.py:126-130).
+#:   "auto"  : float64 rasters are converted on the device; float32 rasters on the host with numpy,
+#:             because numpy's float32 log10 is a platform-specific few-ulp SIMD routine and only the
+#:             host can reproduce its bits (DESIGN.md "float32 dB").
+#:   True    : always on the device (fastest; float32 log10 correctly rounded instead of numpy's).
+#:   False   : always on the host.
+db_on_device = "auto"
+
+#: search kernel: "auto" | "pruned" | "exhaustive" | "exact"  (include/xsw.h XSW_ALGO_*)
+algo = "auto"

@@ -1,0 +1,84 @@
+"""Glue between the model layer and libxsw: LUT upload cache and the numpy-in/numpy-out call that
+stands where the reference's `_invert_from_model_numpy` stands (windspeed/windspeed.py:132-331)."""
+import numpy as np
+
+from .. import _lib, options
+
+
+def host_tables(wspd, phi):
+    """Tables of xsw_lut whose last bit depends on the math library, evaluated with numpy by the same
+    expressions the reference uses (windspeed.py:167-168, :235-236, :257, :270-276), so that device
+    results carry exactly the bits this host's CPU path would produce."""
+    wspd = np.asarray(wspd, dtype=np.float64)
+    phi = np.asarray(phi, dtype=np.float64)
+    e = np.stack([np.exp(1j * np.deg2rad(phi)), np.exp(1j * np.deg2rad(-phi))])  # (2, n_phi)
+    sol = wspd[None, :, None] * e[:, None, :]  # (2, n_wspd, n_phi)
+    unit = np.exp(1j * np.angle(sol))
+    return dict(cos_phi=np.cos(np.radians(phi)), sin_phi=np.sin(np.radians(phi)),
+                out_dir=np.stack([e.real, e.imag], axis=-1), abs_co=np.abs(sol[0]),
+                dual_dir=np.stack([unit.real, unit.imag], axis=-1))
+
+
+def _co_dict(lut):
+    return dict(db=lut.values, inc=lut.incidence, wspd=lut.wspd, phi=lut.phi, **host_tables(lut.wspd, lut.phi))
+
+
+def _cr_dict(lut):
+    return dict(db=lut.values, inc=lut.incidence, wspd=lut.wspd)
+
+
+def ensure_luts(ctx, lut_co, lut_cr):
+    """Upload the dB LUT objects unless this context already holds exactly them."""
+    key_co, key_cr = ctx.lut_key
+    up_co = lut_co is not None and key_co is not lut_co
+    up_cr = lut_cr is not None and key_cr is not lut_cr
+    if up_co or up_cr:
+        ctx.upload_luts(co=_co_dict(lut_co) if up_co else None, cr=_cr_dict(lut_cr) if up_cr else None)
+        ctx.lut_key = (lut_co if up_co else key_co, lut_cr if up_cr else key_cr)
+
+
+def _to_db(x):
+    with np.errstate(all="ignore"):
+        return 10 * np.log10(x + 1e-15)  # windspeed.py:126-130, dtype follows x
+
+
+def invert_numpy(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_co=0.1):
+    """(ws_co, ws_cr) complex128 for numpy rasters; any of sigma0_co / sigma0_cr / anc may be None.
+
+    Raster dtypes follow the reference: the dB conversion runs in each sigma0's own dtype, then
+    everything is handled as float64/complex128 (the gufunc signature, windspeed.py:308-318).  When
+    every raster is float32/complex64 the device reads them as such (half the PCIe and HBM bytes)
+    and widens in registers, which is the same arithmetic.
+    """
+    ctx = _lib.default_context(options.device)
+    ensure_luts(ctx, lut_co if sigma0_co is not None else None, lut_cr if sigma0_cr is not None else None)
+    inc = np.asarray(inc)
+    shape = inc.shape
+    rasters = [a for a in (inc, sigma0_co, sigma0_cr, None if np.isscalar(dsig_cr) else dsig_cr) if a is not None]
+    all_f32 = all(np.asarray(a).dtype == np.float32 for a in rasters) and (
+        anc is None or np.asarray(anc).dtype == np.complex64)
+    on_dev = options.db_on_device
+    if on_dev == "auto":
+        on_dev = not any(np.asarray(a).dtype == np.float32 for a in (sigma0_co, sigma0_cr) if a is not None)
+    is_db = not on_dev
+    if is_db:
+        sigma0_co = None if sigma0_co is None else _to_db(np.asarray(sigma0_co))
+        sigma0_cr_lin = sigma0_cr
+        sigma0_cr = None if sigma0_cr is None else _to_db(np.asarray(sigma0_cr))
+    else:
+        sigma0_cr_lin = sigma0_cr
+    dt = np.float32 if all_f32 else np.float64
+    if sigma0_cr is not None and np.isscalar(dsig_cr):
+        if is_db:  # the kernel derives the broadcast from linear sigma0; do it here as the reference does
+            with np.errstate(all="ignore"):
+                dsig_cr = np.asarray(sigma0_cr_lin) * 0 + dsig_cr  # windspeed.py:122-123
+        elif dt == np.float32:
+            dsig_cr = float(np.float32(dsig_cr))
+    cast = lambda a, t: None if a is None else np.ascontiguousarray(np.broadcast_to(np.asarray(a), shape), dtype=t)
+    out_co, out_cr, _ = ctx.invert_host(
+        cast(inc, dt), sigma0_co=cast(sigma0_co, dt), sigma0_cr=cast(sigma0_cr, dt),
+        dsig_cr=dsig_cr if (dsig_cr is None or np.isscalar(dsig_cr)) else cast(dsig_cr, dt),
+        anc=cast(anc, np.complex64 if dt == np.float32 else np.complex128), dsig_co=dsig_co, sigma0_is_db=is_db,
+        algo=options.algo, out_dtype=np.complex128)
+    nan_c = lambda: np.full(shape, np.nan * 1j, dtype=np.complex128)
+    return (out_co if out_co is not None else nan_c()), (out_cr if out_cr is not None else nan_c())

@@ -1,0 +1,162 @@
+"""`invert_from_model`: drop-in for `xsarsea.windspeed.invert_from_model`
+(reference: src/xsarsea/windspeed/windspeed.py:17-439), running the per-pixel search on MI355X.
+
+What stays on the host, line for line in behaviour: model lookup (:78-83), mono / cross / dual
+routing with its pol check, warnings and assertion (:88-120), scalar `dsig_cr` broadcasting
+(:122-123), container handling (xarray in -> xarray out with name/attrs :338-343, :395-438; numpy
+in -> numpy out; dask in -> lazy dask out :350-364) and the return conventions (:415-439).
+What moves to the device: the sigma0 -> dB conversion (:126-130, see `options.db_on_device`) and all
+of `_invert_from_model_numpy` (:132-331) through `xsw_invert` (include/xsw.h).
+"""
+import logging
+import time
+import warnings
+
+import numpy as np
+
+from .. import options
+from . import _engine
+from .lut import xr
+from .models import get_model
+
+logger = logging.getLogger("xsarsea.windspeed")
+
+try:
+    import dask.array as da
+except ImportError:  # pragma: no cover - dask is absent from the build image
+    da = None
+
+
+def _is_xr(v):
+    return xr is not None and isinstance(v, xr.DataArray)
+
+
+def _is_dask(v):
+    data = getattr(v, "data", v)
+    return da is not None and isinstance(data, da.Array)
+
+
+def invert_from_model(inc, sigma0, sigma0_dual=None, /, ancillary_wind=None, dsig_co=0.1, dsig_cr=0.1, model=None,
+                      **kwargs):
+    """
+    Invert sigma0 to wind from a model (GMF or LUT).
+
+    Parameters
+    ----------
+    inc : xarray.DataArray | numpy.ndarray
+        incidence angle (deg)
+    sigma0 : same type
+        linear sigma0 to invert
+    sigma0_dual : same type, optional
+        cross-pol sigma0 for the dual-pol inversion
+    ancillary_wind : complex array, optional
+        a-priori wind in **antenna convention** (real = sample axis, imag = line axis)
+    dsig_co : float
+        `Jsig_co = ((sigma0_gmf - sigma0) / dsig_co) ** 2`
+    dsig_cr : float or array
+        `Jsig_cr = ((sigma0_gmf - sigma0) / dsig_cr) ** 2`
+    model : str | Model | (co, cross) tuple
+    **kwargs : forwarded to `Model.to_lut` (`resolution`, `inc_step`, ...)
+
+    Returns
+    -------
+    co-pol model: complex wind (antenna convention);  cross-pol model: wind speed (float);
+    dual-pol: `(wind_co, wind_dual)`.  The container type follows the inputs.
+    """
+    t0 = time.time()
+    nan = sigma0 * np.nan
+
+    models = model if isinstance(model, tuple) else (model, None)
+    models = tuple(get_model(m) if m is not None else None for m in models)
+
+    if ancillary_wind is None:
+        ancillary_wind = nan
+
+    if sigma0_dual is None:
+        try:
+            pol = sigma0.pol.values.item()
+        except AttributeError:
+            pol = None
+        model_pol = models[0].pol
+        if pol is None:
+            warnings.warn(f"Unable to check sigma0 pol. Assuming  {model_pol}")
+        elif pol not in model_pol:
+            raise ValueError(f"sigma0 pol is {pol}, and model {models[0].name} can only handle {model_pol}")
+        if models[0].iscopol:
+            sigma0_co, sigma0_cr = sigma0, None
+            assert np.any(~np.isnan(ancillary_wind)), "co-pol inversion needs a valid ancillary wind"
+        elif models[0].iscrosspol:
+            sigma0_co, sigma0_cr = None, sigma0
+            if not np.all(np.isnan(ancillary_wind)):
+                warnings.warn("crosspol inversion is best without ancillary wind, but using it as requested.")
+            models = (None, models[0])
+    else:
+        sigma0_co, sigma0_cr = sigma0, sigma0_dual
+
+    lut_co = models[0]._lut(units="dB", **kwargs) if models[0] is not None else None
+    lut_cr = models[1]._lut(units="dB", **kwargs) if (models[1] is not None and sigma0_cr is not None) else None
+    if sigma0_cr is not None and lut_cr is None:
+        raise ValueError("a cross-pol sigma0 was given but `model` names no cross-pol model")
+
+    def _numpy(np_inc, np_co, np_cr, np_dsig, np_anc):
+        return _engine.invert_numpy(lut_co, lut_cr, np_inc, np_co, np_cr, np_dsig, np_anc, dsig_co=dsig_co)
+
+    # cross-pol search disabled for every pixel when all cross sigma0 are NaN (:170) is implicit: NaN pixels skip it
+    template = next((v for v in (sigma0, inc, sigma0_dual, ancillary_wind) if _is_xr(v)), None)
+    dsig_in = dsig_cr if np.isscalar(dsig_cr) else dsig_cr
+    args = (inc, sigma0_co, sigma0_cr, dsig_in, ancillary_wind if ancillary_wind is not nan else None)
+
+    if any(_is_dask(v) for v in args if v is not None and not np.isscalar(v)):
+        # dask in -> lazy dask out, one device call per row block (core dimension = last axis, :356-364)
+        present = [i for i, v in enumerate(args) if v is not None and not np.isscalar(v)]
+
+        def _block(*blocks):
+            full = list(args)
+            for i, b in zip(present, blocks):
+                full[i] = b
+            for i, v in enumerate(full):
+                if i not in present and v is not None and not np.isscalar(v):
+                    full[i] = np.asarray(v)
+            return _numpy(*full)
+
+        ws_co, ws_cr = da.apply_gufunc(_block, ",".join(["(n)"] * len(present)) + "->(n),(n)",
+                                       *[getattr(args[i], "data", args[i]) for i in present],
+                                       output_dtypes=(np.complex128, np.complex128))
+    else:
+        ws_co, ws_cr = _numpy(*[None if v is None else (v if np.isscalar(v) else np.asarray(v)) for v in args])
+
+    if template is not None:
+        def wrap(values):
+            out = xr.zeros_like(template, dtype=np.complex128)
+            out.data = values
+            out.name = "windspeed_gmf"
+            out.attrs.clear()
+            return out
+        ws_co, ws_cr = wrap(ws_co), wrap(ws_cr)
+
+    logger.debug("timing invert_from_model : %.2fs.", time.time() - t0)
+
+    if models[0] and models[0].iscopol and template is not None:
+        ws_co.attrs["comment"] = f"wind speed and direction inverted from model {models[0].name} ({models[0].pol})"
+        ws_co.attrs["model"] = models[0].name
+
+    if sigma0_dual is None:
+        if models[0] is not None:
+            return ws_co  # mono co-pol
+        ws = np.abs(ws_cr)  # mono cross-pol: speed only
+        if template is not None:
+            ws.attrs["comment"] = f"wind speed inverted from model {models[1].name} ({models[1].pol})"
+            ws.attrs["model"] = models[1].name
+            ws.attrs["units"] = "m/s"
+        return ws
+
+    # dual-pol: keep the co-pol wind where either solution is below 5 m/s (:426-428)
+    if template is not None:
+        wspd_dual = xr.where((np.abs(ws_co) < 5) | (np.abs(ws_cr) < 5), ws_co, ws_cr)
+        wspd_dual.attrs["comment"] = (f"wind speed and direction inverted from model {models[0].name} ({models[0].pol})"
+                                      f" and {models[1].name} ({models[1].pol})")
+        wspd_dual.attrs["model"] = f"{models[0].name} {models[1].name}"
+    else:
+        with np.errstate(all="ignore"):
+            wspd_dual = np.where((np.abs(ws_co) < 5) | (np.abs(ws_cr) < 5), ws_co, ws_cr)
+    return ws_co, wspd_dual
