@@ -204,18 +204,19 @@ def main():
     lines, samples = args.lines, args.samples
     inc, s_vv, anc = make_scene(lines, samples, lines * n_gpus, rank * lines, 20260320 + 2 + rank, device)
     out = torch.empty((lines, samples), dtype=torch.complex64, device=device)
-    gathered = None
+    full = None  # rank 0: the gathered (lines * N) x samples raster
     if world > 1 and rank == 0:
-        gathered = [torch.empty_like(out) for _ in range(world)]
+        full = torch.empty((lines * world, samples), dtype=torch.complex64, device=device)
     algo = _lib.ALGOS[args.algo]
+    from xsarsea_amd import multi_gpu
 
     def step():
         ctx.invert_raw(lines, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, inc.data_ptr(), s_vv.data_ptr(), None,
                        None, anc.data_ptr(), out.data_ptr(), None, algo=algo)
 
     def gather():
-        if world > 1:
-            dist.gather(out, gathered, dst=0)
+        if world > 1:  # the single exchange of the path: output tiles -> rank 0, point-to-point over xGMI
+            multi_gpu.gather_rows(out, lines * world, dst=0, out=full)
 
     def fence():
         torch.cuda.synchronize()

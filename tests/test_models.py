@@ -1,0 +1,178 @@
+"""CPU: host logic of the drop-in layer -- model registry, GMFs, LUT preparation -- against the oracle
+and the golden vectors.  (No device compute here.)"""
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle import gmf as ogmf
+from oracle import lut as olut
+from xsarsea_amd import windspeed
+from xsarsea_amd.windspeed import cmod7, gmfs, lut as plut, models
+
+
+def test_registry_names_and_aliases():
+    df = windspeed.available_models()
+    for name in ogmf.GMFS:
+        assert name in df.index
+    assert set(df.columns) == {"alias", "pol", "model"}
+    assert windspeed.get_model("cmod5n") is windspeed.get_model("gmf_cmod5n")
+    assert windspeed.get_model(windspeed.get_model("gmf_s1_v2")).name == "gmf_s1_v2"
+    with pytest.raises(KeyError, match="not found"):
+        windspeed.get_model("gmf_does_not_exist")
+    vh = windspeed.available_models(pol="VH")
+    assert len(vh) >= 8 and all(vh.pol == "VH")
+    m = windspeed.get_model("gmf_cmod5n")
+    assert m.iscopol and not m.iscrosspol and m.phi_range == [0.0, 180.0] and m.wspd_range == [0.2, 50.0]
+    x = windspeed.get_model("gmf_s1_v2")
+    assert x.iscrosspol and x.phi_range is None and x.wspd_range == [3.0, 80.0]
+
+
+def test_register_decorator_contract():
+    """The plugin decorator as the reference's test uses it (test_xsarsea.py:8-21)."""
+    @gmfs.GmfModel.register(inc_range=[17., 50.], wspd_range=[3., 80.], pol="VH", units="linear", defer=False)
+    def gmf_dummy(inc, wspd, phi=None):
+        a = 0.00013106836021008122 + -4.530598283705591e-06 * inc + 4.429277425062766e-08 * inc ** 2
+        b = 1.3925444179360706 + 0.004157838450541205 * inc + 3.4735809771069953e-05 * inc ** 2
+        return a * wspd ** b
+
+    m = windspeed.get_model("gmf_dummy")
+    assert m.inc_range == [17., 50.] and m.pol == "VH"
+    v = np.asarray(m(np.arange(20, 22), np.arange(10, 12)))
+    assert np.allclose(v, [[0.00179606, 0.00207004], [0.0017344, 0.00200004]], rtol=2e-6)  # gmfs.py:60-63
+    assert np.isscalar(m(35, 15, 90))
+    with pytest.raises(ValueError, match="must start with"):
+        gmfs.GmfModel.register(pol="VV")(lambda inc, wspd, phi: 1.0)
+
+    @gmfs.GmfModel.register("gmf_scalar_only", pol="VV", units="linear", defer=False)
+    def _scalar_only(inc, wspd, phi):  # branches on a scalar: numpy arrays make `if` ambiguous
+        import math
+        mod = 1 + 0.3 * math.cos(math.radians(phi))
+        base = 0.01 * wspd * mod if wspd > 2 else 0.001 * mod
+        return base * (40.0 / inc)
+
+    ms = windspeed.get_model("gmf_scalar_only")
+    assert ms.phi_range == [0.0, 180.0]
+    lut = ms._lut(units="linear", resolution="low", inc_step_lr=10.0, wspd_step_lr=10.0, phi_step_lr=45.0)
+    assert lut.shape == (6, 6, 5) and np.isfinite(lut.values).all()
+
+
+@pytest.mark.parametrize("name", sorted(ogmf.GMFS))
+def test_product_gmfs_match_reference_lattice(name):
+    g = golden("gmf_lattice.npz")
+    f = windspeed.get_model(name)._gmf_pyfunc_scalar
+    with np.errstate(all="ignore"):
+        v = np.broadcast_to(f(g["inc"][:, None, None], g["wspd"][None, :, None], g["phi"][None, None, :]), g[name].shape)
+    ok = np.isfinite(g[name]) & (g[name] != 0)
+    assert np.array_equal(np.isnan(v), np.isnan(g[name]))
+    assert np.max(np.abs(v[ok] - g[name][ok]) / np.abs(g[name][ok])) < 1e-13
+
+
+def test_lut_policy_and_values_lowres():
+    """resolution='low' -> raw grids, no interpolation; identical to the oracle's restatement."""
+    for name in ("gmf_cmod5n", "gmf_s1_v2"):
+        mine = windspeed.get_model(name)._lut(units="dB", resolution="low")
+        ref = olut.to_lut(name, resolution="low")
+        assert mine.attrs["units"] == "dB" and mine.attrs["resolution"] == "low"
+        assert mine.shape == ref.values.shape and np.array_equal(mine.values, ref.values)
+        assert np.array_equal(mine.wspd, ref.wspd) and np.array_equal(mine.incidence, ref.incidence)
+    co = windspeed.get_model("gmf_cmod5n")._lut(units="dB", resolution="low")
+    assert co.shape == (51, 250, 73) and co.dims == ("incidence", "wspd", "phi")
+
+
+def test_lut_default_highres_equals_oracle(default_luts):
+    """Default call (raw low-res -> linear interpolation inc, wspd, phi -> dB) == oracle, bit for bit."""
+    lco, lcr = default_luts
+    mine = windspeed.get_model("gmf_cmod5n")._lut(units="dB")
+    assert mine.shape == (501, 499, 181) and mine.attrs["resolution"] == "high"
+    assert np.array_equal(mine.values, lco.values)
+    cr = windspeed.get_model("gmf_s1_v2")._lut(units="dB")
+    assert cr.shape == (501, 771) and np.array_equal(cr.values, lcr.values)
+    assert windspeed.get_model("gmf_cmod5n")._lut(units="dB") is mine  # memoised
+
+
+def test_lerp_matches_scipy_bitwise():
+    from scipy.interpolate import interp1d
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal((7, 11, 5))
+    x_old = np.linspace(0.2, 50, 11)
+    x_new = np.linspace(0.2, 50, 101)
+    ref = interp1d(x_old, y, kind="linear", axis=1, bounds_error=True)(x_new)
+    assert np.array_equal(plut.lerp_axis(y, x_old, x_new, 1), ref)
+    with pytest.raises(ValueError):
+        plut.lerp_axis(y, x_old, np.array([0.0, 1.0]), 1)
+
+
+def test_lut_validation_errors():
+    """Same exception types as Model._normalize_lut (models.py:84-105)."""
+    class Fake:
+        def __init__(self, dims, attrs):
+            self.dims, self.attrs = dims, attrs
+            self._v = np.zeros((2, 2))
+
+        def __array__(self, dtype=None, copy=None):
+            return self._v
+
+        def __getitem__(self, k):
+            return np.array([0.0, 1.0])
+
+    with pytest.raises(KeyError):
+        plut.Lut.from_any(Fake(("incidence", "wspd"), {"resolution": "high"}))
+    with pytest.raises(ValueError, match="Unknown lut units"):
+        plut.Lut.from_any(Fake(("incidence", "wspd"), {"units": "furlongs", "resolution": "high"}))
+    with pytest.raises(IndexError):
+        plut.Lut.from_any(Fake(("wspd", "incidence"), {"units": "dB", "resolution": "high"}))
+    with pytest.raises(AssertionError):
+        plut.Lut.from_any(Fake(("incidence", "wspd"), {"units": "dB"}))
+
+
+def test_cmod7_binary_roundtrip(tmp_path):
+    """CMOD7 file format (cmod7.py:27-40): float32 LE, one marker word each end, Fortran (250,73,51)."""
+    rng = np.random.default_rng(1)
+    table = rng.uniform(1e-4, 1.0, (250, 73, 51)).astype(np.float32)
+    cmod7.write_cmod7_table(tmp_path / "gmf_cmod7_vv.dat_little_endian", table)
+    m = cmod7.register_cmod7(str(tmp_path))
+    assert m.name == "gmf_cmod7" and m.pol == "VV" and windspeed.get_model("cmod7") is m
+    raw = m._raw_lut()
+    assert raw.shape == (51, 250, 73) and raw.attrs["units"] == "linear" and raw.attrs["resolution"] == "low"
+    assert np.array_equal(raw.values, np.transpose(table, (2, 0, 1)).astype(np.float64))
+    hi = m._lut(units="dB")
+    assert hi.shape == (501, 499, 181)
+    # low-res grid points (inc every 10th, wspd 0.2*k -> index 2k-2... checked on inc & phi axes) are reproduced
+    assert np.allclose(hi.values[::10, 0, ::5], 10 * np.log10(raw.values[:, 0, ::2] + 1e-15), rtol=0, atol=1e-9)
+    with pytest.raises(FileNotFoundError):
+        cmod7.register_cmod7(str(tmp_path / "nope"))
+
+
+def test_invert_host_side_errors():
+    """Argument routing errors raised before any device work (windspeed.py:88-120)."""
+    inc = np.full((4, 4), 30.0)
+    s = np.full((4, 4), 0.05)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(AssertionError):  # co-pol inversion without any valid ancillary wind (:107)
+            windspeed.invert_from_model(inc, s, model="gmf_cmod5n", resolution="low")
+        with pytest.raises(KeyError):
+            windspeed.invert_from_model(inc, s, model="gmf_nope")
+    with pytest.warns(UserWarning, match="Unable to check sigma0 pol"):
+        try:
+            windspeed.invert_from_model(inc, s, ancillary_wind=s + 0j, model="gmf_cmod5n", resolution="low")
+        except Exception:
+            pass  # no GPU here: the device call raises after the host-side warning
+
+
+def test_utils_formulas():
+    from xsarsea_amd.windspeed import utils
+    s, n = np.array([1e-3, 2e-3]), np.array([1e-4, 1e-4])
+    assert np.allclose(utils.get_dsig("nc_lut_cmodms1ahw", None, s, n), (1.25 / (s / n)) ** 4)
+    assert np.allclose(utils.get_dsig("gmf_rs2_v2", None, s, n), 1 / np.sqrt((s / n) ** 8))
+    with pytest.raises(ValueError):
+        utils.get_dsig("other", None, s, n)
+    inc = np.broadcast_to(np.linspace(20, 45, 50), (6, 50)).copy()
+    noise = 10 ** ((-0.1 * inc - 20) / 10)
+    noise[2, 5] = np.nan
+    flat = utils.nesz_flattening(noise, inc)
+    assert np.allclose(flat, 10 ** ((-0.1 * inc - 21) / 10), rtol=1e-9)
+    with pytest.raises(IndexError):
+        utils.nesz_flattening(noise[0], inc[0])

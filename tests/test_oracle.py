@@ -1,0 +1,123 @@
+"""CPU: the oracle is pinned against the golden vectors captured from the reference's own code
+(tests/golden/make_golden.py) before anything else trusts it."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from util import bits_equal, small_luts
+from oracle import cport, gmf
+from oracle import invert as oinv
+from oracle import lut as olut
+
+
+def test_gmf_known_answers():
+    """The only numeric values the reference itself publishes (gmfs.py:60-63) + SURVEY.md 8c table."""
+    v = gmf.gmf_dummy(np.array([20, 21])[:, None], np.array([10, 11])[None, :])
+    assert np.allclose(v, [[0.00179606, 0.00207004], [0.0017344, 0.00200004]], rtol=2e-6)
+    assert gmf.gmf_cmod5n(35.0, 10.0, 45.0) == pytest.approx(0.05376709128885202, rel=1e-14)
+    assert gmf.GMFS["gmf_s1_v2"][0](35.0, 10.0) == pytest.approx(0.0006528105083749748, rel=1e-14)
+
+
+@pytest.mark.parametrize("name", sorted(gmf.GMFS))
+def test_gmf_lattice(name):
+    """All 13 GMFs on the lattice evaluated by the reference's scalar functions."""
+    g = golden("gmf_lattice.npz")
+    f = gmf.GMFS[name][0]
+    with np.errstate(all="ignore"):
+        v = np.broadcast_to(f(g["inc"][:, None, None], g["wspd"][None, :, None], g["phi"][None, None, :]), g[name].shape)
+    ref = g[name]
+    assert np.array_equal(np.isnan(v), np.isnan(ref))
+    ok = np.isfinite(ref) & (ref != 0)
+    assert np.max(np.abs(v[ok] - ref[ok]) / np.abs(ref[ok])) < 1e-13
+
+
+def test_cmod5n_branch_sweeps():
+    g = golden("gmf_lattice.npz")
+    for tag, inc in (("17", 17.0), ("60", 60.0)):
+        v = gmf.gmf_cmod5n(inc, g["sweep_wspd"], 37.0)
+        assert np.max(np.abs(v - g["cmod5n_sweep_inc" + tag]) / g["cmod5n_sweep_inc" + tag]) < 1e-13
+
+
+def test_raw_lut_samples():
+    s = golden("raw_lut_samples.npz")
+    raw = olut.raw_lut("gmf_cmod5n")
+    assert raw.values.shape == (51, 250, 73)
+    v = raw.values[s["ii"], s["jj"], s["kk"]]
+    assert np.max(np.abs(v - s["cmod5n"]) / s["cmod5n"]) < 1e-13
+    raw = olut.raw_lut("gmf_s1_v2")
+    assert raw.values.shape == (51, 386)
+    v = raw.values[s["ii"], s["jc"]]
+    assert np.max(np.abs(v - s["s1_v2"]) / s["s1_v2"]) < 1e-13
+
+
+@pytest.mark.parametrize("tag", ["phi180_f64", "phi360_f64", "phi180_f32"])
+def test_kernel_small_goldens_bit_exact(tag):
+    """numpy restatement == the reference's kernel body, bit for bit, on the self-contained goldens
+    (mono co-pol, dual-pol with the <5 m/s select, cross-pol only; NaN / clamp / zero edge cases)."""
+    d = golden(f"kernel_small_{tag}.npz")
+    lco, lcr = small_luts(d)
+    r1 = oinv.invert_from_model(d["inc"], d["sigma0_vv"], ancillary_wind=d["anc"], lut_co=lco)
+    r2 = oinv.invert_from_model(d["inc"], d["sigma0_vv"], d["sigma0_vh"], ancillary_wind=d["anc"],
+                                dsig_cr=d["dsig_cr"], lut_co=lco, lut_cr=lcr)
+    r3 = oinv.invert_from_model(d["inc"], d["sigma0_vh"], dsig_cr=0.1, lut_cr=lcr)
+    assert bits_equal(r1, d["mono_co"])
+    assert bits_equal(r2[0], d["dual_co"]) and bits_equal(r2[1], d["dual_dual"])
+    assert bits_equal(r3, d["cross_only"])
+    assert np.isnan(r1).sum() >= 3  # the edge cases are really in there
+
+
+def test_kernel_default_golden_and_c_port(default_luts):
+    """Default-resolution LUT: numpy restatement == golden (f64), and the C restatement (both LUT
+    layouts) == numpy restatement index for index."""
+    lco, lcr = default_luts
+    d = golden("kernel_default_f64.npz")
+    assert float(lco.values.sum()) == pytest.approx(float(d["lut_co_sum"]), rel=1e-12)
+    sl = (slice(0, 12), slice(None))  # first 12 lines hold every edge case; keeps the numpy loop short
+    r2, idx = oinv.invert_from_model(d["inc"][sl], d["sigma0_vv"][sl], d["sigma0_vh"][sl], ancillary_wind=d["anc"][sl],
+                                     dsig_cr=d["dsig_cr"][sl], lut_co=lco, lut_cr=lcr, return_idx=True)
+    assert bits_equal(r2[0], d["dual_co"][sl]) and bits_equal(r2[1], d["dual_dual"][sl])
+    p = oinv.Prepared(lco, lcr)
+    sco, scr = oinv.to_db(d["sigma0_vv"]), oinv.to_db(d["sigma0_vh"])
+    a = cport.invert_numpy(p, d["inc"], sco, scr, d["dsig_cr"], d["anc"], return_idx=True, reference_layout=True)
+    b = cport.invert_numpy(p, d["inc"], sco, scr, d["dsig_cr"], d["anc"], return_idx=True, reference_layout=False)
+    assert np.array_equal(a[2], b[2]) and bits_equal(a[0], b[0])
+    assert np.array_equal(a[2][sl], idx)
+    assert bits_equal(a[0], d["dual_co"])  # co-pol output bit-identical to the reference's
+
+
+@pytest.mark.parametrize("tag", ["phi180_f64", "phi360_f64"])
+def test_c_port_small(tag):
+    d = golden(f"kernel_small_{tag}.npz")
+    lco, lcr = small_luts(d)
+    p = oinv.Prepared(lco, lcr)
+    sco, scr = oinv.to_db(d["sigma0_vv"]), oinv.to_db(d["sigma0_vh"])
+    a = oinv.invert_numpy(p, d["inc"], sco, scr, d["dsig_cr"], d["anc"], return_idx=True)
+    b = cport.invert_numpy(p, d["inc"], sco, scr, d["dsig_cr"], d["anc"], return_idx=True)
+    assert np.array_equal(a[2], b[2]) and bits_equal(a[0], b[0])
+    ok = ~np.isnan(a[1].real)
+    assert np.array_equal(ok, ~np.isnan(b[1].real)) and np.max(np.abs(a[1][ok] - b[1][ok])) < 1e-12
+
+
+def test_hypot_replica_matches_libm():
+    """The device's hypot (csrc/xsw_device.hpp hypot_glibc) restated in numpy == numpy.hypot bit for bit."""
+    rng = np.random.default_rng(0)
+    x = rng.normal(0, 10, 400000)
+    y = rng.normal(0, 10, 400000) * 10 ** rng.uniform(-8, 0, 400000)
+    ax, ay = np.maximum(np.abs(x), np.abs(y)), np.minimum(np.abs(x), np.abs(y))
+    h = np.sqrt(ax * ax + ay * ay)
+    d1 = h - ay
+    r1 = h - (ax * (2.0 * d1 - ax) + (d1 - 2.0 * (ax - ay)) * d1) / (2.0 * h)
+    d2 = h - ax
+    r2 = h - (2.0 * d2 * (ax - 2.0 * ay) + ((4.0 * d2 - ay) * ay + d2 * d2)) / (2.0 * h)
+    mine = np.where(ax >= ay * 2.0 ** 54, ax + ay, np.where(h <= 2.0 * ay, r1, r2))
+    assert np.array_equal(mine, np.hypot(x, y))
+
+
+def test_detrend_formula():
+    from oracle import detrend as odet
+    rng = np.random.default_rng(4)
+    inc = np.broadcast_to(np.linspace(20, 45, 64), (16, 64)).copy()
+    s = rng.uniform(0.01, 0.2, inc.shape)
+    out = odet.sigma0_detrend(s, inc)
+    g = gmf.gmf_cmod5n(inc[0], 10.0, 45.0)
+    assert np.allclose(out, s * np.mean(g) / g[None, :], rtol=1e-14)
