@@ -241,7 +241,7 @@ static int upload_co(xsw_ctx *c, const xsw_lut *l)
     T.phi_last = l->phi[nP - 1];
     T.inv_wstep = nW > 1 ? (nW - 1) / (l->wspd[nW - 1] - l->wspd[0]) : 0.0;
     T.inv_dphi = nP > 1 ? (nP - 1) / (l->phi[nP - 1] - l->phi[0]) : 0.0;
-    T.prunable = (nW >= 2 && nP >= 2 && uniform_axis(l->wspd, nW) && uniform_axis(l->phi, nP) && trig_ok &&
+    T.prunable = (nW >= 2 && nP >= 2 && nW < 32768 && nP < 65536 && (int64_t)nW * ppad < ((int64_t)1 << 30) && uniform_axis(l->wspd, nW) && uniform_axis(l->phi, nP) && trig_ok &&
                   (l->phi[nP - 1] - l->phi[0]) <= 360.0 + 1e-9 && all_finite(l->db, (size_t)nI * nW * nP))
                      ? 1 : 0;
     // transposed slices for the ray scan

@@ -58,11 +58,25 @@ __device__ __forceinline__ double rd_lane_d(double v, int l)
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
 }
+// DPP lane permutes (no LDS traffic): ctrl codes of the gfx9 family -- quad_perm 0x00-0xFF,
+// row_half_mirror 0x141, row_mirror 0x140, row_bcast:15 0x142, row_bcast:31 0x143.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false),
+                            __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false));
+}
+// minimum over the 64 lanes, returned wave-uniform (every lane must be active)
 __device__ __forceinline__ double wave_min_d(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
-    return v;
+    v = fmin(v, dpp_d<0xB1, 0xF>(v));   // lane ^ 1
+    v = fmin(v, dpp_d<0x4E, 0xF>(v));   // lane ^ 2
+    v = fmin(v, dpp_d<0x141, 0xF>(v));  // 8-lane halves mirrored
+    v = fmin(v, dpp_d<0x140, 0xF>(v));  // 16-lane rows mirrored
+    v = fmin(v, dpp_d<0x142, 0xA>(v));  // lane 15 of rows 0,2 -> rows 1,3
+    v = fmin(v, dpp_d<0x143, 0xC>(v));  // lane 31 -> rows 2,3
+    return rd_lane_d(v, 63);
 }
 // lexicographic (J, idx) minimum over the wave; J never NaN here
 __device__ __forceinline__ void wave_argmin(double &J, int &idx)
@@ -179,35 +193,46 @@ __device__ __forceinline__ int exact_scan_cr(const DevTables &L, int i_inc, doub
 
 // ------------------------------------------------------------------------------------------------
 // Branch-and-bound co-pol search (tests/prune_model.py is the executable specification).
-// Preconditions (caller): L.prunable, s/a/b finite, b already |b| when phi_180.
-// Returns the flat index iw*n_phi+ip (wave-uniform).  `cand` accumulates scored candidates.
+// Preconditions (caller): L.prunable, s/a/b finite, b already |b| when phi_180; mag = |(a, b)|,
+// theta = its direction in degrees normalised into [phi0, phi0 + 360), ipr = nearest direction index
+// (all three prepared per lane in load_pixel).  Returns the flat index iw*n_phi+ip (wave-uniform).
+// Memory-latency discipline: every loop issues its (independent) loads four at a time before using
+// them, and nothing inside a loop depends on a cross-lane reduction.
 __device__ __forceinline__ int pruned_search_co(const DevTables &L, int i_inc, double s, double a, double b,
-                                                double dsig, double inv_dsig, int lane, unsigned &cand,
-                                                bool &went_exact)
+                                                double mag, double theta, int ipr, double dsig, double inv_dsig,
+                                                int lane, unsigned &cand, bool &went_exact)
 {
     const double ah = 0.5 * a, bh = 0.5 * b;
     const double m2 = ah * ah + bh * bh;
     const double sn = -s * inv_dsig;
-    const double mag = sqrt(a * a + b * b);
-    double theta = atan2(b, a) * 57.295779513082320877;  // degrees
-    if (theta < L.phi0) theta += 360.0;
+    const double inf = __builtin_inf();
+    const double wh0 = 0.5 * L.w0, whs = 0.5 / L.inv_wstep;  // screening only needs w/2 to ~1e-15
 
     // 1. upper bound along the direction nearest to the ancillary wind (transposed slice: contiguous)
-    int ipr = (int)rint(fmin(fmax((theta - L.phi0) * L.inv_dphi, 0.0), (double)(L.n_phi - 1)));
     const double ur = 2.0 * (ah * L.cphi[ipr] + bh * L.sphi[ipr]);
     const double *__restrict__ ray = L.coT + ((size_t)i_inc * L.n_phi + ipr) * L.w_pad;
-    double rbest = __builtin_inf();
-    for (int iw = lane; iw < L.n_w; iw += 64) {
-        double wh = L.wh[iw];
-        double dd = fma(ray[iw], inv_dsig, sn);
-        double J = fma(dd, dd, wh * (wh - ur));
-        rbest = fmin(rbest, J);
+    double rbest = inf;
+    for (int base = 0; base < L.n_w; base += 256) {
+        double v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int iw = base + k * 64 + lane;
+            v[k] = ray[iw < L.n_w ? iw : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int iw = base + k * 64 + lane;
+            const double wh = fma((double)iw, whs, wh0);
+            const double dd = fma(v[k], inv_dsig, sn);
+            const double J = fma(dd, dd, wh * (wh - ur));
+            rbest = fmin(rbest, iw < L.n_w ? J : inf);
+        }
     }
     rbest = wave_min_d(rbest);
     cand += (unsigned)L.n_w;
-    double jub = (rbest + m2) * (1.0 + 1e-9) + 1e-9;
+    const double jub = (rbest + m2) * (1.0 + 1e-9) + 1e-9;
 
-    // 2. polar bounding box of the disc |c - m| <= R
+    // 2. polar bounding box of the disc |c - m| <= R  (one index of slack on every side)
     const double R = 2.0 * sqrt(jub);
     const double nwd = (double)L.n_w;
     int w_lo = (int)floor(fmin(fmax((mag - R - L.w0) * L.inv_wstep, -4.0), nwd + 4.0)) - 1;
@@ -215,11 +240,12 @@ __device__ __forceinline__ int pruned_search_co(const DevTables &L, int i_inc, d
     w_lo = max(w_lo, 0);
     w_hi = min(w_hi, L.n_w - 1);
     int ip_lo = 0, ip_hi = L.n_phi - 1;
-    if (R < mag * (1.0 - 1e-12)) {
-        const double half = asin(R / mag) * 57.295779513082320877;
+    if (R < mag * (1.0 - 1e-6)) {
+        // half-width of the disc seen from the origin; float is ample: the slack is a whole grid step
+        const double half = (double)(asinf((float)(R / mag)) * 57.29578f) + 1e-3;
         const double nphd = (double)L.n_phi;
-        int plo = (int)floor(fmin(fmax((theta - half - L.phi0) * L.inv_dphi, -4.0), nphd + 4.0)) - 1;
-        int phi_i = (int)ceil(fmin(fmax((theta + half - L.phi0) * L.inv_dphi, -4.0), nphd + 4.0)) + 1;
+        const int plo = (int)floor(fmin(fmax((theta - half - L.phi0) * L.inv_dphi, -4.0), nphd + 4.0)) - 1;
+        const int phi_i = (int)ceil(fmin(fmax((theta + half - L.phi0) * L.inv_dphi, -4.0), nphd + 4.0)) + 1;
         if (L.phi_last - theta <= 180.0 && theta - L.phi0 <= 180.0) {
             ip_lo = max(plo, 0);
             ip_hi = min(phi_i, L.n_phi - 1);
@@ -237,8 +263,8 @@ __device__ __forceinline__ int pruned_search_co(const DevTables &L, int i_inc, d
 
     // 3. screen the box: lanes = directions (<= 64 per chunk), narrow chunks fold several speed rows
     const double *__restrict__ slice = L.co + (size_t)i_inc * L.n_w * L.phi_pad;
-    double best = __builtin_inf(), second = __builtin_inf();
-    int bidx = 0x7fffffff;
+    double best = inf, second = inf;
+    int bidx = 0;  // (iw << 16) | ip
     for (int c0 = 0; c0 < ncols; c0 += 64) {
         const int width = min(64, ncols - c0);
         const int sh = (width <= 1) ? 0 : (32 - __clz(width - 1));  // log2(pow2ceil(width))
@@ -248,37 +274,53 @@ __device__ __forceinline__ int pruned_search_co(const DevTables &L, int i_inc, d
         const int ip = ip_lo + c0 + (act ? col : 0);
         const double U = 2.0 * (ah * L.cphi[ip] + bh * L.sphi[ip]);
         const double *__restrict__ colp = slice + ip;
-        for (int r0 = 0; r0 < nrows; r0 += G) {
-            const int r = r0 + grp;
-            const bool ok = act && (r < nrows);
-            const int iw = w_lo + (ok ? r : 0);
-            const double wh = L.wh[iw];
-            const double dd = fma(colp[(size_t)iw * L.phi_pad], inv_dsig, sn);
-            double J = fma(dd, dd, wh * (wh - U));
-            J = ok ? J : __builtin_inf();
-            second = fmin(second, fmax(J, best));
-            if (J < best) { best = J; bidx = iw * L.n_phi + ip; }
+        for (int r0 = 0; r0 < nrows; r0 += 4 * G) {
+            double v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = r0 + k * G + grp;
+                v[k] = colp[(w_lo + (r < nrows ? r : 0)) * L.phi_pad];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = r0 + k * G + grp;
+                const int iw = w_lo + r;
+                const double wh = fma((double)iw, whs, wh0);
+                const double dd = fma(v[k], inv_dsig, sn);
+                double J = fma(dd, dd, wh * (wh - U));
+                J = (act && r < nrows) ? J : inf;
+                second = fmin(second, fmax(J, best));
+                if (J < best) { best = J; bidx = (iw << 16) | ip; }
+            }
         }
     }
 
-    // 4. exact re-scoring of everything within eps of the screening minimum
+    // 4. settle: a unique candidate within eps of the screening minimum IS the reference's argmin;
+    //    several (in different lanes) are re-scored in the reference's operation order; two in one lane
+    //    (or nothing finite) go to the exact full scan.
     const double gmin = wave_min_d(best);
     const double T = gmin + 1e-9 * (1.0 + fabs(gmin) + m2);
-    if (__ballot(second <= T) != 0ULL || !(gmin < __builtin_inf())) {
-        // two near-minimal candidates met in one lane (or nothing finite): settle it the slow way
+    if (__ballot(second <= T) != 0ULL || !(gmin < inf)) {
         went_exact = true;
         return exact_scan_co(L, i_inc, s, a, b, dsig, lane);
     }
     unsigned long long surv = __ballot(best <= T);
-    double eJ = __builtin_inf();
-    int eI = 0x7fffffff;
-    while (surv) {
-        const int l = __ffsll((long long)surv) - 1;
-        surv &= surv - 1;
-        const int flat = rd_lane_i(bidx, l);
-        const int iw = flat / L.n_phi, ip = flat - iw * L.n_phi;
-        const double J = exact_J_co(L.w[iw], L.cphi[ip], L.sphi[ip], slice[(size_t)iw * L.phi_pad + ip], s, a, b, dsig);
-        if (J < eJ || (J == eJ && flat < eI)) { eJ = J; eI = flat; }
+    const int first = __ffsll((long long)surv) - 1;
+    const int pk0 = rd_lane_i(bidx, first);
+    int eI = (pk0 >> 16) * L.n_phi + (pk0 & 0xffff);
+    surv &= surv - 1;
+    if (surv) {
+        int iw = pk0 >> 16, ip = pk0 & 0xffff;
+        double eJ = exact_J_co(L.w[iw], L.cphi[ip], L.sphi[ip], slice[iw * L.phi_pad + ip], s, a, b, dsig);
+        while (surv) {
+            const int l = __ffsll((long long)surv) - 1;
+            surv &= surv - 1;
+            const int pk = rd_lane_i(bidx, l);
+            iw = pk >> 16; ip = pk & 0xffff;
+            const int flat = iw * L.n_phi + ip;
+            const double J = exact_J_co(L.w[iw], L.cphi[ip], L.sphi[ip], slice[iw * L.phi_pad + ip], s, a, b, dsig);
+            if (J < eJ || (J == eJ && flat < eI)) { eJ = J; eI = flat; }
+        }
     }
     return eI;
 }
@@ -382,7 +424,8 @@ template <typename T> __device__ __forceinline__ double ld(const void *p, long l
 // Per-lane pixel state shared by the kernels.
 struct Pixel {
     double s_co, s_cr, dsig, a_re, a_im, b_eff;
-    int flags, i_inc, i_inc_cr;
+    double mag, theta;  // |(a_re, b_eff)| and its direction in degrees within [phi0, phi0 + 360)
+    int flags, i_inc, i_inc_cr, ipr;
 };
 
 // Loads pixel `il` (already clamped in range), converts to dB, classifies it (windspeed.py:198-209,
@@ -422,6 +465,13 @@ __device__ __forceinline__ void load_pixel(const DevTables &L, const KArgs &A, l
         }
     }
     P.b_eff = L.phi_180 ? fabs(P.a_im) : P.a_im;  // windspeed.py:218-219
+    // search-window geometry of the branch-and-bound kernel, one pixel per lane (64 at a time)
+    P.mag = sqrt(P.a_re * P.a_re + P.b_eff * P.b_eff);
+    double th = atan2(P.b_eff, P.a_re) * 57.295779513082320877;
+    if (th < L.phi0) th += 360.0;
+    P.theta = th;
+    P.ipr = (P.flags & F_CO_FINITE)
+                ? (int)rint(fmin(fmax((th - L.phi0) * L.inv_dphi, 0.0), (double)(L.n_phi - 1))) : 0;
 }
 
 // Forms pixel i's complex winds from the winning indices and stores them (windspeed.py:231-250,
@@ -517,7 +567,8 @@ __global__ __launch_bounds__(256) void k_invert(DevTables L, KArgs A)
             int flat;
             bool went_exact = false;
             if (ALGO == 1 && L.prunable && (uf & F_CO_FINITE))
-                flat = pruned_search_co(L, u_iinc, us, ua, ub, A.dsig_co, A.inv_dsig_co, lane, cand, went_exact);
+                flat = pruned_search_co(L, u_iinc, us, ua, ub, rd_lane_d(P.mag, p), rd_lane_d(P.theta, p),
+                                        rd_lane_i(P.ipr, p), A.dsig_co, A.inv_dsig_co, lane, cand, went_exact);
             else {
                 flat = exact_scan_co(L, u_iinc, us, ua, ub, A.dsig_co, lane);
                 went_exact = true;
@@ -526,8 +577,10 @@ __global__ __launch_bounds__(256) void k_invert(DevTables L, KArgs A)
             n_exact += went_exact ? 1u : 0u;
             n_co += 1u;
             if (lane == p) my_flat = flat;
-            aco = L.abs_co[flat];  // np.abs(wind_co): table [n_w][n_phi], flat = iw*n_phi + ip
-            have_co = aco == aco;
+            if (uf & F_NEED_CR) {
+                aco = L.abs_co[flat];  // np.abs(wind_co): table [n_w][n_phi], flat = iw*n_phi + ip
+                have_co = aco == aco;
+            }
         }
         if (uf & F_NEED_CR) {
             const int u_iinc = rd_lane_i(P.i_inc_cr, p);
