@@ -189,7 +189,7 @@ static int upload_co(xsw_ctx *c, const xsw_lut *l)
     const int nI = l->n_inc, nW = l->n_wspd, nP = l->n_phi;
     const int ppad = (nP + 3) & ~3, wpad = (nW + 3) & ~3;
     // padded incidence-major copy
-    std::vector<double> pad((size_t)nI * nW * ppad, 0.0);
+    std::vector<double> pad((size_t)nI * nW * ppad + (size_t)260 * ppad, 0.0);  // + slack rows: kernels read 4 row groups ahead unmasked
     for (size_t r = 0; r < (size_t)nI * nW; ++r) memcpy(&pad[r * ppad], l->db + r * nP, nP * sizeof(double));
     int rc;
     if ((rc = upload(c, c->co_allocs, pad.data(), pad.size(), &T.co))) return rc;
@@ -246,9 +246,9 @@ static int upload_co(xsw_ctx *c, const xsw_lut *l)
                      ? 1 : 0;
     // transposed slices for the ray scan
     double *dT = nullptr;
-    HIPCHK(c, hipMalloc((void **)&dT, (size_t)nI * nP * wpad * sizeof(double) + 64));
+    HIPCHK(c, hipMalloc((void **)&dT, (size_t)nI * nP * wpad * sizeof(double) + 512 * sizeof(double)));
     c->co_allocs.push_back(dT);
-    HIPCHK(c, hipMemsetAsync(dT, 0, (size_t)nI * nP * wpad * sizeof(double), c->stream));
+    HIPCHK(c, hipMemsetAsync(dT, 0, (size_t)nI * nP * wpad * sizeof(double) + 512 * sizeof(double), c->stream));
     dim3 grid((nP + 31) / 32, (nW + 31) / 32, nI);
     hipLaunchKernelGGL(k_transpose_slices, grid, dim3(256), 0, c->stream, T.co, dT, nW, nP, ppad, wpad);
     HIPCHK(c, hipGetLastError());

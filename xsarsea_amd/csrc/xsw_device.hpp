@@ -58,6 +58,21 @@ __device__ __forceinline__ double rd_lane_d(double v, int l)
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
 }
+// v_min_f64 / v_max_f64 without the NaN-canonicalisation moves clang adds around fmin/fmax
+// (callers guarantee non-NaN operands).
+__device__ __forceinline__ double vmin(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double vmax(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // DPP lane permutes (no LDS traffic): ctrl codes of the gfx9 family -- quad_perm 0x00-0xFF,
 // row_half_mirror 0x141, row_mirror 0x140, row_bcast:15 0x142, row_bcast:31 0x143.
 template <int CTRL, int ROW_MASK>
@@ -208,24 +223,28 @@ __device__ __forceinline__ int pruned_search_co(const DevTables &L, int i_inc, d
     const double inf = __builtin_inf();
     const double wh0 = 0.5 * L.w0, whs = 0.5 / L.inv_wstep;  // screening only needs w/2 to ~1e-15
 
-    // 1. upper bound along the direction nearest to the ancillary wind (transposed slice: contiguous)
+    // 1. upper bound along the direction nearest to the ancillary wind (transposed slice: contiguous).
+    //    p(w) = wh*(wh - U) is advanced by forward differences (2 adds per candidate).
     const double ur = 2.0 * (ah * L.cphi[ipr] + bh * L.sphi[ipr]);
     const double *__restrict__ ray = L.coT + ((size_t)i_inc * L.n_phi + ipr) * L.w_pad;
     double rbest = inf;
-    for (int base = 0; base < L.n_w; base += 256) {
-        double v[4];
+    {
+        const double d64 = 64.0 * whs;
+        double wh = fma((double)lane, whs, wh0);
+        double pw = wh * (wh - ur), dp = d64 * (2.0 * wh - ur) + d64 * d64;
+        const double ddp = 2.0 * d64 * d64;
+        for (int base = 0; base < L.n_w; base += 256) {
+            double v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int iw = base + k * 64 + lane;
-            v[k] = ray[iw < L.n_w ? iw : 0];
-        }
+            for (int k = 0; k < 4; ++k) v[k] = ray[base + k * 64 + lane];  // w_pad rows + 256 doubles of slack
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int iw = base + k * 64 + lane;
-            const double wh = fma((double)iw, whs, wh0);
-            const double dd = fma(v[k], inv_dsig, sn);
-            const double J = fma(dd, dd, wh * (wh - ur));
-            rbest = fmin(rbest, iw < L.n_w ? J : inf);
+            for (int k = 0; k < 4; ++k) {
+                const double dd = fma(v[k], inv_dsig, sn);
+                const double J = fma(dd, dd, pw);
+                rbest = vmin(rbest, (base + k * 64 + lane) < L.n_w ? J : inf);
+                pw += dp;
+                dp += ddp;
+            }
         }
     }
     rbest = wave_min_d(rbest);
@@ -261,7 +280,10 @@ __device__ __forceinline__ int pruned_search_co(const DevTables &L, int i_inc, d
     }
     cand += (unsigned)(nrows * ncols);
 
-    // 3. screen the box: lanes = directions (<= 64 per chunk), narrow chunks fold several speed rows
+    // 3. screen the box: lanes = directions (<= 64 per chunk); a narrow chunk folds G = 64/W speed rows
+    //    into one wave iteration.  Rows are taken four groups at a time: the window is rounded up to a
+    //    multiple of 4*G rows (extra rows are real candidates, scoring them is harmless) and slid down
+    //    if it would leave the grid; only a window taller than the whole grid needs row masking.
     const double *__restrict__ slice = L.co + (size_t)i_inc * L.n_w * L.phi_pad;
     double best = inf, second = inf;
     int bidx = 0;  // (iw << 16) | ip
@@ -272,27 +294,39 @@ __device__ __forceinline__ int pruned_search_co(const DevTables &L, int i_inc, d
         const int col = lane & ((1 << sh) - 1), grp = lane >> sh;
         const bool act = col < width;
         const int ip = ip_lo + c0 + (act ? col : 0);
-        const double U = 2.0 * (ah * L.cphi[ip] + bh * L.sphi[ip]);
-        const double *__restrict__ colp = slice + ip;
-        for (int r0 = 0; r0 < nrows; r0 += 4 * G) {
+        // inactive lanes: U = -inf makes every score +inf, no per-candidate masking
+        const double U = act ? 2.0 * (ah * L.cphi[ip] + bh * L.sphi[ip]) : -inf;
+        const int step = 4 * G;
+        int rows_r = (nrows + step - 1) / step * step;
+        int w_base = w_lo;
+        const bool mask_rows = rows_r > L.n_w;
+        if (!mask_rows && w_base + rows_r > L.n_w) w_base = L.n_w - rows_r;
+        const double dG = (double)G * whs;
+        double wh = fma((double)(w_base + grp), whs, wh0);
+        double pw = act ? wh * (wh - U) : inf, dp = act ? dG * (2.0 * wh - U) + dG * dG : 0.0;
+        const double ddp = 2.0 * dG * dG;
+        const double *ptr = slice + (size_t)(w_base + grp) * L.phi_pad + ip;
+        const size_t pstep = (size_t)G * L.phi_pad;
+        int code = -1;  // iteration slot of this lane's best within the chunk
+        for (int r0 = 0; r0 < rows_r; r0 += step) {
             double v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int r = r0 + k * G + grp;
-                v[k] = colp[(w_lo + (r < nrows ? r : 0)) * L.phi_pad];
-            }
+            for (int k = 0; k < 4; ++k) v[k] = ptr[k * pstep];  // allocation carries slack rows past the LUT end
+            ptr += 4 * pstep;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int r = r0 + k * G + grp;
-                const int iw = w_lo + r;
-                const double wh = fma((double)iw, whs, wh0);
                 const double dd = fma(v[k], inv_dsig, sn);
-                double J = fma(dd, dd, wh * (wh - U));
-                J = (act && r < nrows) ? J : inf;
-                second = fmin(second, fmax(J, best));
-                if (J < best) { best = J; bidx = (iw << 16) | ip; }
+                double J = fma(dd, dd, pw);
+                if (mask_rows) J = (w_base + r0 + k * G + grp) < L.n_w ? J : inf;
+                second = vmin(second, vmax(J, best));
+                const bool lt = J < best;
+                best = lt ? J : best;
+                code = lt ? (r0 + k * G) : code;
+                pw += dp;
+                dp += ddp;
             }
         }
+        if (code >= 0) bidx = ((w_base + code + grp) << 16) | ip;
     }
 
     // 4. settle: a unique candidate within eps of the screening minimum IS the reference's argmin;
