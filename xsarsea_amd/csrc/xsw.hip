@@ -296,8 +296,9 @@ extern "C" int xsw_lut_upload(xsw_ctx *c, const xsw_lut *co, const xsw_lut *cr)
 template <typename T, typename TO>
 static int launch_invert(xsw_ctx *c, const KArgs &A, int algo)
 {
-    const long long nstrips = (A.n + 63) / 64;
-    const long long nblocks = (nstrips + 3) / 4;
+    // k_invert grid: 8 XCD lanes x ceil(columns/8) tile columns x line groups (see the kernel)
+    const long long strips_per_line = (A.samples + 63) / 64, line_groups = (A.lines + 3) / 4;
+    const long long nblocks = 8 * ((strips_per_line + 7) / 8) * line_groups;
     if (nblocks > 0x7fffffffLL) return fail(c, XSW_EINVAL, "raster too large for one launch");
     if (algo == XSW_ALGO_EXHAUSTIVE) return launch_exhaustive<T, TO>(c->T, A, c->stream) == hipSuccess
                                                 ? XSW_OK : fail(c, XSW_EHIP, "exhaustive launch failed: %s", hipGetErrorString(hipGetLastError()));

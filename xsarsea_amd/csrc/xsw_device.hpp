@@ -576,14 +576,24 @@ template <typename T, typename TO, int ALGO>
 __global__ __launch_bounds__(256) void k_invert(DevTables L, KArgs A)
 {
     const int lane = threadIdx.x & 63;
-    const long long strip = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long i = strip * 64 + lane;
-    if (strip * 64 >= A.n) return;  // whole wave out of range
-    const bool in = i < A.n;
+    // Raster tile of this workgroup: 4 lines x 64 samples (one strip per wave).  Incidence varies along
+    // `sample` only, so a column of tiles shares one or two LUT slices.  Workgroups are dealt round-robin
+    // over the 8 XCDs (b % 8 shares an XCD; placement is a speed heuristic, never a correctness
+    // assumption): XCD x walks its own contiguous range of tile columns, line groups fastest, so that the
+    // waves resident on one XCD at any time work in the same few slices and its L2 keeps them.
+    const long long strips_per_line = (A.samples + 63) >> 6, line_groups = (A.lines + 3) >> 2;
+    const long long cols_per_xcd = (strips_per_line + 7) >> 3;
+    const long long xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const long long col = xcd * cols_per_xcd + j / line_groups;
+    const long long line = (j % line_groups) * 4 + (threadIdx.x >> 6);
+    if (j / line_groups >= cols_per_xcd || col >= strips_per_line || line >= A.lines) return;  // wave-uniform
+    const long long smp = col * 64 + lane;
+    const bool in = smp < A.samples;
+    const long long i = line * A.samples + (in ? smp : A.samples - 1);
     const double nan = __builtin_nan("");
 
     Pixel P;
-    load_pixel<T>(L, A, in ? i : (A.n - 1), in, P);
+    load_pixel<T>(L, A, i, in, P);
 
     // ---- wave-cooperative searches, one pixel at a time, parameters wave-uniform
     int my_flat = -1, my_icr = -1;
