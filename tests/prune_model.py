@@ -10,8 +10,8 @@ observed sigma0 in dB, c = w*(cos phi, sin phi) a candidate and L its LUT value:
 
     J(c) = |c - m|^2 / 4 + ((L - s)/dsig)^2          (windspeed.py:220-225)
 
-1. Upper bound: evaluate J along the ray phi_r nearest to the direction of m, all wind speeds.
-   J_ub = min over the ray.
+1. Upper bound: evaluate J along the ray phi_r nearest to the direction of m, over at most 256 wind
+   speeds centred on |m| (any subset of candidates bounds the minimum from above).  J_ub = min.
 2. Since both terms are >= 0, a candidate with |c - m|^2/4 > J_ub cannot be the argmin: only the
    disc |c - m| <= R = 2*sqrt(J_ub) matters.  Its polar bounding box is
    w in [|m|-R, |m|+R],  phi in [theta - asin(R/|m|), theta + asin(R/|m|)]  (all phi if R >= |m|).
@@ -32,17 +32,19 @@ def search_window(mag, theta_deg, j_ub, w0, inv_wstep, n_w, phi0, phi_last, inv_
     |c - m|^2/4 <= j_ub (uniform axes; one index of slack on every side).  theta_deg is the
     direction of m normalised into [phi0, phi0 + 360)."""
     j_ub = j_ub * (1.0 + 1e-9) + 1e-9
-    R = 2.0 * np.sqrt(j_ub)
+    R = float(np.float32(2.0) * np.sqrt(np.float32(j_ub)) * np.float32(1.001) + np.float32(1e-3))  # kernel: float32
     lo = np.floor(np.clip((mag - R - w0) * inv_wstep, -4.0, n_w + 4.0)) - 1
     hi = np.ceil(np.clip((mag + R - w0) * inv_wstep, -4.0, n_w + 4.0)) + 1
     w_lo = int(max(lo, 0))
     w_hi = int(min(hi, n_w - 1))
-    if not (R < mag * (1.0 - 1e-12)):
+    if not (mag < 1e4 and R < 1e4):
+        return 0, n_w - 1, 0, n_phi - 1
+    if not (R < mag * 0.9999):
         return w_lo, w_hi, 0, n_phi - 1  # the disc contains the origin: every direction
-    half = np.degrees(np.arcsin(R / mag))
+    half = np.degrees(np.arcsin(R / mag)) + 0.01
     plo = np.floor((theta_deg - half - phi0) * inv_dphi) - 1
     phi_hi = np.ceil((theta_deg + half - phi0) * inv_dphi) + 1
-    if phi_last - theta_deg <= 180.0 and theta_deg - phi0 <= 180.0:
+    if phi_last - theta_deg <= 179.9 and theta_deg - phi0 <= 179.9:
         # no axis direction is more than 180 deg from theta: |phi - theta| is the true angular
         # distance, so directions outside the window are outside the disc -> clamp to the axis
         return w_lo, w_hi, int(max(plo, 0)), int(min(phi_hi, n_phi - 1))
@@ -77,8 +79,10 @@ def pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig):
     ipr = int(np.clip(np.rint((theta - phi0) * inv_dphi), 0, n_phi - 1))
     wh = 0.5 * wspd
     ur = 2.0 * (ah * cphi[ipr] + bh * sphi[ipr])
-    dd = slice_wp[:, ipr] * inv + sn
-    ray = wh * (wh - ur) + dd * dd
+    nray = min(n_w, 256)
+    r_lo = min(max(int((mag - w0) * inv_wstep) - nray // 2, 0), n_w - nray)
+    dd = slice_wp[r_lo:r_lo + nray, ipr] * inv + sn
+    ray = wh[r_lo:r_lo + nray] * (wh[r_lo:r_lo + nray] - ur) + dd * dd
     j_ub = ray.min() + m2
     w_lo, w_hi, ip_lo, ip_hi = search_window(mag, theta, j_ub, w0, inv_wstep, n_w, phi0, phi[-1], inv_dphi, n_phi)
     u = 2.0 * (ah * cphi[ip_lo:ip_hi + 1] + bh * sphi[ip_lo:ip_hi + 1])
@@ -95,4 +99,4 @@ def pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig):
         if best is None or key < best:
             best = key
     flat = best[1]
-    return flat // n_phi, flat % n_phi, js.size + n_w
+    return flat // n_phi, flat % n_phi, js.size + nray

@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace xsw {
 
 struct DevTables {
@@ -85,12 +87,12 @@ __device__ __forceinline__ double dpp_d(double v)
 // minimum over the 64 lanes, returned wave-uniform (every lane must be active)
 __device__ __forceinline__ double wave_min_d(double v)
 {
-    v = fmin(v, dpp_d<0xB1, 0xF>(v));   // lane ^ 1
-    v = fmin(v, dpp_d<0x4E, 0xF>(v));   // lane ^ 2
-    v = fmin(v, dpp_d<0x141, 0xF>(v));  // 8-lane halves mirrored
-    v = fmin(v, dpp_d<0x140, 0xF>(v));  // 16-lane rows mirrored
-    v = fmin(v, dpp_d<0x142, 0xA>(v));  // lane 15 of rows 0,2 -> rows 1,3
-    v = fmin(v, dpp_d<0x143, 0xC>(v));  // lane 31 -> rows 2,3
+    v = vmin(v, dpp_d<0xB1, 0xF>(v));   // lane ^ 1
+    v = vmin(v, dpp_d<0x4E, 0xF>(v));   // lane ^ 2
+    v = vmin(v, dpp_d<0x141, 0xF>(v));  // 8-lane halves mirrored
+    v = vmin(v, dpp_d<0x140, 0xF>(v));  // 16-lane rows mirrored
+    v = vmin(v, dpp_d<0x142, 0xA>(v));  // lane 15 of rows 0,2 -> rows 1,3
+    v = vmin(v, dpp_d<0x143, 0xC>(v));  // lane 31 -> rows 2,3
     return rd_lane_d(v, 63);
 }
 // lexicographic (J, idx) minimum over the wave; J never NaN here
@@ -229,48 +231,52 @@ __device__ __forceinline__ int pruned_search_co(const DevTables &L, int i_inc, d
     const double *__restrict__ ray = L.coT + ((size_t)i_inc * L.n_phi + ipr) * L.w_pad;
     double rbest = inf;
     {
+        // at most 256 speeds, centred on the ancillary speed: any subset of candidates bounds the minimum
+        // from above; a pixel whose solution lies further than that from its a-priori just gets a wider box
+        const int nray = min(L.n_w, 256);
+        const int r_lo = min(max((int)((mag - L.w0) * L.inv_wstep) - nray / 2, 0), L.n_w - nray);
         const double d64 = 64.0 * whs;
-        double wh = fma((double)lane, whs, wh0);
+        double wh = fma((double)(r_lo + lane), whs, wh0);
         double pw = wh * (wh - ur), dp = d64 * (2.0 * wh - ur) + d64 * d64;
         const double ddp = 2.0 * d64 * d64;
-        for (int base = 0; base < L.n_w; base += 256) {
-            double v[4];
+        double v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = ray[base + k * 64 + lane];  // w_pad rows + 256 doubles of slack
+        for (int k = 0; k < 4; ++k) v[k] = ray[r_lo + k * 64 + lane];  // w_pad rows + 512 doubles of slack
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double dd = fma(v[k], inv_dsig, sn);
-                const double J = fma(dd, dd, pw);
-                rbest = vmin(rbest, (base + k * 64 + lane) < L.n_w ? J : inf);
-                pw += dp;
-                dp += ddp;
-            }
+        for (int k = 0; k < 4; ++k) {
+            const double dd = fma(v[k], inv_dsig, sn);
+            const double J = fma(dd, dd, pw);
+            rbest = vmin(rbest, (k * 64 + lane) < nray ? J : inf);
+            pw += dp;
+            dp += ddp;
         }
+        cand += (unsigned)nray;
     }
     rbest = wave_min_d(rbest);
-    cand += (unsigned)L.n_w;
     const double jub = (rbest + m2) * (1.0 + 1e-9) + 1e-9;
 
-    // 2. polar bounding box of the disc |c - m| <= R  (one index of slack on every side)
-    const double R = 2.0 * sqrt(jub);
-    const double nwd = (double)L.n_w;
-    int w_lo = (int)floor(fmin(fmax((mag - R - L.w0) * L.inv_wstep, -4.0), nwd + 4.0)) - 1;
-    int w_hi = (int)ceil(fmin(fmax((mag + R - L.w0) * L.inv_wstep, -4.0), nwd + 4.0)) + 1;
-    w_lo = max(w_lo, 0);
-    w_hi = min(w_hi, L.n_w - 1);
-    int ip_lo = 0, ip_hi = L.n_phi - 1;
-    if (R < mag * (1.0 - 1e-6)) {
-        // half-width of the disc seen from the origin; float is ample: the slack is a whole grid step
-        const double half = (double)(asinf((float)(R / mag)) * 57.29578f) + 1e-3;
-        const double nphd = (double)L.n_phi;
-        const int plo = (int)floor(fmin(fmax((theta - half - L.phi0) * L.inv_dphi, -4.0), nphd + 4.0)) - 1;
-        const int phi_i = (int)ceil(fmin(fmax((theta + half - L.phi0) * L.inv_dphi, -4.0), nphd + 4.0)) + 1;
-        if (L.phi_last - theta <= 180.0 && theta - L.phi0 <= 180.0) {
-            ip_lo = max(plo, 0);
-            ip_hi = min(phi_i, L.n_phi - 1);
-        } else if (plo >= 0 && phi_i <= L.n_phi - 1) {
-            ip_lo = plo;
-            ip_hi = phi_i;
+    // 2. polar bounding box of the disc |c - m| <= R, one index of slack on every side.  float32 is ample
+    //    here: every rounding is covered by the 1e-3 inflation of R plus a whole grid step of slack
+    //    (huge ancillary winds, where float32 could not resolve a grid step, take the whole axis).
+    const float Rf = 2.0f * sqrtf((float)jub) * 1.001f + 1e-3f;
+    const float magf = (float)mag, thf = (float)theta;
+    const float nwf = (float)L.n_w, w0f = (float)L.w0, iwsf = (float)L.inv_wstep;
+    int w_lo = 0, w_hi = L.n_w - 1, ip_lo = 0, ip_hi = L.n_phi - 1;
+    if (magf < 1e4f && Rf < 1e4f) {
+        w_lo = max((int)floorf(fminf(fmaxf((magf - Rf - w0f) * iwsf, -4.0f), nwf + 4.0f)) - 1, 0);
+        w_hi = min((int)ceilf(fminf(fmaxf((magf + Rf - w0f) * iwsf, -4.0f), nwf + 4.0f)) + 1, L.n_w - 1);
+        if (Rf < magf * 0.9999f) {
+            const float half = asinf(Rf / magf) * 57.29578f + 0.01f;
+            const float npf = (float)L.n_phi, p0f = (float)L.phi0, idpf = (float)L.inv_dphi;
+            const int plo = (int)floorf(fminf(fmaxf((thf - half - p0f) * idpf, -4.0f), npf + 4.0f)) - 1;
+            const int phi_i = (int)ceilf(fminf(fmaxf((thf + half - p0f) * idpf, -4.0f), npf + 4.0f)) + 1;
+            if ((float)L.phi_last - thf <= 179.9f && thf - p0f <= 179.9f) {
+                ip_lo = max(plo, 0);
+                ip_hi = min(phi_i, L.n_phi - 1);
+            } else if (plo >= 0 && phi_i <= L.n_phi - 1) {
+                ip_lo = plo;
+                ip_hi = phi_i;
+            }
         }
     }
     const int nrows = w_hi - w_lo + 1, ncols = ip_hi - ip_lo + 1;
@@ -308,24 +314,27 @@ __device__ __forceinline__ int pruned_search_co(const DevTables &L, int i_inc, d
         const double *ptr = slice + (size_t)(w_base + grp) * L.phi_pad + ip;
         const size_t pstep = (size_t)G * L.phi_pad;
         int code = -1;  // iteration slot of this lane's best within the chunk
-        for (int r0 = 0; r0 < rows_r; r0 += step) {
-            double v[4];
+        auto sweep = [&](auto masked) {
+            for (int r0 = 0; r0 < rows_r; r0 += step) {
+                double v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = ptr[k * pstep];  // allocation carries slack rows past the LUT end
-            ptr += 4 * pstep;
+                for (int k = 0; k < 4; ++k) v[k] = ptr[k * pstep];  // allocation carries slack rows past the LUT end
+                ptr += 4 * pstep;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double dd = fma(v[k], inv_dsig, sn);
-                double J = fma(dd, dd, pw);
-                if (mask_rows) J = (w_base + r0 + k * G + grp) < L.n_w ? J : inf;
-                second = vmin(second, vmax(J, best));
-                const bool lt = J < best;
-                best = lt ? J : best;
-                code = lt ? (r0 + k * G) : code;
-                pw += dp;
-                dp += ddp;
+                for (int k = 0; k < 4; ++k) {
+                    const double dd = fma(v[k], inv_dsig, sn);
+                    double J = fma(dd, dd, pw);
+                    if (masked.value) J = (w_base + r0 + k * G + grp) < L.n_w ? J : inf;
+                    second = vmin(second, vmax(J, best));
+                    const bool lt = J < best;
+                    best = lt ? J : best;
+                    code = lt ? (r0 + k * G) : code;
+                    pw += dp;
+                    dp += ddp;
+                }
             }
-        }
+        };
+        if (mask_rows) sweep(std::true_type{}); else sweep(std::false_type{});
         if (code >= 0) bidx = ((w_base + code + grp) << 16) | ip;
     }
 
