@@ -8,7 +8,7 @@ REPO = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "xsw.hip")
 DEPS = [os.path.join(HERE, "csrc", f) for f in ("xsw.hip", "xsw_device.hpp", "xsw_exhaustive.hpp")] + [
     os.path.join(REPO, "include", "xsw.h")]
-LIB = os.path.join(HERE, "libxsw.so")
+LIB = os.environ.get("XSW_LIB") or os.path.join(HERE, "libxsw.so")  # XSW_LIB: experiment builds only
 ARCH = "gfx950"
 
 

@@ -581,8 +581,11 @@ __device__ __forceinline__ void store_pixel(const DevTables &L, const KArgs &A, 
 }
 
 // Production kernel.  ALGO: 1 = branch-and-bound, 3 = exact full sweep for every pixel.
+#ifndef XSW_INVERT_WAVES_PER_SIMD
+#define XSW_INVERT_WAVES_PER_SIMD 1
+#endif
 template <typename T, typename TO, int ALGO>
-__global__ __launch_bounds__(256) void k_invert(DevTables L, KArgs A)
+__global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTables L, KArgs A)
 {
     const int lane = threadIdx.x & 63;
     // Raster tile of this workgroup: 4 lines x 64 samples (one strip per wave).  Incidence varies along
