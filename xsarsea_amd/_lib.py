@@ -216,6 +216,13 @@ class Context:
                             _ptr(idx), dsig_co, dsig_scalar, sigma0_is_db, ALGOS.get(algo, algo), dual_select)
         return out_co, out_cr, idx
 
+    def detrend_raw(self, lines, samples, dtype, out_dtype, mem, sigma0_ptr, ratio_row, out_ptr):
+        """Thin call of xsw_detrend (raster pointers are ints; ratio_row is a host float64 array)."""
+        ratio_row = _f64(ratio_row)
+        self._check(self._lib.xsw_detrend(self._h, int(lines), int(samples), dtype, out_dtype, mem,
+                                          ctypes.c_void_p(sigma0_ptr), _ptr(ratio_row), ctypes.c_void_p(out_ptr)),
+                    "xsw_detrend")
+
     def detrend_host(self, sigma0, ratio_row, out_dtype=np.float64):
         sigma0 = np.ascontiguousarray(sigma0)
         if sigma0.dtype not in (np.float32, np.float64):
