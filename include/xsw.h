@@ -126,6 +126,18 @@ int xsw_invert(xsw_ctx *ctx, const xsw_invert_args *args);
 int xsw_stats_enable(xsw_ctx *ctx, int on);
 int xsw_stats_read(xsw_ctx *ctx, xsw_stats *out);
 
+/* Replaces the low->high resolution interpolation of Model._normalize_lut (windspeed/models.py:142-168:
+ * `lut.interp(incidence=, wspd=, phi=)`, i.e. three sequential linear 1-D interpolations in the order
+ * incidence -> wspd -> phi) on the device, with the arithmetic of scipy.interp1d
+ * (slope = (y_hi-y_lo)/(x_hi-x_lo); y = slope*(x_new-x_lo) + y_lo) so that the result is bit-identical.
+ * raw[n_inc_raw][n_wspd_raw][n_phi_raw] and out[n_inc][n_wspd][n_phi] are host pointers (n_phi* = 0 for a
+ * cross-pol table).  ValueError-equivalent (XSW_EINVAL) when a target point lies outside the raw axis
+ * (bounds_error=True) or an axis is not strictly ascending. */
+int xsw_lut_interp(xsw_ctx *ctx, const double *raw, const double *inc_raw, const double *wspd_raw,
+                   const double *phi_raw, int32_t n_inc_raw, int32_t n_wspd_raw, int32_t n_phi_raw,
+                   const double *inc, const double *wspd, const double *phi, int32_t n_inc, int32_t n_wspd,
+                   int32_t n_phi, double *out);
+
 /* Replaces the per-pixel part of sigma0_detrend (detrend.py:63-64):
  * out[l][s] = sigma0[l][s] / ratio_row[s], ratio_row = g / nanmean(g) (float64, host pointer).
  * out is float64 (the reference's result dtype) when out_dtype == XSW_F64. */

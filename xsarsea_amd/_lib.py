@@ -14,7 +14,7 @@ ALGOS = {"auto": ALGO_AUTO, "pruned": ALGO_PRUNED, "exhaustive": ALGO_EXHAUSTIVE
 
 EXPORTS = (
     "xsw_version", "xsw_device_count", "xsw_ctx_create", "xsw_ctx_destroy", "xsw_last_error", "xsw_set_stream", "xsw_use_own_stream",
-    "xsw_synchronize", "xsw_lut_upload", "xsw_invert", "xsw_stats_enable", "xsw_stats_read", "xsw_detrend",
+    "xsw_synchronize", "xsw_lut_upload", "xsw_invert", "xsw_stats_enable", "xsw_stats_read", "xsw_detrend", "xsw_lut_interp",
 )
 
 
@@ -72,12 +72,22 @@ def load():
         lib.xsw_stats_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(Stats)]
         lib.xsw_detrend.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                     ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.xsw_lut_interp.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4 + [ctypes.c_int32] * 3 + \
+            [ctypes.c_void_p] * 3 + [ctypes.c_int32] * 3 + [ctypes.c_void_p]
         _cdll = lib
     return _cdll
 
 
 def device_count():
     return load().xsw_device_count()
+
+
+def device_count_safe():
+    """0 when the library is not built (host-only uses such as LUT preparation in a CPU-only session)."""
+    try:
+        return device_count()
+    except (XswError, OSError):
+        return 0
 
 
 def _f64(a):
@@ -159,6 +169,19 @@ class Context:
             keep.append(k)
         self._check(self._lib.xsw_lut_upload(self._h, ctypes.byref(sco) if sco else None,
                                              ctypes.byref(scr) if scr else None), "xsw_lut_upload")
+
+    def lut_interp(self, raw, inc_raw, wspd_raw, phi_raw, inc, wspd, phi):
+        """xsw_lut_interp: (incidence, wspd[, phi]) table -> finer axes, bit-identical to three interp1d passes."""
+        raw, inc_raw, wspd_raw, inc, wspd = map(_f64, (raw, inc_raw, wspd_raw, inc, wspd))
+        has_phi = phi_raw is not None
+        phi_raw = _f64(phi_raw) if has_phi else None
+        phi = _f64(phi) if has_phi else None
+        out = np.empty((len(inc), len(wspd)) + ((len(phi),) if has_phi else ()), dtype=np.float64)
+        self._check(self._lib.xsw_lut_interp(
+            self._h, _ptr(raw), _ptr(inc_raw), _ptr(wspd_raw), _ptr(phi_raw), len(inc_raw), len(wspd_raw),
+            len(phi_raw) if has_phi else 0, _ptr(inc), _ptr(wspd), _ptr(phi), len(inc), len(wspd),
+            len(phi) if has_phi else 0, _ptr(out)), "xsw_lut_interp")
+        return out
 
     def stats_enable(self, on=True):
         self._check(self._lib.xsw_stats_enable(self._h, int(bool(on))), "xsw_stats_enable")

@@ -404,6 +404,86 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
     return rc;
 }
 
+// ---------------------------------------------------------------------------------------- LUT interpolation
+static bool left_neighbours(const double *x_old, int n_old, const double *x_new, int n_new, std::vector<int> &lo)
+{
+    // scipy interp1d: searchsorted(x_old, x_new) (side='left'), clip(1, n-1), minus one; bounds_error=True
+    lo.resize(n_new);
+    for (int i = 0; i < n_new; ++i) {
+        const double x = x_new[i];
+        if (!(x >= x_old[0] && x <= x_old[n_old - 1])) return false;
+        int a = 0, b = n_old;
+        while (a < b) { int m = (a + b) >> 1; if (x_old[m] < x) a = m + 1; else b = m; }
+        int hi = a < 1 ? 1 : (a > n_old - 1 ? n_old - 1 : a);
+        lo[i] = hi - 1;
+    }
+    return true;
+}
+
+extern "C" int xsw_lut_interp(xsw_ctx *c, const double *raw, const double *inc_raw, const double *wspd_raw,
+                              const double *phi_raw, int32_t n_inc_raw, int32_t n_wspd_raw, int32_t n_phi_raw,
+                              const double *inc, const double *wspd, const double *phi, int32_t n_inc, int32_t n_wspd,
+                              int32_t n_phi, double *out)
+{
+    if (!c) return XSW_EINVAL;
+    if (!raw || !inc_raw || !wspd_raw || !inc || !wspd || !out || n_inc_raw < 2 || n_wspd_raw < 2 || n_inc < 1 || n_wspd < 1)
+        return fail(c, XSW_EINVAL, "lut_interp: null pointer or axis shorter than 2");
+    const bool has_phi = n_phi_raw > 0;
+    if (has_phi && (!phi_raw || !phi || n_phi_raw < 2 || n_phi < 1)) return fail(c, XSW_EINVAL, "lut_interp: bad phi axis");
+    if (!strictly_ascending(inc_raw, n_inc_raw) || !strictly_ascending(wspd_raw, n_wspd_raw) ||
+        (has_phi && !strictly_ascending(phi_raw, n_phi_raw)))
+        return fail(c, XSW_EINVAL, "lut_interp: raw axes must be strictly ascending");
+    std::vector<int> loi, low, lop;
+    if (!left_neighbours(inc_raw, n_inc_raw, inc, n_inc, loi) || !left_neighbours(wspd_raw, n_wspd_raw, wspd, n_wspd, low) ||
+        (has_phi && !left_neighbours(phi_raw, n_phi_raw, phi, n_phi, lop)))
+        return fail(c, XSW_EINVAL, "A value in x_new is outside the interpolation range.");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<void *> tmp;
+    InterpArgs a{};
+    int rc = XSW_OK;
+    auto up = [&](const void *h, size_t bytes, const void **d) {
+        void *p = nullptr;
+        if (rc) return;
+        if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) { rc = fail(c, XSW_ENOMEM, "lut_interp: hipMalloc failed"); return; }
+        tmp.push_back(p);
+        if (bytes && hipMemcpyAsync(p, h, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(c, XSW_EHIP, "lut_interp: H2D failed");
+        *d = p;
+    };
+    const size_t n_raw = (size_t)n_inc_raw * n_wspd_raw * (has_phi ? n_phi_raw : 1);
+    const size_t n_out = (size_t)n_inc * n_wspd * (has_phi ? n_phi : 1);
+    up(raw, n_raw * 8, (const void **)&a.raw);
+    up(inc_raw, (size_t)n_inc_raw * 8, (const void **)&a.xi_raw);
+    up(wspd_raw, (size_t)n_wspd_raw * 8, (const void **)&a.xw_raw);
+    up(inc, (size_t)n_inc * 8, (const void **)&a.xi);
+    up(wspd, (size_t)n_wspd * 8, (const void **)&a.xw);
+    up(loi.data(), loi.size() * 4, (const void **)&a.loi);
+    up(low.data(), low.size() * 4, (const void **)&a.low);
+    if (has_phi) {
+        up(phi_raw, (size_t)n_phi_raw * 8, (const void **)&a.xp_raw);
+        up(phi, (size_t)n_phi * 8, (const void **)&a.xp);
+        up(lop.data(), lop.size() * 4, (const void **)&a.lop);
+    }
+    if (!rc) {
+        void *p = nullptr;
+        if (hipMalloc(&p, n_out * 8) != hipSuccess) rc = fail(c, XSW_ENOMEM, "lut_interp: hipMalloc(out) failed");
+        else { tmp.push_back(p); a.out = (double *)p; }
+    }
+    a.ni_raw = n_inc_raw; a.nw_raw = n_wspd_raw; a.np_raw = has_phi ? n_phi_raw : 0;
+    a.ni = n_inc; a.nw = n_wspd; a.np = has_phi ? n_phi : 0;
+    if (!rc) {
+        long long blocks = (long long)((n_out + 255) / 256);
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(k_lut_interp, dim3((unsigned)blocks), dim3(256), 0, c->stream, a);
+        if (hipGetLastError() != hipSuccess) rc = fail(c, XSW_EHIP, "lut_interp: launch failed");
+    }
+    if (!rc && hipMemcpyAsync(out, a.out, n_out * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+        rc = fail(c, XSW_EHIP, "lut_interp: D2H failed");
+    hipError_t se = hipStreamSynchronize(c->stream);
+    if (!rc && se != hipSuccess) rc = fail(c, XSW_EHIP, "lut_interp: %s", hipGetErrorString(se));
+    for (void *p : tmp) (void)hipFree(p);
+    return rc;
+}
+
 // ---------------------------------------------------------------------------------------- detrend
 template <typename T, typename TO>
 static void launch_detrend(hipStream_t s, const void *in, const double *ratio, void *out, long long lines, long long samples)

@@ -676,6 +676,44 @@ __global__ __launch_bounds__(256) void k_transpose_slices(const double *__restri
     }
 }
 
+// LUT resolution change (models.py:142-168): out[i][j][k] = lerp_phi(lerp_wspd(lerp_inc(raw))) with the
+// staged rounding of three sequential interp1d passes.  lo*[] hold, per target point, the index of the left
+// raw neighbour (searchsorted(...).clip(1, n-1) - 1, computed on the host).  n_phi == 0: 2-D table.
+struct InterpArgs {
+    const double *raw, *xi_raw, *xw_raw, *xp_raw, *xi, *xw, *xp;
+    const int *loi, *low, *lop;
+    double *out;
+    int ni_raw, nw_raw, np_raw, ni, nw, np;
+};
+__device__ __forceinline__ double lerp1(double y_lo, double y_hi, double x_lo, double x_hi, double x)
+{
+    const double slope = (y_hi - y_lo) / (x_hi - x_lo);
+    return slope * (x - x_lo) + y_lo;
+}
+__global__ __launch_bounds__(256) void k_lut_interp(InterpArgs a)
+{
+    const int np = a.np > 0 ? a.np : 1, np_raw = a.np_raw > 0 ? a.np_raw : 1;
+    const long long n = (long long)a.ni * a.nw * np;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(t % np), j = (int)((t / np) % a.nw), i = (int)(t / ((long long)np * a.nw));
+        const int i0 = a.loi[i], j0 = a.low[j];
+        const double xi0 = a.xi_raw[i0], xi1 = a.xi_raw[i0 + 1], xi = a.xi[i];
+        const double xw0 = a.xw_raw[j0], xw1 = a.xw_raw[j0 + 1], xw = a.xw[j];
+        const int nk = a.np > 0 ? 2 : 1;
+        const int k0 = a.np > 0 ? a.lop[k] : 0;
+        double b[2];
+        for (int kk = 0; kk < nk; ++kk) {
+            double aa[2];
+            for (int jj = 0; jj < 2; ++jj) {
+                const size_t o = ((size_t)i0 * a.nw_raw + (j0 + jj)) * np_raw + (k0 + kk);
+                aa[jj] = lerp1(a.raw[o], a.raw[o + (size_t)a.nw_raw * np_raw], xi0, xi1, xi);  // incidence pass
+            }
+            b[kk] = lerp1(aa[0], aa[1], xw0, xw1, xw);                                          // wspd pass
+        }
+        a.out[t] = a.np > 0 ? lerp1(b[0], b[1], a.xp_raw[k0], a.xp_raw[k0 + 1], a.xp[k]) : b[0];  // phi pass
+    }
+}
+
 // sigma0_detrend's per-pixel work (detrend.py:64): out = sigma0 / ratio[sample]
 template <typename T, typename TO>
 __global__ __launch_bounds__(256) void k_detrend(const T *__restrict__ sigma0, const double *__restrict__ ratio,

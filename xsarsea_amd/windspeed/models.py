@@ -21,6 +21,21 @@ logger = logging.getLogger("xsarsea.windspeed.models")
 _STEP_DEFAULTS = dict(inc_step_lr=1.0, wspd_step_lr=0.2, phi_step_lr=2.5, inc_step=0.1, wspd_step=0.1, phi_step=1.0)
 
 
+def _interp(lut, inc, wspd, phi):
+    """incidence -> wspd -> phi linear interpolation of a Lut; device kernel (xsw_lut_interp) or numpy,
+    same arithmetic and bits either way (tests/test_gpu_api.py::test_lut_interp_device_equals_host)."""
+    from .. import _lib, options
+    mode = options.lut_interp
+    if mode == "device" or (mode == "auto" and _lib.device_count_safe() > 0):
+        ctx = _lib.default_context(options.device)
+        return ctx.lut_interp(lut.values, lut.incidence, lut.wspd, lut.phi, inc, wspd, phi)
+    vals = lerp_axis(lut.values, lut.incidence, inc, 0)
+    vals = lerp_axis(vals, lut.wspd, wspd, 1)
+    if lut.phi is not None:
+        vals = lerp_axis(vals, lut.phi, phi, 2)
+    return vals
+
+
 class Model:
     """Abstract GMF/LUT model.  Registered instances are listed by `available_models()`."""
 
@@ -91,12 +106,9 @@ class Model:
         if resolution == have and not do_interp:
             return lut
         inc, wspd, phi = self._target_axes(resolution, kwargs)
-        vals = lerp_axis(lut.values, lut.incidence, inc, 0)
-        vals = lerp_axis(vals, lut.wspd, wspd, 1)
-        if lut.phi is not None and phi is not None:
-            vals = lerp_axis(vals, lut.phi, phi, 2)
-        else:
+        if lut.phi is None or phi is None:
             phi = lut.phi
+        vals = _interp(lut, inc, wspd, phi)
         return Lut(vals, inc, wspd, phi, **{**lut.attrs, "resolution": resolution})
 
     def _lut(self, units="linear", **kwargs):
