@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--lines", type=int, default=20000)
     ap.add_argument("--samples", type=int, default=20000)
     ap.add_argument("--algo", default="pruned", choices=["pruned", "exhaustive", "exact"])
+    ap.add_argument("--mode", default="mono", choices=["mono", "dual"],
+                    help="mono: CMOD5.N VV (the metric's workload); dual: + Sentinel-1 VH GMF cross-pol refinement (config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stats", action="store_true", help="also report evaluated candidates per pixel (extra pass)")
     args = ap.parse_args()
@@ -204,6 +206,24 @@ def main():
     lines, samples = args.lines, args.samples
     inc, s_vv, anc = make_scene(lines, samples, lines * n_gpus, rank * lines, 20260320 + 2 + rank, device)
     out = torch.empty((lines, samples), dtype=torch.complex64, device=device)
+    s_vh = dsig = out_dual = None
+    if args.mode == "dual":
+        from xsarsea_amd.windspeed import _engine, get_model
+        ctx.upload_luts(cr=_engine._cr_dict(get_model("gmf_s1_v2")._lut(units="dB")))
+        g = torch.Generator(device=device)
+        g.manual_seed(777 + rank)
+        w_abs = anc.abs().clamp(3.0, 80.0).double()  # cross-pol truth ~ the a-priori speed (synthetic)
+        from oracle import gmf as _ogmf  # scene synthesis only (coefficients of the S1 VH GMF)
+        z1, z2, cc = _ogmf._VH_SUM["gmf_s1_v2"]
+        incd = inc.double().nan_to_num(35.0)
+        sig1 = z1[0] * w_abs ** (z1[1] + z1[2] * incd)
+        sig2 = (z2[0] + z2[1] * incd + z2[2] * incd ** 2) * w_abs ** (z2[3] + z2[4] * incd + z2[5] * incd ** 2)
+        vh = sig1 * torch.sigmoid(cc[0] * (w_abs - cc[1])) + sig2 * torch.sigmoid(cc[2] * (w_abs - cc[3]))
+        speck = torch._standard_gamma(torch.full(vh.shape, 100.0, device=device, dtype=torch.float32), generator=g) / 100.0
+        s_vh = (vh.float() * speck + 10 ** -3.5).contiguous()
+        dsig = ((1.25 / (s_vh / 10 ** -3.5)) ** 4.0).contiguous()
+        out_dual = torch.empty((lines, samples), dtype=torch.complex64, device=device)
+        del w_abs, incd, sig1, sig2, vh, speck
     full = None  # rank 0: the gathered (lines * N) x samples raster
     if world > 1 and rank == 0:
         full = torch.empty((lines * world, samples), dtype=torch.complex64, device=device)
@@ -211,8 +231,13 @@ def main():
     from xsarsea_amd import multi_gpu
 
     def step():
-        ctx.invert_raw(lines, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, inc.data_ptr(), s_vv.data_ptr(), None,
-                       None, anc.data_ptr(), out.data_ptr(), None, algo=algo)
+        if args.mode == "dual":
+            ctx.invert_raw(lines, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, inc.data_ptr(), s_vv.data_ptr(),
+                           s_vh.data_ptr(), dsig.data_ptr(), anc.data_ptr(), out.data_ptr(), out_dual.data_ptr(),
+                           algo=algo, dual_select=True)
+        else:
+            ctx.invert_raw(lines, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, inc.data_ptr(), s_vv.data_ptr(),
+                           None, None, anc.data_ptr(), out.data_ptr(), None, algo=algo)
 
     def gather():
         if world > 1:  # the single exchange of the path: output tiles -> rank 0, point-to-point over xGMI
@@ -253,13 +278,14 @@ def main():
     if rank == 0:
         px_step = lines * samples * n_gpus
         value = px_step * args.steps / dt / 1e6
-        achieved = (BYTES_READ_PX + BYTES_WRITE_PX) * lines * samples / (kernel_ms * 1e-3) / 1e9
+        bytes_px = (BYTES_READ_PX + BYTES_WRITE_PX) if args.mode == "mono" else (24 + 16)  # dual: +vh, +dsig; 2 outputs
+        achieved = bytes_px * lines * samples / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(REPO, "profiles", "hbm_traffic.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                key = f"{args.algo}_{lines}x{samples}"
+                key = f"{args.algo}_{lines}x{samples}" if args.mode == "mono" else "-"
                 traffic = tj.get(key)
             except Exception:
                 traffic = None
@@ -270,13 +296,13 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"CMOD5.N mono-VV inversion, {lines}x{samples} float32 sigma0/incidence + complex64 "
                                    f"ancillary per GPU, default LUT 501x499x181 (90319 candidates/pixel), "
-                                   f"complex64 out, algo={args.algo}",
+                                   f"complex64 out, algo={args.algo}, mode={args.mode}",
                        "lines_per_gpu": lines, "samples": samples, "lut": [int(x) for x in lut.shape],
                        "parallelism": f"row tiles x{n_gpus}" + (", RCCL gather to rank 0 in the step" if n_gpus > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel": "k_invert" if args.algo != "exhaustive" else "k_invert_exhaustive",
-                         "kernel_ms": round(kernel_ms, 3), "bytes_per_pixel": BYTES_READ_PX + BYTES_WRITE_PX,
+                         "kernel_ms": round(kernel_ms, 3), "bytes_per_pixel": bytes_px,
                          "note": "algorithmic raster bytes (16 B read + 8 B written per pixel) / mean kernel time "
                                  "(HIP events on the launch stream); the search itself is VALU/L1-bound, see valu"},
         }
@@ -287,7 +313,7 @@ def main():
         if stats:
             res["valu"]["evaluated_candidates_per_pixel"] = round(stats["cand_co"] / max(stats["pixels_co"], 1), 1)
             res["valu"]["pixels_exact_fallback"] = stats["pixels_exact"]
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1 and not args.no_cpu_baseline and args.mode == "mono":
             cpu, parity = cpu_baseline_and_parity(ctx, inc, s_vv, anc, args.algo)
             res["cpu_baseline"] = cpu
             res["parity"] = parity

@@ -411,6 +411,53 @@ __device__ __forceinline__ int search_cr(const DevTables &L, int i_inc, double s
     return eI;
 }
 
+// Cross-pol search, one pixel per lane (all 64 pixels of the strip at once).  The speed axis has the same
+// length for every pixel, so the trip count is wave-uniform and nothing diverges; lanes of one incidence
+// bin read the same LUT word (one cache line per wave load).  Each lane sees ALL candidates of its pixel, so
+// (best, second best) decide uniqueness directly; a lane that cannot decide (near-tie, non-finite input,
+// non-finite LUT) reports `undecided` and is settled by the wave-cooperative exact scan.
+__device__ __forceinline__ void search_cr_lanes(const DevTables &L, bool need, int i_inc, double s, double dsig,
+                                                bool have_co, double aco, int &icr, bool &undecided)
+{
+    const double inf = __builtin_inf();
+    const double inv = 1.0 / dsig;
+    const bool fast = need && L.cr_finite && isfinite(inv) && isfinite(s) && (!have_co || isfinite(aco));
+    const double *__restrict__ row = L.cr + (size_t)(fast ? i_inc : 0) * L.wcr_pad;
+    const double sn = fast ? -s * inv : 0.0, invf = fast ? inv : 0.0;
+    const double f = (fast && have_co) ? 1.0 : 0.0;   // Jwind_cr only when a co-pol wind exists (windspeed.py:259-264)
+    const double g = (fast && have_co) ? -0.5 * aco : 0.0;
+    double best = inf, second = inf;
+    int code = 0;
+    int k = 0;
+    for (; k + 4 <= L.n_wcr; k += 4) {
+        double v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = row[k + q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double dd = fma(v[q], invf, sn);
+            const double t = fma(L.wcrh[k + q], f, g);   // (w - |co|)/2, wave-uniform table word
+            const double J = fma(t, t, dd * dd);
+            second = vmin(second, vmax(J, best));
+            const bool lt = J < best;
+            best = lt ? J : best;
+            code = lt ? (k + q) : code;
+        }
+    }
+    for (; k < L.n_wcr; ++k) {
+        const double dd = fma(row[k], invf, sn);
+        const double t = fma(L.wcrh[k], f, g);
+        const double J = fma(t, t, dd * dd);
+        second = vmin(second, vmax(J, best));
+        const bool lt = J < best;
+        best = lt ? J : best;
+        code = lt ? k : code;
+    }
+    const double T = best + 1e-9 * (1.0 + fabs(best));
+    icr = code;
+    undecided = need && (!fast || !(best < inf) || second <= T);
+}
+
 // hypot as glibc >= 2.35 computes it without FMA (sysdeps/ieee754/dbl-64/e_hypot.c, after C. Borges,
 // "An improved algorithm for hypot(a,b)"): correctly rounded in all but very rare cases.  Verified
 // bit-identical to numpy.hypot on 2e6 random pairs (tests/test_oracle.py).  Used for |wind_dual| in
@@ -610,13 +657,11 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTa
     // ---- wave-cooperative searches, one pixel at a time, parameters wave-uniform
     int my_flat = -1, my_icr = -1;
     unsigned cand = 0, n_exact = 0, n_co = 0, n_cr = 0;
-    unsigned long long todo = __ballot((P.flags & (F_NEED_CO | F_NEED_CR)) != 0);
+    unsigned long long todo = __ballot((P.flags & F_NEED_CO) != 0);
     while (todo) {
         const int p = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
         const int uf = rd_lane_i(P.flags, p);
-        double aco = nan;
-        bool have_co = false;
         if (uf & F_NEED_CO) {
             const int u_iinc = rd_lane_i(P.i_inc, p);
             const double us = rd_lane_d(P.s_co, p), ua = rd_lane_d(P.a_re, p), ub = rd_lane_d(P.b_eff, p);
@@ -633,16 +678,23 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTa
             n_exact += went_exact ? 1u : 0u;
             n_co += 1u;
             if (lane == p) my_flat = flat;
-            if (uf & F_NEED_CR) {
-                aco = L.abs_co[flat];  // np.abs(wind_co): table [n_w][n_phi], flat = iw*n_phi + ip
-                have_co = aco == aco;
-            }
         }
-        if (uf & F_NEED_CR) {
-            const int u_iinc = rd_lane_i(P.i_inc_cr, p);
-            const double us = rd_lane_d(P.s_cr, p), ud = rd_lane_d(P.dsig, p);
-            const int k = search_cr(L, u_iinc, us, ud, have_co, aco, lane, ALGO == 1 && L.cr_finite);
-            n_cr += 1u;
+    }
+
+    // ---- cross-pol search (windspeed.py:252-269): one pixel per lane, then the undecided ones cooperatively
+    if (A.s_cr) {
+        const bool need_cr = (P.flags & F_NEED_CR) != 0;
+        const bool have_co = (P.flags & F_NEED_CO) != 0;  // |wind_co| is never NaN once a co-pol search ran
+        const double aco = have_co ? L.abs_co[my_flat] : nan;  // np.abs(wind_co), table [n_w][n_phi]
+        bool undecided = need_cr;
+        if (ALGO == 1) search_cr_lanes(L, need_cr, P.i_inc_cr, P.s_cr, P.dsig, have_co, aco, my_icr, undecided);
+        n_cr = (unsigned)__popcll(__ballot(need_cr));
+        unsigned long long und = __ballot(undecided);
+        while (und) {
+            const int p = __ffsll((long long)und) - 1;
+            und &= und - 1;
+            const int k = exact_scan_cr(L, rd_lane_i(P.i_inc_cr, p), rd_lane_d(P.s_cr, p), rd_lane_d(P.dsig, p),
+                                        rd_lane_i((int)have_co, p) != 0, rd_lane_d(aco, p), lane);
             if (lane == p) my_icr = k;
         }
     }
