@@ -230,7 +230,24 @@ def main():
     algo = _lib.ALGOS[args.algo]
     from xsarsea_amd import multi_gpu
 
+    # N > 1: the tile is inverted in row chunks so that chunk k travels to rank 0 over xGMI while chunk k+1
+    # is being inverted (RCCL runs on its own stream; requests are waited for at the end of the step)
+    n_chunks = 4 if world > 1 else 1
+    bounds = [(lines * c // n_chunks, lines * (c + 1) // n_chunks) for c in range(n_chunks)]
+    es_in = 4   # float32 rasters
+    pending = []
+
+    def step_chunked():
+        for (r0, r1) in bounds:
+            off = r0 * samples
+            ctx.invert_raw(r1 - r0, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, inc.data_ptr() + off * es_in,
+                           s_vv.data_ptr() + off * es_in, None, None, anc.data_ptr() + off * 8, out.data_ptr() + off * 8,
+                           None, algo=algo)
+            pending.extend(multi_gpu.gather_rows_async(out, lines * world, r0, r1, dst=0, out=full))
+
     def step():
+        if world > 1 and args.mode == "mono":
+            return step_chunked()
         if args.mode == "dual":
             ctx.invert_raw(lines, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, inc.data_ptr(), s_vv.data_ptr(),
                            s_vh.data_ptr(), dsig.data_ptr(), anc.data_ptr(), out.data_ptr(), out_dual.data_ptr(),
@@ -240,7 +257,10 @@ def main():
                            None, None, anc.data_ptr(), out.data_ptr(), None, algo=algo)
 
     def gather():
-        if world > 1:  # the single exchange of the path: output tiles -> rank 0, point-to-point over xGMI
+        if world > 1 and args.mode == "mono":
+            while pending:  # the single exchange of the path, started chunk by chunk inside step()
+                pending.pop().wait()
+        elif world > 1:
             multi_gpu.gather_rows(out, lines * world, dst=0, out=full)
 
     def fence():

@@ -40,6 +40,17 @@ def _worker(rank, world, port, lines, samples, ret):
             ret["ok"] = bool(torch.equal(out, full * 2))
         else:
             assert out is None
+        # pipelined variant used by bench.py (equal tiles): two row chunks, waits deferred
+        if lines % world == 0:
+            per = lines // world
+            glob = torch.zeros_like(full) if rank == 0 else None
+            reqs = []
+            for r0, r1 in ((0, per // 2), (per // 2, per)):
+                reqs += multi_gpu.gather_rows_async(tile, lines, r0, r1, dst=0, out=glob)
+            for q in reqs:
+                q.wait()
+            if rank == 0:
+                ret["ok"] = ret["ok"] and bool(torch.equal(glob, full * 2))
     finally:
         dist.destroy_process_group()
 

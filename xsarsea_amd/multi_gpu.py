@@ -21,6 +21,25 @@ def tile_bounds(lines, world, rank):
     return l0, l1
 
 
+def gather_rows_async(tile, lines, row0, row1, dst=0, group=None, out=None):
+    """Start gathering rows [row0, row1) of every rank's tile (rows are tile-local, the same for all
+    ranks: equal tiles) into `out` on `dst`; returns the list of requests to `wait()` on.  Lets a caller
+    pipeline: invert chunk k, start its gather, invert chunk k+1 while chunk k travels over xGMI."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    ops = []
+    if rank == dst:
+        for r in range(world):
+            t0, _ = tile_bounds(lines, world, r)
+            if r == dst:
+                out[t0 + row0:t0 + row1].copy_(tile[row0:row1], non_blocking=True)
+            else:
+                ops.append(dist.P2POp(dist.irecv, out[t0 + row0:t0 + row1], r, group))
+    else:
+        ops.append(dist.P2POp(dist.isend, tile[row0:row1], dst, group))
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
 def gather_rows(tile, lines, dst=0, group=None, out=None):
     """Gather row tiles (shape (l1-l0, samples, ...)) into the full raster on rank `dst`.
 
