@@ -209,87 +209,106 @@ __device__ __forceinline__ int exact_scan_cr(const DevTables &L, int i_inc, doub
 }
 
 // ------------------------------------------------------------------------------------------------
-// Branch-and-bound co-pol search (tests/prune_model.py is the executable specification).
-// Preconditions (caller): L.prunable, s/a/b finite, b already |b| when phi_180; mag = |(a, b)|,
-// theta = its direction in degrees normalised into [phi0, phi0 + 360), ipr = nearest direction index
-// (all three prepared per lane in load_pixel).  Returns the flat index iw*n_phi+ip (wave-uniform).
-// Memory-latency discipline: every loop issues its (independent) loads four at a time before using
-// them, and nothing inside a loop depends on a cross-lane reduction.
-__device__ __forceinline__ int pruned_search_co(const DevTables &L, int i_inc, double s, double a, double b,
-                                                double mag, double theta, int ipr, double dsig, double inv_dsig,
-                                                int lane, unsigned &cand, bool &went_exact)
-{
-    const double ah = 0.5 * a, bh = 0.5 * b;
-    const double m2 = ah * ah + bh * bh;
-    const double sn = -s * inv_dsig;
-    const double inf = __builtin_inf();
-    const double wh0 = 0.5 * L.w0, whs = 0.5 / L.inv_wstep;  // screening only needs w/2 to ~1e-15
+// Per-lane pixel state shared by the kernels.
+struct Pixel {
+    double s_co, s_cr, dsig, a_re, a_im, b_eff;
+    double mag, theta;  // |(a_re, b_eff)| and its direction in degrees within [phi0, phi0 + 360)
+    int flags, i_inc, i_inc_cr, ipr;
+};
 
-    // 1. upper bound along the direction nearest to the ancillary wind (transposed slice: contiguous).
-    //    p(w) = wh*(wh - U) is advanced by forward differences (2 adds per candidate).
+// Branch-and-bound co-pol search (tests/prune_model.py is the executable specification), in two stages.
+//
+// Stage 1, `co_window_lanes`: ONE PIXEL PER LANE (64 pixels at once, wave-uniform trip count).  Upper bound
+// J_ub = min of the score along the direction nearest to the ancillary wind over <= 256 speeds centred on
+// |ancillary| (transposed slice: each lane streams a contiguous run), then the polar bounding box of the disc
+// |c - m| <= 2 sqrt(J_ub) in index space, one grid step of slack on every side.  float32 is ample for the box:
+// every rounding is covered by the 1e-3 inflation of R plus that slack; huge ancillary winds, where float32
+// could not resolve a grid step, take the whole axis.
+struct CoWindow {
+    int w_lo, w_hi, ip_lo, ip_hi;
+};
+__device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pixel &P, double inv_dsig)
+{
+    const double inf = __builtin_inf();
+    const bool fin = (P.flags & F_CO_FINITE) != 0;
+    const double a = fin ? P.a_re : 0.0, b = fin ? P.b_eff : 0.0, s = fin ? P.s_co : 0.0;
+    const double mag = fin ? P.mag : 0.0, theta = fin ? P.theta : 0.0;
+    const double ah = 0.5 * a, bh = 0.5 * b, m2 = ah * ah + bh * bh, sn = -s * inv_dsig;
+    const double wh0 = 0.5 * L.w0, whs = 0.5 / L.inv_wstep;
+    const int nray = min(L.n_w, 256);  // wave-uniform
+    const int r_lo = min(max((int)((mag - L.w0) * L.inv_wstep) - nray / 2, 0), L.n_w - nray);
+    const int ipr = fin ? P.ipr : 0;
     const double ur = 2.0 * (ah * L.cphi[ipr] + bh * L.sphi[ipr]);
-    const double *__restrict__ ray = L.coT + ((size_t)i_inc * L.n_phi + ipr) * L.w_pad;
+    const double *__restrict__ ray = L.coT + ((size_t)(fin ? P.i_inc : 0) * L.n_phi + ipr) * L.w_pad + r_lo;
+    double wh = fma((double)r_lo, whs, wh0);
+    double pw = wh * (wh - ur), dp = whs * (2.0 * wh - ur) + whs * whs;  // p(w) = wh*(wh-U) by forward differences
+    const double ddp = 2.0 * whs * whs;
     double rbest = inf;
-    {
-        // at most 256 speeds, centred on the ancillary speed: any subset of candidates bounds the minimum
-        // from above; a pixel whose solution lies further than that from its a-priori just gets a wider box
-        const int nray = min(L.n_w, 256);
-        const int r_lo = min(max((int)((mag - L.w0) * L.inv_wstep) - nray / 2, 0), L.n_w - nray);
-        const double d64 = 64.0 * whs;
-        double wh = fma((double)(r_lo + lane), whs, wh0);
-        double pw = wh * (wh - ur), dp = d64 * (2.0 * wh - ur) + d64 * d64;
-        const double ddp = 2.0 * d64 * d64;
+    int k = 0;
+    for (; k + 4 <= nray; k += 4) {
         double v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = ray[r_lo + k * 64 + lane];  // w_pad rows + 512 doubles of slack
+        for (int q = 0; q < 4; ++q) v[q] = ray[k + q];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double dd = fma(v[k], inv_dsig, sn);
-            const double J = fma(dd, dd, pw);
-            rbest = vmin(rbest, (k * 64 + lane) < nray ? J : inf);
+        for (int q = 0; q < 4; ++q) {
+            const double dd = fma(v[q], inv_dsig, sn);
+            rbest = vmin(rbest, fma(dd, dd, pw));
             pw += dp;
             dp += ddp;
         }
-        cand += (unsigned)nray;
     }
-    rbest = wave_min_d(rbest);
+    for (; k < nray; ++k) {
+        const double dd = fma(ray[k], inv_dsig, sn);
+        rbest = vmin(rbest, fma(dd, dd, pw));
+        pw += dp;
+        dp += ddp;
+    }
     const double jub = (rbest + m2) * (1.0 + 1e-9) + 1e-9;
 
-    // 2. polar bounding box of the disc |c - m| <= R, one index of slack on every side.  float32 is ample
-    //    here: every rounding is covered by the 1e-3 inflation of R plus a whole grid step of slack
-    //    (huge ancillary winds, where float32 could not resolve a grid step, take the whole axis).
+    CoWindow W;
+    W.w_lo = 0; W.w_hi = L.n_w - 1; W.ip_lo = 0; W.ip_hi = L.n_phi - 1;
     const float Rf = 2.0f * sqrtf((float)jub) * 1.001f + 1e-3f;
     const float magf = (float)mag, thf = (float)theta;
     const float nwf = (float)L.n_w, w0f = (float)L.w0, iwsf = (float)L.inv_wstep;
-    int w_lo = 0, w_hi = L.n_w - 1, ip_lo = 0, ip_hi = L.n_phi - 1;
     if (magf < 1e4f && Rf < 1e4f) {
-        w_lo = max((int)floorf(fminf(fmaxf((magf - Rf - w0f) * iwsf, -4.0f), nwf + 4.0f)) - 1, 0);
-        w_hi = min((int)ceilf(fminf(fmaxf((magf + Rf - w0f) * iwsf, -4.0f), nwf + 4.0f)) + 1, L.n_w - 1);
+        W.w_lo = max((int)floorf(fminf(fmaxf((magf - Rf - w0f) * iwsf, -4.0f), nwf + 4.0f)) - 1, 0);
+        W.w_hi = min((int)ceilf(fminf(fmaxf((magf + Rf - w0f) * iwsf, -4.0f), nwf + 4.0f)) + 1, L.n_w - 1);
         if (Rf < magf * 0.9999f) {
             const float half = asinf(Rf / magf) * 57.29578f + 0.01f;
             const float npf = (float)L.n_phi, p0f = (float)L.phi0, idpf = (float)L.inv_dphi;
             const int plo = (int)floorf(fminf(fmaxf((thf - half - p0f) * idpf, -4.0f), npf + 4.0f)) - 1;
             const int phi_i = (int)ceilf(fminf(fmaxf((thf + half - p0f) * idpf, -4.0f), npf + 4.0f)) + 1;
             if ((float)L.phi_last - thf <= 179.9f && thf - p0f <= 179.9f) {
-                ip_lo = max(plo, 0);
-                ip_hi = min(phi_i, L.n_phi - 1);
+                W.ip_lo = max(plo, 0);
+                W.ip_hi = min(phi_i, L.n_phi - 1);
             } else if (plo >= 0 && phi_i <= L.n_phi - 1) {
-                ip_lo = plo;
-                ip_hi = phi_i;
+                W.ip_lo = plo;
+                W.ip_hi = phi_i;
             }
         }
     }
+    return W;
+}
+
+// Stage 2, `co_box_search`: WAVE-COOPERATIVE, one pixel at a time, every argument wave-uniform (SGPRs).
+// Lanes = directions (<= 64 per chunk); a narrow chunk folds G = 64/W speed rows into one wave iteration.
+// Rows are taken four groups at a time with their loads issued first: the window is rounded up to a multiple
+// of 4*G rows (extra rows are real candidates, scoring them is harmless) and slid down if it would leave the
+// grid, so the main sweep has no per-candidate masking (slack rows after the LUT keep look-ahead loads legal).
+// Returns the flat index iw*n_phi+ip of the reference's argmin.
+__device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, double s, double a, double b, int w_lo,
+                                             int w_hi, int ip_lo, int ip_hi, double dsig, double inv_dsig, int lane,
+                                             unsigned &cand, bool &went_exact)
+{
+    const double inf = __builtin_inf();
+    const double ah = 0.5 * a, bh = 0.5 * b, m2 = ah * ah + bh * bh, sn = -s * inv_dsig;
+    const double wh0 = 0.5 * L.w0, whs = 0.5 / L.inv_wstep;
     const int nrows = w_hi - w_lo + 1, ncols = ip_hi - ip_lo + 1;
     if (nrows <= 0 || ncols <= 0) {  // cannot happen in exact arithmetic; stay safe
         went_exact = true;
         return exact_scan_co(L, i_inc, s, a, b, dsig, lane);
     }
     cand += (unsigned)(nrows * ncols);
-
-    // 3. screen the box: lanes = directions (<= 64 per chunk); a narrow chunk folds G = 64/W speed rows
-    //    into one wave iteration.  Rows are taken four groups at a time: the window is rounded up to a
-    //    multiple of 4*G rows (extra rows are real candidates, scoring them is harmless) and slid down
-    //    if it would leave the grid; only a window taller than the whole grid needs row masking.
     const double *__restrict__ slice = L.co + (size_t)i_inc * L.n_w * L.phi_pad;
     double best = inf, second = inf;
     int bidx = 0;  // (iw << 16) | ip
@@ -300,16 +319,15 @@ __device__ __forceinline__ int pruned_search_co(const DevTables &L, int i_inc, d
         const int col = lane & ((1 << sh) - 1), grp = lane >> sh;
         const bool act = col < width;
         const int ip = ip_lo + c0 + (act ? col : 0);
-        // inactive lanes: U = -inf makes every score +inf, no per-candidate masking
-        const double U = act ? 2.0 * (ah * L.cphi[ip] + bh * L.sphi[ip]) : -inf;
+        const double U = 2.0 * (ah * L.cphi[ip] + bh * L.sphi[ip]);
         const int step = 4 * G;
-        int rows_r = (nrows + step - 1) / step * step;
+        const int rows_r = (nrows + step - 1) / step * step;
         int w_base = w_lo;
         const bool mask_rows = rows_r > L.n_w;
         if (!mask_rows && w_base + rows_r > L.n_w) w_base = L.n_w - rows_r;
         const double dG = (double)G * whs;
-        double wh = fma((double)(w_base + grp), whs, wh0);
-        double pw = act ? wh * (wh - U) : inf, dp = act ? dG * (2.0 * wh - U) + dG * dG : 0.0;
+        const double wh = fma((double)(w_base + grp), whs, wh0);
+        double pw = act ? wh * (wh - U) : inf, dp = act ? dG * (2.0 * wh - U) + dG * dG : 0.0;  // inactive lanes: +inf
         const double ddp = 2.0 * dG * dG;
         const double *ptr = slice + (size_t)(w_base + grp) * L.phi_pad + ip;
         const size_t pstep = (size_t)G * L.phi_pad;
@@ -318,7 +336,7 @@ __device__ __forceinline__ int pruned_search_co(const DevTables &L, int i_inc, d
             for (int r0 = 0; r0 < rows_r; r0 += step) {
                 double v[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = ptr[k * pstep];  // allocation carries slack rows past the LUT end
+                for (int k = 0; k < 4; ++k) v[k] = ptr[k * pstep];
                 ptr += 4 * pstep;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -338,9 +356,9 @@ __device__ __forceinline__ int pruned_search_co(const DevTables &L, int i_inc, d
         if (code >= 0) bidx = ((w_base + code + grp) << 16) | ip;
     }
 
-    // 4. settle: a unique candidate within eps of the screening minimum IS the reference's argmin;
-    //    several (in different lanes) are re-scored in the reference's operation order; two in one lane
-    //    (or nothing finite) go to the exact full scan.
+    // settle: a unique candidate within eps of the screening minimum IS the reference's argmin; several (in
+    // different lanes) are re-scored in the reference's operation order; two in one lane (or nothing finite)
+    // go to the exact full scan.
     const double gmin = wave_min_d(best);
     const double T = gmin + 1e-9 * (1.0 + fabs(gmin) + m2);
     if (__ballot(second <= T) != 0ULL || !(gmin < inf)) {
@@ -511,12 +529,6 @@ template <> struct Cx<double> { typedef double2 type; };
 template <typename T> __device__ __forceinline__ double ld(const void *p, long long i) { return (double)((const T *)p)[i]; }
 
 // ------------------------------------------------------------------------------------------------
-// Per-lane pixel state shared by the kernels.
-struct Pixel {
-    double s_co, s_cr, dsig, a_re, a_im, b_eff;
-    double mag, theta;  // |(a_re, b_eff)| and its direction in degrees within [phi0, phi0 + 360)
-    int flags, i_inc, i_inc_cr, ipr;
-};
 
 // Loads pixel `il` (already clamped in range), converts to dB, classifies it (windspeed.py:198-209,
 // :252) and finds its incidence bins (:212, :254).
@@ -654,31 +666,37 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTa
     Pixel P;
     load_pixel<T>(L, A, i, in, P);
 
-    // ---- wave-cooperative searches, one pixel at a time, parameters wave-uniform
+    // ---- co-pol search.  Stage 1 (one pixel per lane): upper bound + search window.  Stage 2: the wave
+    //      walks its pixels one at a time, window and parameters wave-uniform (readlane -> SGPRs).
     int my_flat = -1, my_icr = -1;
     unsigned cand = 0, n_exact = 0, n_co = 0, n_cr = 0;
+    const bool use_prune = ALGO == 1 && L.prunable;
+    CoWindow W;
+    W.w_lo = W.w_hi = W.ip_lo = W.ip_hi = 0;
     unsigned long long todo = __ballot((P.flags & F_NEED_CO) != 0);
+    if (use_prune && todo) {
+        W = co_window_lanes(L, P, A.inv_dsig_co);
+        cand += (unsigned)__popcll(__ballot((P.flags & F_CO_FINITE) != 0)) * (unsigned)min(L.n_w, 256);
+    }
     while (todo) {
         const int p = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
         const int uf = rd_lane_i(P.flags, p);
-        if (uf & F_NEED_CO) {
-            const int u_iinc = rd_lane_i(P.i_inc, p);
-            const double us = rd_lane_d(P.s_co, p), ua = rd_lane_d(P.a_re, p), ub = rd_lane_d(P.b_eff, p);
-            int flat;
-            bool went_exact = false;
-            if (ALGO == 1 && L.prunable && (uf & F_CO_FINITE))
-                flat = pruned_search_co(L, u_iinc, us, ua, ub, rd_lane_d(P.mag, p), rd_lane_d(P.theta, p),
-                                        rd_lane_i(P.ipr, p), A.dsig_co, A.inv_dsig_co, lane, cand, went_exact);
-            else {
-                flat = exact_scan_co(L, u_iinc, us, ua, ub, A.dsig_co, lane);
-                went_exact = true;
-                cand += (unsigned)(L.n_w * L.n_phi);
-            }
-            n_exact += went_exact ? 1u : 0u;
-            n_co += 1u;
-            if (lane == p) my_flat = flat;
+        const int u_iinc = rd_lane_i(P.i_inc, p);
+        const double us = rd_lane_d(P.s_co, p), ua = rd_lane_d(P.a_re, p), ub = rd_lane_d(P.b_eff, p);
+        int flat;
+        bool went_exact = false;
+        if (use_prune && (uf & F_CO_FINITE))
+            flat = co_box_search(L, u_iinc, us, ua, ub, rd_lane_i(W.w_lo, p), rd_lane_i(W.w_hi, p), rd_lane_i(W.ip_lo, p),
+                                 rd_lane_i(W.ip_hi, p), A.dsig_co, A.inv_dsig_co, lane, cand, went_exact);
+        else {
+            flat = exact_scan_co(L, u_iinc, us, ua, ub, A.dsig_co, lane);
+            went_exact = true;
+            cand += (unsigned)(L.n_w * L.n_phi);
         }
+        n_exact += went_exact ? 1u : 0u;
+        n_co += 1u;
+        if (lane == p) my_flat = flat;
     }
 
     // ---- cross-pol search (windspeed.py:252-269): one pixel per lane, then the undecided ones cooperatively
