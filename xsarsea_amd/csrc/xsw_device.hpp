@@ -243,7 +243,7 @@ __device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pi
     double wh = fma((double)r_lo, whs, wh0);
     double pw = wh * (wh - ur), dp = whs * (2.0 * wh - ur) + whs * whs;  // p(w) = wh*(wh-U) by forward differences
     const double ddp = 2.0 * whs * whs;
-    double rbest = inf;
+    double rb[4] = {inf, inf, inf, inf};  // independent minima: no serial dependency between the four slots
     int k = 0;
     for (; k + 4 <= nray; k += 4) {
         double v[4];
@@ -252,11 +252,12 @@ __device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pi
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const double dd = fma(v[q], inv_dsig, sn);
-            rbest = vmin(rbest, fma(dd, dd, pw));
+            rb[q] = vmin(rb[q], fma(dd, dd, pw));
             pw += dp;
             dp += ddp;
         }
     }
+    double rbest = vmin(vmin(rb[0], rb[1]), vmin(rb[2], rb[3]));
     for (; k < nray; ++k) {
         const double dd = fma(ray[k], inv_dsig, sn);
         rbest = vmin(rbest, fma(dd, dd, pw));
@@ -444,8 +445,8 @@ __device__ __forceinline__ void search_cr_lanes(const DevTables &L, bool need, i
     const double sn = fast ? -s * inv : 0.0, invf = fast ? inv : 0.0;
     const double f = (fast && have_co) ? 1.0 : 0.0;   // Jwind_cr only when a co-pol wind exists (windspeed.py:259-264)
     const double g = (fast && have_co) ? -0.5 * aco : 0.0;
-    double best = inf, second = inf;
-    int code = 0;
+    double b4[4] = {inf, inf, inf, inf}, s4[4] = {inf, inf, inf, inf};
+    int c4[4] = {0, 0, 0, 0};
     int k = 0;
     for (; k + 4 <= L.n_wcr; k += 4) {
         double v[4];
@@ -456,11 +457,18 @@ __device__ __forceinline__ void search_cr_lanes(const DevTables &L, bool need, i
             const double dd = fma(v[q], invf, sn);
             const double t = fma(L.wcrh[k + q], f, g);   // (w - |co|)/2, wave-uniform table word
             const double J = fma(t, t, dd * dd);
-            second = vmin(second, vmax(J, best));
-            const bool lt = J < best;
-            best = lt ? J : best;
-            code = lt ? (k + q) : code;
+            s4[q] = vmin(s4[q], vmax(J, b4[q]));
+            const bool lt = J < b4[q];
+            b4[q] = lt ? J : b4[q];
+            c4[q] = lt ? (k + q) : c4[q];
         }
+    }
+    double best = inf, second = inf;
+    int code = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        second = vmin(vmin(second, s4[q]), vmax(best, b4[q]));
+        if (b4[q] < best) { best = b4[q]; code = c4[q]; }
     }
     for (; k < L.n_wcr; ++k) {
         const double dd = fma(row[k], invf, sn);
