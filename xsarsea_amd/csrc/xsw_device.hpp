@@ -322,7 +322,7 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
         const int ip = ip_lo + c0 + (act ? col : 0);
         const double U = 2.0 * (ah * L.cphi[ip] + bh * L.sphi[ip]);
         const int step = 4 * G;
-        const int rows_r = (nrows + step - 1) / step * step;
+        const int rows_r = (nrows + step - 1) & ~(step - 1);  // step = 256 >> sh is a power of two
         int w_base = w_lo;
         const bool mask_rows = rows_r > L.n_w;
         if (!mask_rows && w_base + rows_r > L.n_w) w_base = L.n_w - rows_r;
