@@ -1,6 +1,7 @@
 // libxsw host side: context, LUT upload, launch logic behind the C ABI of include/xsw.h.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -360,46 +361,84 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
         return dispatch_invert(c, A, a->dtype, a->out_dtype, algo);
     }
 
-    // host rasters: stage through device buffers (synchronous)
+    // Host rasters: device buffers for the whole raster, work cut into chunks of whole lines and software-
+    // pipelined so that the GPU inverts chunk k while the host side moves chunk k+1 in and chunk k-1 out
+    // (pageable hipMemcpyAsync blocks the host but not the device).  Two streams + one event per chunk.
     const size_t es = a->dtype == XSW_F32 ? 4 : 8, os = a->out_dtype == XSW_F32 ? 8 : 16;
     std::vector<void *> tmp;
-    auto stage_in = [&](const void *h, size_t bytes, const void **d) -> int {
-        *d = nullptr;
-        if (!h) return XSW_OK;
-        void *p = nullptr;
-        HIPCHK(c, hipMalloc(&p, bytes));
-        tmp.push_back(p);
-        HIPCHK(c, hipMemcpyAsync(p, h, bytes, hipMemcpyHostToDevice, c->stream));
-        *d = p;
-        return XSW_OK;
-    };
-    auto stage_out = [&](void *h, size_t bytes, void **d) -> int {
-        *d = nullptr;
-        if (!h) return XSW_OK;
-        HIPCHK(c, hipMalloc(d, bytes));
-        tmp.push_back(*d);
-        return XSW_OK;
-    };
     int rc = XSW_OK;
-    void *d_idx = nullptr;
-    if (!rc) rc = stage_in(a->inc, n * es, &A.inc);
-    if (!rc) rc = stage_in(a->sigma0_co, n * es, &A.s_co);
-    if (!rc) rc = stage_in(a->sigma0_cr, n * es, &A.s_cr);
-    if (!rc) rc = stage_in(a->dsig_cr, n * es, &A.dsig_cr);
-    if (!rc) rc = stage_in(a->anc, n * es * 2, &A.anc);
-    if (!rc) rc = stage_out(a->out_co, n * os, &A.out_co);
-    if (!rc) rc = stage_out(a->out_cr, n * os, &A.out_cr);
-    if (!rc) rc = stage_out(a->out_idx, n * 12, &d_idx);
-    A.out_idx = (int *)d_idx;
-    if (!rc) rc = dispatch_invert(c, A, a->dtype, a->out_dtype, algo);
-    if (!rc && a->out_co && hipMemcpyAsync(a->out_co, A.out_co, n * os, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
-        rc = fail(c, XSW_EHIP, "D2H out_co failed");
-    if (!rc && a->out_cr && hipMemcpyAsync(a->out_cr, A.out_cr, n * os, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
-        rc = fail(c, XSW_EHIP, "D2H out_cr failed");
-    if (!rc && a->out_idx && hipMemcpyAsync(a->out_idx, d_idx, n * 12, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
-        rc = fail(c, XSW_EHIP, "D2H out_idx failed");
+    auto dev_alloc = [&](bool want, size_t bytes, void **d) {
+        *d = nullptr;
+        if (rc || !want) return;
+        if (hipMalloc(d, bytes) != hipSuccess) { rc = fail(c, XSW_ENOMEM, "hipMalloc(%zu) failed", bytes); *d = nullptr; return; }
+        tmp.push_back(*d);
+    };
+    void *d_inc, *d_co, *d_cr, *d_dsig, *d_anc, *d_oco, *d_ocr, *d_idx;
+    dev_alloc(true, n * es, &d_inc);
+    dev_alloc(a->sigma0_co != nullptr, n * es, &d_co);
+    dev_alloc(a->sigma0_cr != nullptr, n * es, &d_cr);
+    dev_alloc(a->dsig_cr != nullptr, n * es, &d_dsig);
+    dev_alloc(a->anc != nullptr, n * es * 2, &d_anc);
+    dev_alloc(a->out_co != nullptr, n * os, &d_oco);
+    dev_alloc(a->out_cr != nullptr, n * os, &d_ocr);
+    dev_alloc(a->out_idx != nullptr, n * 12, &d_idx);
+
+    const long long target_px = 8LL << 20;  // ~8 Mpx per chunk
+    long long lines_per_chunk = a->samples > 0 ? (target_px + a->samples - 1) / a->samples : a->lines;
+    if (lines_per_chunk < 4) lines_per_chunk = 4;
+    lines_per_chunk = (lines_per_chunk + 3) & ~3LL;  // whole 4-line tile rows
+    const long long nchunks = (a->lines + lines_per_chunk - 1) / lines_per_chunk;
+    hipStream_t s_out = nullptr;
+    std::vector<hipEvent_t> done((size_t)nchunks, nullptr);
+    if (!rc && hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking) != hipSuccess) rc = fail(c, XSW_EHIP, "stream create failed");
+    auto h2d = [&](void *d, const void *h, size_t off, size_t bytes) {
+        if (!rc && h && hipMemcpyAsync((char *)d + off, (const char *)h + off, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+            rc = fail(c, XSW_EHIP, "H2D copy failed");
+    };
+    auto d2h = [&](void *h, const void *d, size_t off, size_t bytes) {
+        if (!rc && h && hipMemcpyAsync((char *)h + off, (const char *)d + off, bytes, hipMemcpyDeviceToHost, s_out) != hipSuccess)
+            rc = fail(c, XSW_EHIP, "D2H copy failed");
+    };
+    auto drain = [&](long long k) {  // outputs of chunk k -> host, once its kernel has finished
+        const long long l0 = k * lines_per_chunk, l1 = std::min((long long)a->lines, l0 + lines_per_chunk);
+        const size_t px0 = (size_t)l0 * a->samples, npx = (size_t)(l1 - l0) * a->samples;
+        if (!rc && hipStreamWaitEvent(s_out, done[(size_t)k], 0) != hipSuccess) rc = fail(c, XSW_EHIP, "stream wait failed");
+        d2h(a->out_co, d_oco, px0 * os, npx * os);
+        d2h(a->out_cr, d_ocr, px0 * os, npx * os);
+        d2h(a->out_idx, d_idx, px0 * 12, npx * 12);
+    };
+    for (long long k = 0; k < nchunks && !rc; ++k) {
+        const long long l0 = k * lines_per_chunk, l1 = std::min((long long)a->lines, l0 + lines_per_chunk);
+        const size_t px0 = (size_t)l0 * a->samples, npx = (size_t)(l1 - l0) * a->samples;
+        h2d(d_inc, a->inc, px0 * es, npx * es);
+        h2d(d_co, a->sigma0_co, px0 * es, npx * es);
+        h2d(d_cr, a->sigma0_cr, px0 * es, npx * es);
+        h2d(d_dsig, a->dsig_cr, px0 * es, npx * es);
+        h2d(d_anc, a->anc, px0 * es * 2, npx * es * 2);
+        KArgs B = A;
+        B.lines = l1 - l0;
+        B.n = (long long)npx;
+        B.inc = (const char *)d_inc + px0 * es;
+        B.s_co = d_co ? (const char *)d_co + px0 * es : nullptr;
+        B.s_cr = d_cr ? (const char *)d_cr + px0 * es : nullptr;
+        B.dsig_cr = d_dsig ? (const char *)d_dsig + px0 * es : nullptr;
+        B.anc = d_anc ? (const char *)d_anc + px0 * es * 2 : nullptr;
+        B.out_co = d_oco ? (char *)d_oco + px0 * os : nullptr;
+        B.out_cr = d_ocr ? (char *)d_ocr + px0 * os : nullptr;
+        B.out_idx = d_idx ? (int *)((char *)d_idx + px0 * 12) : nullptr;
+        if (!rc) rc = dispatch_invert(c, B, a->dtype, a->out_dtype, algo);
+        if (!rc && (hipEventCreateWithFlags(&done[(size_t)k], hipEventDisableTiming) != hipSuccess ||
+                    hipEventRecord(done[(size_t)k], c->stream) != hipSuccess))
+            rc = fail(c, XSW_EHIP, "event record failed");
+        if (k > 0) drain(k - 1);  // overlaps with the kernel of chunk k
+    }
+    if (!rc && nchunks > 0) drain(nchunks - 1);
     hipError_t se = hipStreamSynchronize(c->stream);
-    if (!rc && se != hipSuccess) rc = fail(c, XSW_EHIP, "kernel execution failed: %s", hipGetErrorString(se));
+    hipError_t so = s_out ? hipStreamSynchronize(s_out) : hipSuccess;
+    if (!rc && (se != hipSuccess || so != hipSuccess))
+        rc = fail(c, XSW_EHIP, "kernel execution failed: %s", hipGetErrorString(se != hipSuccess ? se : so));
+    for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e);
+    if (s_out) (void)hipStreamDestroy(s_out);
     for (void *p : tmp) (void)hipFree(p);
     return rc;
 }
