@@ -176,3 +176,11 @@ def test_utils_formulas():
     assert np.allclose(flat, 10 ** ((-0.1 * inc - 21) / 10), rtol=1e-9)
     with pytest.raises(IndexError):
         utils.nesz_flattening(noise[0], inc[0])
+
+
+def test_direction_helpers():
+    import xsarsea_amd as xa
+    assert xa.dir_meteo_to_oceano(10) == 190 and xa.dir_oceano_to_meteo(190) == 10
+    assert xa.dir_to_180(270) == -90 and xa.dir_to_360(-90) == 270
+    assert np.isclose(xa.dir_meteo_to_sample(90.0, 0.0), 0.0)
+    assert xa.dir_sample_to_meteo(0.0, 10.0) == 100.0

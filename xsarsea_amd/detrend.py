@@ -64,3 +64,45 @@ def sigma0_detrend(sigma0, inc_angle, wind_speed_gmf=np.array([10.0]), wind_dir_
         res.attrs["comment"] = f"detrended with model {model.name}"
         return res
     return out
+
+
+# ---- direction-convention helpers used by callers around the hot path (reference: detrend.py:96-201).
+# One-line elementwise formulas; they turn the complex antenna-convention output into met/ocean directions.
+def dir_meteo_to_sample(meteo_dir, ground_heading):
+    """Meteorological direction (deg from north, clockwise) -> angle relative to the sample axis (rad, anticlockwise)."""
+    return np.pi / 2 - np.deg2rad(meteo_dir - ground_heading)
+
+
+def dir_sample_to_meteo(sample_dir, ground_heading):
+    """Angle relative to the sample axis (deg, anticlockwise) -> meteorological direction (deg from north)."""
+    return 90 - sample_dir + ground_heading
+
+
+def dir_meteo_to_oceano(meteo_dir):
+    """'from' convention -> 'to' convention (deg)."""
+    return (meteo_dir + 180) % 360
+
+
+def dir_oceano_to_meteo(oceano_dir):
+    """'to' convention -> 'from' convention (deg)."""
+    return (oceano_dir - 180) % 360
+
+
+def dir_to_180(angle):
+    """Wrap degrees into [-180, 180)."""
+    return (angle + 180) % 360 - 180
+
+
+def dir_to_360(angle):
+    """Wrap degrees into [0, 360)."""
+    return (angle + 360) % 360
+
+
+def read_sarwing_owi(owi_file):
+    """Open a sarwing OWI netCDF product in the xsar-like layout the notebooks use (needs xarray)."""
+    from .windspeed.lut import xr as _xr
+    if _xr is None:
+        raise ImportError("read_sarwing_owi needs xarray")
+    ds = _xr.merge([_xr.open_dataset(owi_file), _xr.open_dataset(owi_file, group="owiInversionTables_UV")])
+    ds = ds.rename_dims({"owiAzSize": "line", "owiRaSize": "sample"}).drop_vars(["owiCalConstObsi", "owiCalConstInci"])
+    return ds.assign_coords({"line": np.arange(len(ds.line)), "sample": np.arange(len(ds.sample))})
