@@ -228,3 +228,73 @@ def test_detrend_kernel(gpu_ctx):
         out = gpu_ctx.detrend_host(s, ratio)
         ref = s / ratio[None, :]
         assert out.dtype == np.float64 and np.array_equal(out, ref.astype(np.float64))
+
+
+def _axis_case_lut(rng, phi_axis, w_axis=None, inc_axis=None):
+    from oracle import gmf, lut as olut
+    inc_axis = np.linspace(20, 44, 7) if inc_axis is None else inc_axis
+    w_axis = np.linspace(0.5, 39.5, 79) if w_axis is None else w_axis
+    co = 10 * np.log10(gmf.gmf_cmod5n(inc_axis[:, None, None], w_axis[None, :, None], phi_axis[None, None, :]) + 1e-15)
+    co = co + 0.05 * rng.standard_normal(co.shape)
+    return olut.Lut(co, inc_axis, w_axis, phi_axis, "dB", "x", "co", "VV")
+
+
+@pytest.mark.parametrize("case", ["phi0_170", "phi0_90", "phi0_360", "nonuniform_w", "nan_in_lut", "inf_in_lut", "tiny"])
+def test_axis_and_lut_edge_cases(gpu_ctx, case):
+    """Direction axes that are not [0,180] (phi_180 False: no +-phi choice, window clamping / seam logic),
+    non-uniform axes and non-finite LUT entries (exact path, numpy's first-NaN rule), a 2x2x2 LUT."""
+    rng = np.random.default_rng(abs(hash(case)) % 1000)
+    if case == "phi0_170":
+        lco = _axis_case_lut(rng, np.linspace(0, 170, 86))
+    elif case == "phi0_90":
+        lco = _axis_case_lut(rng, np.linspace(0, 90, 91))
+    elif case == "phi0_360":
+        lco = _axis_case_lut(rng, np.linspace(0, 360, 181))
+    elif case == "nonuniform_w":
+        w = np.cumsum(rng.uniform(0.2, 0.8, 60)) + 0.3
+        lco = _axis_case_lut(rng, np.linspace(0, 180, 61), w_axis=w)
+    elif case == "tiny":
+        lco = _axis_case_lut(rng, np.array([0.0, 180.0]), w_axis=np.array([2.0, 20.0]), inc_axis=np.array([20.0, 40.0]))
+    else:
+        lco = _axis_case_lut(rng, np.linspace(0, 180, 61))
+        lco.values[2, 10, 7] = np.nan if case == "nan_in_lut" else np.inf
+        lco.values[4, 30:33, 20] = np.nan if case == "nan_in_lut" else -np.inf
+    co, _ = lut_dicts(lco, None)
+    gpu_ctx.upload_luts(co=co)
+    n = 3000
+    inc = rng.uniform(18, 46, n)
+    wt, pt = rng.uniform(0.5, 35, n), rng.uniform(-180, 180, n)
+    from oracle import gmf
+    s = gmf.gmf_cmod5n(inc, wt, pt) * rng.gamma(100, 1 / 100, n)
+    anc = wt * np.exp(1j * np.deg2rad(pt)) + rng.normal(0, 1.5, n) + 1j * rng.normal(0, 1.5, n)
+    anc[:300] = rng.uniform(0, 40, 300) * np.exp(1j * rng.uniform(-np.pi, np.pi, 300))
+    inc, s, anc = inc.reshape(30, 100), s.reshape(30, 100), anc.reshape(30, 100)
+    o = oracle_full(inc, s, None, None, anc, lco, None)
+    for algo in ALGOS_ALL:
+        got = gpu_ctx.invert_host(inc, sigma0_co=s, anc=anc, algo=algo, want_idx=True)
+        assert np.array_equal(got[2][..., :2], o[2][..., :2]), (case, algo)
+        assert_complex_close(got[0], o[0], what=f"{case} {algo}")
+
+
+def test_cmod7_shaped_lut(gpu_ctx, tmp_path):
+    """BASELINE config 5: a CMOD7-format table (250 x 73 x 51 float32, Fortran order, linear units) read by the
+    product, interpolated to the high-resolution grid and inverted; oracle gets the same high-resolution LUT."""
+    import warnings
+    from oracle import gmf, lut as olut
+    from xsarsea_amd import windspeed
+    from xsarsea_amd.windspeed import cmod7
+    rng = np.random.default_rng(7)
+    w, p, i = np.arange(1, 251) * 0.2, np.arange(73) * 2.5, np.arange(16, 67) * 1.0
+    table = gmf.gmf_cmod5n(i[None, None, :], w[:, None, None], p[None, :, None])
+    table = (table * (1 + 0.05 * np.sin(w[:, None, None] / 7.0) * np.cos(np.radians(p[None, :, None])))).astype(np.float32)
+    cmod7.write_cmod7_table(tmp_path / "gmf_cmod7_vv.dat_little_endian", table)
+    m = cmod7.register_cmod7(str(tmp_path))
+    lut = m._lut(units="dB")
+    assert lut.shape == (501, 499, 181)
+    lco = olut.Lut(lut.values, lut.incidence, lut.wspd, lut.phi, "dB", "high", "gmf_cmod7", "VV")
+    inc, s_vv, _, _, anc = synthetic_scene(40, 130, np.float64, 55)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = windspeed.invert_from_model(inc, s_vv, ancillary_wind=anc, model="gmf_cmod7")
+    o = oracle_full(inc, s_vv, None, None, anc, lco, None)
+    assert_complex_close(got, o[0], what="cmod7")

@@ -184,3 +184,17 @@ def test_direction_helpers():
     assert xa.dir_to_180(270) == -90 and xa.dir_to_360(-90) == 270
     assert np.isclose(xa.dir_meteo_to_sample(90.0, 0.0), 0.0)
     assert xa.dir_sample_to_meteo(0.0, 10.0) == 100.0
+
+
+def test_lut_kwargs_do_not_leak_between_calls():
+    """A call with step overrides must not change what a later default call builds (the reference mutates the
+    model's steps in _raw_lut, gmfs.py:370-379; the build carries the generated steps with the LUT instead)."""
+    m = windspeed.get_model("gmf_cmod5")
+    before = (m.inc_step_lr, m.wspd_step_lr, m.phi_step_lr)
+    a = m._lut(units="linear", resolution="low")
+    b = m._lut(units="linear", resolution="low", inc_step_lr=2.0)
+    assert b.shape[0] == 26 and a.shape[0] == 51
+    assert (m.inc_step_lr, m.wspd_step_lr, m.phi_step_lr) == before
+    m._lut_cache.clear()
+    c = m._lut(units="linear", resolution="low")
+    assert np.array_equal(a.values, c.values)

@@ -144,10 +144,11 @@ class GmfModel(Model):
         if resolution is None:
             resolution = "low" if self.iscopol else "high"
         sfx = "_lr" if resolution == "low" else ""
-        steps = []
-        for n in ("inc", "wspd", "phi"):
-            st = kwargs.get(f"{n}_step{sfx}", getattr(self, f"{n}_step{sfx}"))
-            setattr(self, f"{n}_step{sfx}", st)  # the reference records the steps it generated with
-            steps.append(st)
-        inc, wspd, phi = (axis_grid(r, st) for r, st in zip((self.inc_range, self.wspd_range, self.phi_range), steps))
-        return Lut(self._grid(inc, wspd, phi), inc, wspd, phi, units=self.units, resolution=resolution)
+        # The reference overwrites self.<axis>_step<sfx> with the steps it generated with (gmfs.py:370-379) so
+        # that _normalize_lut sees "already at the requested steps"; that also leaks one call's kwargs into
+        # every later call.  Here the generated steps travel with the LUT instead (same decision, no leak).
+        steps = {n: kwargs.get(f"{n}_step{sfx}", getattr(self, f"{n}_step{sfx}")) for n in ("inc", "wspd", "phi")}
+        inc, wspd, phi = (axis_grid(r, steps[n]) for r, n in
+                          zip((self.inc_range, self.wspd_range, self.phi_range), ("inc", "wspd", "phi")))
+        return Lut(self._grid(inc, wspd, phi), inc, wspd, phi, units=self.units, resolution=resolution,
+                   generated_steps=steps)

@@ -101,15 +101,16 @@ class Model:
         if resolution == have:
             sfx = "" if resolution == "high" else "_lr"
             names = ["inc", "wspd"] + (["phi"] if self.iscopol else [])
-            do_interp = any(getattr(self, f"{n}_step{sfx}") != kwargs.get(f"{n}_step{sfx}", getattr(self, f"{n}_step{sfx}"))
-                            for n in names)
+            own = lut.attrs.get("generated_steps") or {n: getattr(self, f"{n}_step{sfx}") for n in names}
+            do_interp = any(own[n] != kwargs.get(f"{n}_step{sfx}", own[n]) for n in names)
         if resolution == have and not do_interp:
             return lut
         inc, wspd, phi = self._target_axes(resolution, kwargs)
         if lut.phi is None or phi is None:
             phi = lut.phi
         vals = _interp(lut, inc, wspd, phi)
-        return Lut(vals, inc, wspd, phi, **{**lut.attrs, "resolution": resolution})
+        attrs = {k: v for k, v in lut.attrs.items() if k != "generated_steps"}
+        return Lut(vals, inc, wspd, phi, **{**attrs, "resolution": resolution})
 
     def _lut(self, units="linear", **kwargs):
         """`to_lut` on the internal container, memoised."""
