@@ -175,7 +175,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--lines", type=int, default=20000)
     ap.add_argument("--samples", type=int, default=20000)
-    ap.add_argument("--algo", default="pruned", choices=["pruned", "exhaustive", "exact"])
+    ap.add_argument("--algo", default="pruned", choices=["pruned", "exhaustive", "exhaustive_f64", "exact"])
     ap.add_argument("--mode", default="mono", choices=["mono", "dual"],
                     help="mono: CMOD5.N VV (the metric's workload); dual: + Sentinel-1 VH GMF cross-pol refinement (config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -321,7 +321,7 @@ def main():
                        "parallelism": f"row tiles x{n_gpus}" + (", RCCL gather to rank 0 in the step" if n_gpus > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel": "k_invert" if args.algo != "exhaustive" else "k_invert_exhaustive",
+                         "kernel": {"exhaustive": "k_invert_exhaustive32", "exhaustive_f64": "k_invert_exhaustive"}.get(args.algo, "k_invert"),
                          "kernel_ms": round(kernel_ms, 3), "bytes_per_pixel": bytes_px,
                          "note": "algorithmic raster bytes (16 B read + 8 B written per pixel) / mean kernel time "
                                  "(HIP events on the launch stream); the search itself is VALU/L1-bound, see valu"},

@@ -32,8 +32,10 @@ enum { XSW_MEM_HOST = 0, XSW_MEM_DEVICE = 1 };
 enum {
     XSW_ALGO_AUTO = 0,       /* pruned when the LUT axes are uniform and finite, else exact        */
     XSW_ALGO_PRUNED = 1,     /* exact branch-and-bound search (production kernel)                   */
-    XSW_ALGO_EXHAUSTIVE = 2, /* full (wspd x phi) sweep, LUT slice tiled through LDS                */
-    XSW_ALGO_EXACT = 3       /* full sweep in the reference's operation order (slow, any LUT)       */
+    XSW_ALGO_EXHAUSTIVE = 2, /* full (wspd x phi) sweep, LUT slice tiled through LDS; float32 screening,
+                                float64 settle (results identical to the reference's)                */
+    XSW_ALGO_EXACT = 3,      /* full sweep in the reference's operation order (slow, any LUT)       */
+    XSW_ALGO_EXHAUSTIVE_F64 = 4 /* the LDS-tiled sweep with float64 screening                       */
 };
 enum {
     XSW_OK = 0,
@@ -99,7 +101,8 @@ typedef struct {
     uint64_t pixels_co;        /* pixels that ran a co-pol search                   */
     uint64_t cand_co;          /* co-pol candidates actually scored                 */
     uint64_t pixels_exact;     /* pixels that took the exact full-scan path         */
-    uint64_t pixels_cr;        /* pixels that ran a cross-pol search                */
+    uint64_t pixels_cr;        /* pixels that ran a cross-pol search (XSW_ALGO_EXHAUSTIVE: pixels the float32
+                                  sweep could not decide, finished by the float64 box search) */
 } xsw_stats;
 
 int xsw_version(void);

@@ -41,7 +41,7 @@ def run_gpu(ctx, d, mode, algo, is_db=False, out_dtype=np.complex128):
 
 
 @pytest.mark.parametrize("tag", ["phi180_f64", "phi360_f64", "phi180_f32"])
-@pytest.mark.parametrize("algo", ALGOS_ALL + ["exhaustive"])
+@pytest.mark.parametrize("algo", ALGOS_ALL + ["exhaustive", "exhaustive_f64"])
 def test_small_goldens(gpu_ctx, tag, algo):
     """Self-contained goldens (LUT stored in the fixture) produced by the reference's kernel body."""
     d = golden(f"kernel_small_{tag}.npz")
@@ -53,7 +53,7 @@ def test_small_goldens(gpu_ctx, tag, algo):
     assert_complex_close(got[0], d["mono_co"], what=f"{tag} mono_co {algo}")
     o = oracle_full(d["inc"], d["sigma0_vv"], d["sigma0_vh"], d["dsig_cr"], d["anc"], lco, lcr, fast_c=False)
     assert np.array_equal(got[2][..., :2], o[2][..., :2]), "co-pol grid indices differ from the oracle"
-    if algo == "exhaustive":
+    if algo.startswith("exhaustive"):
         return  # mono co-pol only
     got = run_gpu(gpu_ctx, d, "dual", algo, is_db)
     assert_complex_close(got[0], d["dual_co"], what=f"{tag} dual_co {algo}")
@@ -64,7 +64,7 @@ def test_small_goldens(gpu_ctx, tag, algo):
 
 
 @pytest.mark.parametrize("tag", ["f64", "f32"])
-@pytest.mark.parametrize("algo", ALGOS_ALL + ["exhaustive"])
+@pytest.mark.parametrize("algo", ALGOS_ALL + ["exhaustive", "exhaustive_f64"])
 def test_default_goldens(gpu_ctx, default_luts, tag, algo):
     """Default-resolution LUT (501 x 499 x 181 / 501 x 771), 48 x 48 pixels incl. the edge cases."""
     d = golden(f"kernel_default_{tag}.npz")
@@ -74,7 +74,7 @@ def test_default_goldens(gpu_ctx, default_luts, tag, algo):
     is_db = tag == "f32"
     got = run_gpu(gpu_ctx, d, "mono_co", algo, is_db)
     assert_complex_close(got[0], d["mono_co"], what=f"default {tag} mono_co {algo}")
-    if algo == "exhaustive":
+    if algo.startswith("exhaustive"):
         return
     got = run_gpu(gpu_ctx, d, "dual", algo, is_db)
     o = oracle_full(d["inc"], d["sigma0_vv"], d["sigma0_vh"], d["dsig_cr"], d["anc"], lco, lcr)
@@ -134,9 +134,9 @@ def test_scene_vs_oracle(gpu_ctx, default_luts, dtype):
         assert np.array_equal(got[2], o[2]), f"{algo}: grid indices differ"
         assert_complex_close(got[0], o[0], what=f"scene co {algo}")
         assert_complex_close(got[1], o[1], rtol=1e-9, what=f"scene cr {algo}")
-    got = gpu_ctx.invert_host(inc, sigma0_co=oinv.to_db(s_vv), anc=anc, sigma0_is_db=True, algo="exhaustive",
-                              want_idx=True)
-    assert np.array_equal(got[2][..., :2], o[2][..., :2]), "exhaustive: grid indices differ"
+    for algo in ("exhaustive", "exhaustive_f64"):
+        got = gpu_ctx.invert_host(inc, sigma0_co=oinv.to_db(s_vv), anc=anc, sigma0_is_db=True, algo=algo, want_idx=True)
+        assert np.array_equal(got[2][..., :2], o[2][..., :2]), f"{algo}: grid indices differ"
     # device-side dB conversion
     got = gpu_ctx.invert_host(inc, sigma0_co=s_vv, sigma0_cr=s_vh, dsig_cr=dsig, anc=anc, algo="pruned", want_idx=True)
     mism = np.mean(np.any(got[2] != o[2], axis=-1))
@@ -202,7 +202,7 @@ def test_ragged_and_empty(gpu_ctx, default_luts, shape):
     inc = rng.uniform(20, 60, shape)
     s = 10 ** rng.uniform(-2.5, -0.5, shape)
     anc = rng.uniform(-15, 15, shape) + 1j * rng.uniform(-15, 15, shape)
-    for algo in ALGOS_ALL + ["exhaustive"]:
+    for algo in ALGOS_ALL + ["exhaustive", "exhaustive_f64"]:
         got = gpu_ctx.invert_host(inc, sigma0_co=s, anc=anc, algo=algo, want_idx=True)
         assert got[0].shape == shape
         if n:

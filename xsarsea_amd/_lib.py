@@ -9,8 +9,9 @@ from . import _build
 
 XSW_F32, XSW_F64 = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
-ALGO_AUTO, ALGO_PRUNED, ALGO_EXHAUSTIVE, ALGO_EXACT = 0, 1, 2, 3
-ALGOS = {"auto": ALGO_AUTO, "pruned": ALGO_PRUNED, "exhaustive": ALGO_EXHAUSTIVE, "exact": ALGO_EXACT}
+ALGO_AUTO, ALGO_PRUNED, ALGO_EXHAUSTIVE, ALGO_EXACT, ALGO_EXHAUSTIVE_F64 = 0, 1, 2, 3, 4
+ALGOS = {"auto": ALGO_AUTO, "pruned": ALGO_PRUNED, "exhaustive": ALGO_EXHAUSTIVE, "exact": ALGO_EXACT,
+         "exhaustive_f64": ALGO_EXHAUSTIVE_F64}
 
 EXPORTS = (
     "xsw_version", "xsw_device_count", "xsw_ctx_create", "xsw_ctx_destroy", "xsw_last_error", "xsw_set_stream", "xsw_use_own_stream",
@@ -51,6 +52,29 @@ def library_path():
     return _build.LIB
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 (same soname as the system
+    one); if libxsw.so pulled in the system runtime first, a later `import torch` would find "no ROCm-capable
+    device".  So when torch is installed but not imported yet, its bundled runtime is loaded first (libxsw.so then
+    binds to it); when torch is already imported, or absent, nothing needs doing."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load libxsw.so (raises if it has not been built: run `python -m xsarsea_amd._build`)."""
     global _cdll
@@ -58,6 +82,7 @@ def load():
         if not os.path.exists(_build.LIB):
             raise XswError(f"{_build.LIB} is missing: build it with `python -m xsarsea_amd._build` "
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        _preload_hip_runtime()
         lib = ctypes.CDLL(_build.LIB)
         lib.xsw_last_error.restype = ctypes.c_char_p
         lib.xsw_last_error.argtypes = [ctypes.c_void_p]

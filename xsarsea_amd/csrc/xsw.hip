@@ -194,6 +194,17 @@ static int upload_co(xsw_ctx *c, const xsw_lut *l)
     for (size_t r = 0; r < (size_t)nI * nW; ++r) memcpy(&pad[r * ppad], l->db + r * nP, nP * sizeof(double));
     int rc;
     if ((rc = upload(c, c->co_allocs, pad.data(), pad.size(), &T.co))) return rc;
+    {
+        std::vector<float> pad32(pad.size());
+        double amax = 0.0;
+        for (size_t k = 0; k < pad.size(); ++k) {
+            pad32[k] = (float)pad[k];
+            const double v = std::fabs(pad[k]);
+            if (v > amax && std::isfinite(v)) amax = v;
+        }
+        T.co_absmax = amax;
+        if ((rc = upload(c, c->co_allocs, pad32.data(), pad32.size(), &T.co32))) return rc;
+    }
     std::vector<double>().swap(pad);
     std::vector<double> wh(nW), cp(nP), sp(nP);
     for (int i = 0; i < nW; ++i) wh[i] = 0.5 * l->wspd[i];
@@ -207,6 +218,11 @@ static int upload_co(xsw_ctx *c, const xsw_lut *l)
     if ((rc = upload(c, c->co_allocs, l->inc, nI, &T.inc))) return rc;
     if ((rc = upload(c, c->co_allocs, l->wspd, nW, &T.w))) return rc;
     if ((rc = upload(c, c->co_allocs, wh.data(), nW, &T.wh))) return rc;
+    {
+        std::vector<float> wh32(nW);
+        for (int i = 0; i < nW; ++i) wh32[i] = (float)wh[i];
+        if ((rc = upload(c, c->co_allocs, wh32.data(), (size_t)nW, &T.wh32))) return rc;
+    }
     if ((rc = upload(c, c->co_allocs, l->phi, nP, &T.phi))) return rc;
     if ((rc = upload(c, c->co_allocs, cp.data(), nP, &T.cphi))) return rc;
     if ((rc = upload(c, c->co_allocs, sp.data(), nP, &T.sphi))) return rc;
@@ -301,7 +317,8 @@ static int launch_invert(xsw_ctx *c, const KArgs &A, int algo)
     const long long strips_per_line = (A.samples + 63) / 64, line_groups = (A.lines + 3) / 4;
     const long long nblocks = 8 * ((strips_per_line + 7) / 8) * line_groups;
     if (nblocks > 0x7fffffffLL) return fail(c, XSW_EINVAL, "raster too large for one launch");
-    if (algo == XSW_ALGO_EXHAUSTIVE) return launch_exhaustive<T, TO>(c->T, A, c->stream) == hipSuccess
+    if (algo == XSW_ALGO_EXHAUSTIVE || algo == XSW_ALGO_EXHAUSTIVE_F64)
+        return launch_exhaustive<T, TO>(c->T, A, c->stream, algo == XSW_ALGO_EXHAUSTIVE) == hipSuccess
                                                 ? XSW_OK : fail(c, XSW_EHIP, "exhaustive launch failed: %s", hipGetErrorString(hipGetLastError()));
     if (algo == XSW_ALGO_PRUNED)
         hipLaunchKernelGGL((k_invert<T, TO, 1>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, A);
@@ -331,13 +348,13 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
     if (a->sigma0_co && !c->have_co) return fail(c, XSW_ENOLUT, "sigma0_co given but no co-pol LUT uploaded");
     if (a->sigma0_cr && !c->have_cr) return fail(c, XSW_ENOLUT, "sigma0_cr given but no cross-pol LUT uploaded");
     if (a->sigma0_co && !a->out_co) return fail(c, XSW_EINVAL, "out_co is NULL");
-    if (a->algo < XSW_ALGO_AUTO || a->algo > XSW_ALGO_EXACT) return fail(c, XSW_EINVAL, "unknown algo %d", a->algo);
+    if (a->algo < XSW_ALGO_AUTO || a->algo > XSW_ALGO_EXHAUSTIVE_F64) return fail(c, XSW_EINVAL, "unknown algo %d", a->algo);
     const long long n = (long long)a->lines * a->samples;
     if (n == 0) return XSW_OK;
     HIPCHK(c, hipSetDevice(c->device));
 
     int algo = a->algo == XSW_ALGO_AUTO ? XSW_ALGO_PRUNED : a->algo;
-    if (algo == XSW_ALGO_EXHAUSTIVE && !(a->sigma0_co && c->T.prunable && !a->sigma0_cr))
+    if ((algo == XSW_ALGO_EXHAUSTIVE || algo == XSW_ALGO_EXHAUSTIVE_F64) && !(a->sigma0_co && c->T.prunable && !a->sigma0_cr))
         return fail(c, XSW_EINVAL, "XSW_ALGO_EXHAUSTIVE handles mono co-pol on a uniform finite LUT only");
 
     KArgs A{};

@@ -26,6 +26,9 @@ struct DevTables {
     const double *co;    // [n_inc][n_w][phi_pad]   incidence-major slices (722 KB each at default size)
     const double *coT;   // [n_inc][n_phi][w_pad]   same slices transposed: one direction, all speeds
     const double *inc, *w, *wh, *phi, *cphi, *sphi;  // axes; wh = w/2; cphi/sphi = cos/sin(radians(phi))
+    const float *co32;       // [n_inc][n_w][phi_pad] float copy of `co` (screening of the exhaustive kernel)
+    const float *wh32;       // [n_w] float(w/2)
+    double co_absmax;        // max |co|: bounds the float32 screening error
     const double *out_dir;   // [2][n_phi][2]       exp(1j*deg2rad(+-phi))
     const double *abs_co;    // [n_w][n_phi]        |w*exp(1j*deg2rad(phi))|
     const double *dual_dir;  // [2][n_w][n_phi][2]  exp(1j*angle(sol / sol_2))
@@ -94,6 +97,34 @@ __device__ __forceinline__ double wave_min_d(double v)
     v = vmin(v, dpp_d<0x142, 0xA>(v));  // lane 15 of rows 0,2 -> rows 1,3
     v = vmin(v, dpp_d<0x143, 0xC>(v));  // lane 31 -> rows 2,3
     return rd_lane_d(v, 63);
+}
+__device__ __forceinline__ float vminf(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmaxf(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    const int x = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(x, x, CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_min_f(float v)
+{
+    v = vminf(v, dpp_f<0xB1, 0xF>(v));
+    v = vminf(v, dpp_f<0x4E, 0xF>(v));
+    v = vminf(v, dpp_f<0x141, 0xF>(v));
+    v = vminf(v, dpp_f<0x140, 0xF>(v));
+    v = vminf(v, dpp_f<0x142, 0xA>(v));
+    v = vminf(v, dpp_f<0x143, 0xC>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 // lexicographic (J, idx) minimum over the wave; J never NaN here
 __device__ __forceinline__ void wave_argmin(double &J, int &idx)
@@ -227,6 +258,37 @@ struct Pixel {
 struct CoWindow {
     int w_lo, w_hi, ip_lo, ip_hi;
 };
+// Polar bounding box (index space) of the disc |c - m| <= 2 sqrt(jub) around the ancillary wind m = mag*e^{i theta}:
+// every candidate whose wind term alone is <= jub lies inside.  float32 is ample: every rounding is covered by
+// the 1e-3 inflation of R plus one grid step of slack on every side; huge ancillary winds, where float32 could
+// not resolve a grid step, take the whole axis.
+__device__ __forceinline__ CoWindow box_from_jub(const DevTables &L, double mag, double theta, double jub)
+{
+    CoWindow W;
+    W.w_lo = 0; W.w_hi = L.n_w - 1; W.ip_lo = 0; W.ip_hi = L.n_phi - 1;
+    const float Rf = 2.0f * sqrtf((float)jub) * 1.001f + 1e-3f;
+    const float magf = (float)mag, thf = (float)theta;
+    const float nwf = (float)L.n_w, w0f = (float)L.w0, iwsf = (float)L.inv_wstep;
+    if (magf < 1e4f && Rf < 1e4f) {
+        W.w_lo = max((int)floorf(fminf(fmaxf((magf - Rf - w0f) * iwsf, -4.0f), nwf + 4.0f)) - 1, 0);
+        W.w_hi = min((int)ceilf(fminf(fmaxf((magf + Rf - w0f) * iwsf, -4.0f), nwf + 4.0f)) + 1, L.n_w - 1);
+        if (Rf < magf * 0.9999f) {
+            const float half = asinf(Rf / magf) * 57.29578f + 0.01f;
+            const float npf = (float)L.n_phi, p0f = (float)L.phi0, idpf = (float)L.inv_dphi;
+            const int plo = (int)floorf(fminf(fmaxf((thf - half - p0f) * idpf, -4.0f), npf + 4.0f)) - 1;
+            const int phi_i = (int)ceilf(fminf(fmaxf((thf + half - p0f) * idpf, -4.0f), npf + 4.0f)) + 1;
+            if ((float)L.phi_last - thf <= 179.9f && thf - p0f <= 179.9f) {
+                W.ip_lo = max(plo, 0);
+                W.ip_hi = min(phi_i, L.n_phi - 1);
+            } else if (plo >= 0 && phi_i <= L.n_phi - 1) {
+                W.ip_lo = plo;
+                W.ip_hi = phi_i;
+            }
+        }
+    }
+    return W;
+}
+
 __device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pixel &P, double inv_dsig)
 {
     const double inf = __builtin_inf();
@@ -266,29 +328,7 @@ __device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pi
     }
     const double jub = (rbest + m2) * (1.0 + 1e-9) + 1e-9;
 
-    CoWindow W;
-    W.w_lo = 0; W.w_hi = L.n_w - 1; W.ip_lo = 0; W.ip_hi = L.n_phi - 1;
-    const float Rf = 2.0f * sqrtf((float)jub) * 1.001f + 1e-3f;
-    const float magf = (float)mag, thf = (float)theta;
-    const float nwf = (float)L.n_w, w0f = (float)L.w0, iwsf = (float)L.inv_wstep;
-    if (magf < 1e4f && Rf < 1e4f) {
-        W.w_lo = max((int)floorf(fminf(fmaxf((magf - Rf - w0f) * iwsf, -4.0f), nwf + 4.0f)) - 1, 0);
-        W.w_hi = min((int)ceilf(fminf(fmaxf((magf + Rf - w0f) * iwsf, -4.0f), nwf + 4.0f)) + 1, L.n_w - 1);
-        if (Rf < magf * 0.9999f) {
-            const float half = asinf(Rf / magf) * 57.29578f + 0.01f;
-            const float npf = (float)L.n_phi, p0f = (float)L.phi0, idpf = (float)L.inv_dphi;
-            const int plo = (int)floorf(fminf(fmaxf((thf - half - p0f) * idpf, -4.0f), npf + 4.0f)) - 1;
-            const int phi_i = (int)ceilf(fminf(fmaxf((thf + half - p0f) * idpf, -4.0f), npf + 4.0f)) + 1;
-            if ((float)L.phi_last - thf <= 179.9f && thf - p0f <= 179.9f) {
-                W.ip_lo = max(plo, 0);
-                W.ip_hi = min(phi_i, L.n_phi - 1);
-            } else if (plo >= 0 && phi_i <= L.n_phi - 1) {
-                W.ip_lo = plo;
-                W.ip_hi = phi_i;
-            }
-        }
-    }
-    return W;
+    return box_from_jub(L, mag, theta, jub);
 }
 
 // Stage 2, `co_box_search`: WAVE-COOPERATIVE, one pixel at a time, every argument wave-uniform (SGPRs).

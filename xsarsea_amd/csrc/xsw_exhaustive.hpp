@@ -174,32 +174,229 @@ __global__ __launch_bounds__(256) void k_invert_exhaustive(DevTables L, KArgs A,
         if (lane == p) my_flat = flat;
         n_exact++;
     }
+    const unsigned long long n_need = (unsigned long long)__popcll(__ballot((P.flags & F_NEED_CO) != 0));
     if (A.stats && lane == 0) {
-        atomicAdd(&A.stats[0], (unsigned long long)__popcll(__ballot((P.flags & F_NEED_CO) != 0)));
+        atomicAdd(&A.stats[0], n_need);
         atomicAdd(&A.stats[1], cand);
         atomicAdd(&A.stats[2], (unsigned long long)n_exact);
     }
     if (in) store_pixel<TO>(L, A, i, P, my_flat, -1);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Same sweep with FLOAT32 screening (XSW_ALGO_EXHAUSTIVE): the LUT chunk in LDS, the score and the per-lane
+// (best, second, code) are float32 -- twice the VALU rate, half the LDS bytes, 3 registers of state per pixel
+// (16 pixels per batch).  The decision stays exact:
+//   J32 differs from the real score by at most eps32 (bound below: float32 rounding of LUT, s/dsig, U, w/2 and
+//   of the three arithmetic steps); a pixel whose float32 minimum is the only candidate within eps32 is done
+//   (no other candidate can be the reference's argmin); every other pixel is finished by the float64
+//   branch-and-bound search (co_box_search) inside the disc given by its float32 upper bound.
+// p = wh*(wh - U) is evaluated directly per candidate (w/2 is a wave-uniform table word): forward differences
+// would accumulate float32 error over the 499 steps.
+constexpr int XB32 = 16;
+
 template <typename T, typename TO>
-static hipError_t launch_exhaustive(const DevTables &L, const KArgs &A, hipStream_t stream)
+__global__ __launch_bounds__(256) void k_invert_exhaustive32(DevTables L, KArgs A, int rows_per_chunk)
+{
+    extern __shared__ __align__(16) float lds32[];  // [rows_per_chunk][phi_pad]
+    __shared__ int sh_bin, sh_nbatch;
+    __shared__ float2 row_terms[256];
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long strips_per_line = (A.samples + 63) >> 6, line_groups = (A.lines + 3) >> 2;
+    const long long cols_per_xcd = (strips_per_line + 7) >> 3;
+    const long long xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const long long col = xcd * cols_per_xcd + j / line_groups;
+    const long long line = (j % line_groups) * 4 + wv;
+    if (!((j / line_groups < cols_per_xcd) && col < strips_per_line)) return;  // block-uniform
+    const long long smp = col * 64 + lane;
+    const bool in = line < A.lines && smp < A.samples;
+    const long long i = in ? line * A.samples + smp : 0;
+    const float inff = __builtin_inff();
+
+    Pixel P;
+    load_pixel<T>(L, A, i, in, P);
+    bool pending = (P.flags & F_NEED_CO) != 0;
+    const bool fin = (P.flags & F_CO_FINITE) != 0;
+    const double ah = fin ? 0.5 * P.a_re : 0.0, bh = fin ? 0.5 * P.b_eff : 0.0;
+    const double m2 = ah * ah + bh * bh;
+    const double sn = fin ? -P.s_co * A.inv_dsig_co : 0.0;
+    const float inv32 = (float)A.inv_dsig_co;
+    // float32 error of dd = LUT*inv + sn  (LUT and sn rounded to float32, one fused rounding)
+    const float e_dd = 3e-7f * (float)((L.co_absmax + fabs(fin ? P.s_co : 0.0)) * fabs(A.inv_dsig_co));
+    const float whmax = (float)(0.5 * (L.w0 + (L.n_w - 1) / L.inv_wstep));
+    // float32 error of p = wh*(wh - U): U and wh rounded once from float64, two roundings in the product
+    const float e_p = 4e-7f * whmax * (whmax + 2.0f * (float)(fabs(ah) + fabs(bh)));
+    int my_flat = 0;
+    bool need_exact = (P.flags & F_NEED_CO) && !fin;
+    bool need_box = false;
+    double box_jub = 0.0;
+    unsigned long long cand = 0;
+    const int ncc = (L.n_phi + 63) >> 6;
+
+    for (;;) {
+        if (threadIdx.x == 0) { sh_bin = 0x7fffffff; sh_nbatch = 0; }
+        __syncthreads();
+        const int mb = wave_min_i(pending ? P.i_inc : 0x7fffffff);
+        if (lane == 0 && mb != 0x7fffffff) atomicMin(&sh_bin, mb);
+        __syncthreads();
+        const int cur = sh_bin;
+        if (cur == 0x7fffffff) break;
+        const bool mine = pending && P.i_inc == cur;
+        unsigned long long todo = __ballot(mine);
+        if (lane == 0) atomicMax(&sh_nbatch, (__popcll(todo) + XB32 - 1) / XB32);
+        __syncthreads();
+        const int nbatch = sh_nbatch;
+        const float *__restrict__ slice = L.co32 + (size_t)cur * L.n_w * L.phi_pad;
+
+        for (int b = 0; b < nbatch; ++b) {
+            int pl[XB32];
+#pragma unroll
+            for (int q = 0; q < XB32; ++q) {
+                pl[q] = todo ? (__ffsll((long long)todo) - 1) : -1;
+                if (todo) todo &= todo - 1;
+            }
+            float best[XB32], second[XB32], usn[XB32];
+            int code[XB32];
+#pragma unroll
+            for (int q = 0; q < XB32; ++q) {
+                best[q] = inff; second[q] = inff; code[q] = 0;
+                usn[q] = pl[q] >= 0 ? (float)rd_lane_d(sn, pl[q]) : 0.0f;
+            }
+
+            for (int cc = 0; cc < ncc; ++cc) {
+                const int ip = cc * 64 + lane;
+                const bool ok = ip < L.n_phi;
+                const int ipc = ok ? ip : 0;
+                const double cph = L.cphi[ipc], sph = L.sphi[ipc];
+                // U in float64, rounded once; inactive directions / empty slots: U = -inf => every score +inf
+                float U[XB32];
+#pragma unroll
+                for (int q = 0; q < XB32; ++q)
+                    U[q] = (ok && pl[q] >= 0) ? (float)(2.0 * (rd_lane_d(ah, pl[q]) * cph + rd_lane_d(bh, pl[q]) * sph)) : -inff;
+
+                for (int r0 = 0; r0 < L.n_w; r0 += rows_per_chunk) {
+                    const int rows = min(rows_per_chunk, L.n_w - r0);
+                    __syncthreads();  // previous chunk fully consumed
+                    {
+                        const float4 *__restrict__ src = (const float4 *)(slice + (size_t)r0 * L.phi_pad);
+                        float4 *dst = (float4 *)lds32;
+                        const int nvec = rows * L.phi_pad / 4;
+                        for (int v = threadIdx.x; v < nvec; v += 256) dst[v] = src[v];
+                        if ((int)threadIdx.x < rows) {  // per-row speed terms {(w/2)^2, -(w/2)}
+                            const float wh = L.wh32[r0 + threadIdx.x];
+                            row_terms[threadIdx.x] = make_float2(wh * wh, -wh);
+                        }
+                    }
+                    __syncthreads();
+                    const float *colp = lds32 + ipc;
+                    int codev = (r0 << 3) | cc;
+                    // rows outermost, the 16 pixels of the batch innermost: one LDS read of the LUT word and one
+                    // broadcast read of the row terms serve 16 candidates
+                    for (int r = 0; r < rows; ++r) {
+                        const float v = colp[r * L.phi_pad];
+                        const float2 rt = row_terms[r];
+#pragma unroll
+                        for (int q = 0; q < XB32; ++q) {
+                            const float dd = fmaf(v, inv32, usn[q]);
+                            const float J = fmaf(dd, dd, fmaf(U[q], rt.y, rt.x));   // dd^2 + wh*(wh - U)
+                            // two smallest of {best, second, J}: v_med3_f32 + v_min_f32 (best <= second always)
+                            second[q] = __builtin_amdgcn_fmed3f(best[q], second[q], J);
+                            code[q] = J < best[q] ? codev : code[q];
+                            best[q] = vminf(best[q], J);
+                        }
+                        codev += 8;
+                    }
+                }
+            }
+            // wave-level argmin + uniqueness within the float32 error bound, once per pixel
+#pragma unroll
+            for (int q = 0; q < XB32; ++q) {
+                if (pl[q] < 0) continue;
+                const float gmin = wave_min_f(best[q]);
+                const float m2q = (float)rd_lane_d(m2, pl[q]);
+                const float edd = __int_as_float(rd_lane_i(__float_as_int(e_dd), pl[q]));
+                const float ep = __int_as_float(rd_lane_i(__float_as_int(e_p), pl[q]));
+                const float jfull = fmaxf(gmin + m2q, 0.0f);
+                // |J32 - J| <= 2|dd| e_dd + e_dd^2 + e_p + 3 ulp32 of the terms, for every candidate that can matter
+                const float eps = 2.0f * (2.0f * sqrtf(jfull + 1.0f) * edd + edd * edd + ep + 4e-7f * (1.0f + fabsf(gmin) + 2.0f * jfull));
+                const float Tthr = gmin + eps;
+                const unsigned long long win = __ballot(best[q] <= Tthr);
+                const bool amb = !(gmin < inff) || __popcll(win) != 1 || __ballot(second[q] <= Tthr) != 0ULL;
+                const int wl = win ? (__ffsll((long long)win) - 1) : 0;
+                const int c = rd_lane_i(code[q], wl);
+                if (lane == pl[q]) {
+                    my_flat = (c >> 3) * L.n_phi + ((c & 7) * 64 + wl);
+                    need_box = amb && (gmin < inff);
+                    need_exact = need_exact || (amb && !(gmin < inff));
+                    box_jub = ((double)Tthr + (double)m2q) * (1.0 + 1e-6) + 1e-6;  // upper bound of the true minimum
+                }
+                cand += (unsigned long long)L.n_w * L.n_phi;
+            }
+        }
+        if (mine) pending = false;
+        __syncthreads();
+    }
+
+    // pixels the float32 sweep could not decide: float64 branch-and-bound inside the disc of their upper bound
+    unsigned n_box = 0, n_exact = 0;
+    unsigned cand2 = 0;
+    unsigned long long bx = __ballot(need_box && !need_exact);
+    const CoWindow W = box_from_jub(L, P.mag, P.theta, box_jub);
+    while (bx) {
+        const int p = __ffsll((long long)bx) - 1;
+        bx &= bx - 1;
+        bool went_exact = false;
+        const int flat = co_box_search(L, rd_lane_i(P.i_inc, p), rd_lane_d(P.s_co, p), rd_lane_d(P.a_re, p),
+                                       rd_lane_d(P.b_eff, p), rd_lane_i(W.w_lo, p), rd_lane_i(W.w_hi, p),
+                                       rd_lane_i(W.ip_lo, p), rd_lane_i(W.ip_hi, p), A.dsig_co, A.inv_dsig_co, lane,
+                                       cand2, went_exact);
+        if (lane == p) my_flat = flat;
+        n_box++;
+        n_exact += went_exact ? 1u : 0u;
+    }
+    unsigned long long ex = __ballot(need_exact);
+    while (ex) {
+        const int p = __ffsll((long long)ex) - 1;
+        ex &= ex - 1;
+        const int flat = exact_scan_co(L, rd_lane_i(P.i_inc, p), rd_lane_d(P.s_co, p), rd_lane_d(P.a_re, p),
+                                       rd_lane_d(P.b_eff, p), A.dsig_co, lane);
+        if (lane == p) my_flat = flat;
+        n_exact++;
+    }
+    const unsigned long long n_need = (unsigned long long)__popcll(__ballot((P.flags & F_NEED_CO) != 0));
+    if (A.stats && lane == 0) {
+        atomicAdd(&A.stats[0], n_need);
+        atomicAdd(&A.stats[1], cand + cand2);
+        atomicAdd(&A.stats[2], (unsigned long long)n_exact);
+        atomicAdd(&A.stats[3], (unsigned long long)n_box);  // pixels finished by the float64 box search
+    }
+    if (in) store_pixel<TO>(L, A, i, P, my_flat, -1);
+}
+
+template <typename T, typename TO>
+static hipError_t launch_exhaustive(const DevTables &L, const KArgs &A, hipStream_t stream, bool f32_screen)
 {
     if (L.n_phi > 8 * 64 || L.n_w >= (1 << 20)) return hipErrorInvalidValue;  // code = (iw << 3) | direction chunk
 #ifndef XSW_EXH_LDS_KB
 #define XSW_EXH_LDS_KB 40
 #endif
     const size_t lds_budget = (size_t)XSW_EXH_LDS_KB * 1024;  // 40 KB: four workgroups per CU (measured best of 24..128)
-    int rows = (int)(lds_budget / ((size_t)L.phi_pad * sizeof(double)));
+    const size_t esz = f32_screen ? sizeof(float) : sizeof(double);
+    int rows = (int)(lds_budget / ((size_t)L.phi_pad * esz));
     if (rows < 1) return hipErrorInvalidValue;
     if (rows > L.n_w) rows = L.n_w;
+    if (f32_screen && rows > 256) rows = 256;  // row_terms[256]
     rows &= ~3;  // whole groups of four rows
     if (rows < 4) rows = rows < 1 ? 1 : rows;
-    const size_t lds = (size_t)rows * L.phi_pad * sizeof(double);
+    const size_t lds = (size_t)rows * L.phi_pad * esz;
     const long long strips_per_line = (A.samples + 63) / 64, line_groups = (A.lines + 3) / 4;
     const long long nblocks = 8 * ((strips_per_line + 7) / 8) * line_groups;
     if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_invert_exhaustive<T, TO>), dim3((unsigned)nblocks), dim3(256), lds, stream, L, A, rows);
+    if (f32_screen)
+        hipLaunchKernelGGL((k_invert_exhaustive32<T, TO>), dim3((unsigned)nblocks), dim3(256), lds, stream, L, A, rows);
+    else
+        hipLaunchKernelGGL((k_invert_exhaustive<T, TO>), dim3((unsigned)nblocks), dim3(256), lds, stream, L, A, rows);
     return hipGetLastError();
 }
 
