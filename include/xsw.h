@@ -141,6 +141,18 @@ int xsw_lut_interp(xsw_ctx *ctx, const double *raw, const double *inc_raw, const
                    const double *inc, const double *wspd, const double *phi, int32_t n_inc, int32_t n_wspd,
                    int32_t n_phi, double *out);
 
+/* Built-in analytic GMFs on the device: out[i] = gmf(inc[i], wspd[i], phi[i]) over n already-broadcast float64
+ * elements (phi may be NULL for cross-pol models).  Replaces the numba-vectorised forward GMF of
+ * GmfModel.__call__(..., broadcast=True) (windspeed/gmfs.py:202-214, :293-316) for the models of gmfs_impl.py.
+ * gmf_id: XSW_GMF_* below.  Values agree with the host evaluation to ~1e-14 relative (device libm), not bitwise. */
+enum {
+    XSW_GMF_CMOD5 = 0, XSW_GMF_CMOD5N = 1, XSW_GMF_CMOD5N_PR_ZHANGA = 2, XSW_GMF_CMOD5N_PR_MOUCHE1 = 3,
+    XSW_GMF_CMODIFR2 = 4, XSW_GMF_RS2_V2 = 5, XSW_GMF_S1_V2 = 6, XSW_GMF_RCM_NOAA = 7, XSW_GMF_S1_V3_EW_REC = 8,
+    XSW_GMF_RS2_V3 = 9, XSW_GMF_RCM_V3 = 10, XSW_GMF_RCM_V4 = 11, XSW_GMF_RS2_V4 = 12
+};
+int xsw_gmf_eval(xsw_ctx *ctx, int32_t gmf_id, int64_t n, int32_t mem, const double *inc, const double *wspd,
+                 const double *phi, double *out);
+
 /* Replaces the per-pixel part of sigma0_detrend (detrend.py:63-64):
  * out[l][s] = sigma0[l][s] / ratio_row[s], ratio_row = g / nanmean(g) (float64, host pointer).
  * out is float64 (the reference's result dtype) when out_dtype == XSW_F64. */

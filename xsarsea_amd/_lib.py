@@ -13,9 +13,13 @@ ALGO_AUTO, ALGO_PRUNED, ALGO_EXHAUSTIVE, ALGO_EXACT, ALGO_EXHAUSTIVE_F64 = 0, 1,
 ALGOS = {"auto": ALGO_AUTO, "pruned": ALGO_PRUNED, "exhaustive": ALGO_EXHAUSTIVE, "exact": ALGO_EXACT,
          "exhaustive_f64": ALGO_EXHAUSTIVE_F64}
 
+GMF_IDS = {"gmf_cmod5": 0, "gmf_cmod5n": 1, "gmf_cmod5n_pr_zhangA": 2, "gmf_cmod5n_pr_mouche1": 3, "gmf_cmodifr2": 4,
+           "gmf_rs2_v2": 5, "gmf_s1_v2": 6, "gmf_rcm_noaa": 7, "gmf_s1_v3_ew_rec": 8, "gmf_rs2_v3": 9, "gmf_rcm_v3": 10,
+           "gmf_rcm_v4": 11, "gmf_rs2_v4": 12}
+
 EXPORTS = (
     "xsw_version", "xsw_device_count", "xsw_ctx_create", "xsw_ctx_destroy", "xsw_last_error", "xsw_set_stream", "xsw_use_own_stream",
-    "xsw_synchronize", "xsw_lut_upload", "xsw_invert", "xsw_stats_enable", "xsw_stats_read", "xsw_detrend", "xsw_lut_interp",
+    "xsw_synchronize", "xsw_lut_upload", "xsw_invert", "xsw_stats_enable", "xsw_stats_read", "xsw_detrend", "xsw_lut_interp", "xsw_gmf_eval",
 )
 
 
@@ -99,6 +103,7 @@ def load():
                                     ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.xsw_lut_interp.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4 + [ctypes.c_int32] * 3 + \
             [ctypes.c_void_p] * 3 + [ctypes.c_int32] * 3 + [ctypes.c_void_p]
+        lib.xsw_gmf_eval.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32] + [ctypes.c_void_p] * 4
         _cdll = lib
     return _cdll
 
@@ -206,6 +211,18 @@ class Context:
             self._h, _ptr(raw), _ptr(inc_raw), _ptr(wspd_raw), _ptr(phi_raw), len(inc_raw), len(wspd_raw),
             len(phi_raw) if has_phi else 0, _ptr(inc), _ptr(wspd), _ptr(phi), len(inc), len(wspd),
             len(phi) if has_phi else 0, _ptr(out)), "xsw_lut_interp")
+        return out
+
+    def gmf_eval(self, gmf_id, inc, wspd, phi=None):
+        """xsw_gmf_eval on host float64 arrays of one common shape."""
+        inc = _f64(inc)
+        wspd = _f64(wspd)
+        phi = None if phi is None else _f64(phi)
+        if wspd.shape != inc.shape or (phi is not None and phi.shape != inc.shape):
+            raise ValueError("gmf_eval wants already-broadcast arrays of one shape")
+        out = np.empty(inc.shape, dtype=np.float64)
+        self._check(self._lib.xsw_gmf_eval(self._h, int(gmf_id), inc.size, MEM_HOST, _ptr(inc), _ptr(wspd), _ptr(phi),
+                                           _ptr(out)), "xsw_gmf_eval")
         return out
 
     def stats_enable(self, on=True):

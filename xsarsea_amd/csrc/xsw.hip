@@ -12,6 +12,7 @@
 #include "xsw.h"
 #include "xsw_device.hpp"
 #include "xsw_exhaustive.hpp"
+#include "xsw_gmf.hpp"
 
 using namespace xsw;
 
@@ -538,6 +539,49 @@ extern "C" int xsw_lut_interp(xsw_ctx *c, const double *raw, const double *inc_r
     if (!rc && se != hipSuccess) rc = fail(c, XSW_EHIP, "lut_interp: %s", hipGetErrorString(se));
     for (void *p : tmp) (void)hipFree(p);
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------- forward GMF
+extern "C" int xsw_gmf_eval(xsw_ctx *c, int32_t gmf_id, int64_t n, int32_t mem, const double *inc, const double *wspd,
+                            const double *phi, double *out)
+{
+    if (!c) return XSW_EINVAL;
+    if (gmf_id < 0 || gmf_id >= GMF_COUNT) return fail(c, XSW_EINVAL, "unknown gmf_id %d", gmf_id);
+    if (n < 0 || !inc || !wspd || !out) return fail(c, XSW_EINVAL, "gmf_eval: bad argument");
+    if (gmf_id <= GMF_CMODIFR2 && !phi) return fail(c, XSW_EINVAL, "gmf_eval: this GMF needs phi");
+    if (n == 0) return XSW_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const double *d_inc = inc, *d_w = wspd, *d_phi = phi;
+    double *d_out = out;
+    std::vector<void *> tmp;
+    hipError_t e = hipSuccess;
+    if (mem == XSW_MEM_HOST) {
+        auto stage = [&](const double *h, const double **d) {
+            if (e != hipSuccess || !h) return;
+            void *p = nullptr;
+            e = hipMalloc(&p, (size_t)n * 8);
+            if (e != hipSuccess) return;
+            tmp.push_back(p);
+            e = hipMemcpyAsync(p, h, (size_t)n * 8, hipMemcpyHostToDevice, c->stream);
+            *d = (const double *)p;
+        };
+        stage(inc, &d_inc); stage(wspd, &d_w); stage(phi, &d_phi);
+        if (e == hipSuccess) { void *p = nullptr; e = hipMalloc(&p, (size_t)n * 8); if (e == hipSuccess) { tmp.push_back(p); d_out = (double *)p; } }
+    }
+    if (e == hipSuccess) {
+        long long blocks = (n + 255) / 256;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(k_gmf_eval, dim3((unsigned)blocks), dim3(256), 0, c->stream, (int)gmf_id, (long long)n, d_inc, d_w, d_phi, d_out);
+        e = hipGetLastError();
+    }
+    if (mem == XSW_MEM_HOST) {
+        if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream);
+        hipError_t se = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = se;
+        for (void *p : tmp) (void)hipFree(p);
+    }
+    if (e != hipSuccess) return fail(c, XSW_EHIP, "gmf_eval failed: %s", hipGetErrorString(e));
+    return XSW_OK;
 }
 
 // ---------------------------------------------------------------------------------------- detrend

@@ -17,3 +17,9 @@ algo = "auto"
 #: LUT resolution change (Model._normalize_lut): "auto" = on the device when one is present (bit-identical to
 #: the host numpy path, ~100x faster at the default 501x499x181 size), "host" = numpy, "device" = always device.
 lut_interp = "auto"
+
+#: forward GMF of the built-in models on broadcast arrays (GmfModel.__call__(..., broadcast=True)):
+#: "auto" = device for >= gmf_device_min_size elements when a device is present (values agree with the host
+#: evaluation to ~1e-14 relative, not bit for bit; LUT preparation always evaluates on the host), "host", "device".
+gmf_on_device = "auto"
+gmf_device_min_size = 1 << 18

@@ -107,7 +107,7 @@ class GmfModel(Model):
                     template = v
                     break
             arrs = np.broadcast_arrays(*[np.asarray(v, dtype=np.float64) for v in args])
-            out = _array_eval(self._gmf_pyfunc_scalar, arrs[0], arrs[1], arrs[2] if phi is not None else None)
+            out = self._broadcast_eval(arrs[0], arrs[1], arrs[2] if phi is not None else None)
             if template is not None and template.shape == out.shape:
                 res = template.copy().astype(np.float64)
                 res.attrs.clear()
@@ -129,6 +129,17 @@ class GmfModel(Model):
             da.attrs["units"] = self.units
             return da
         raise ValueError("Non 1d shape must all have the same shape")
+
+    def _broadcast_eval(self, inc, wspd, phi):
+        """Elementwise evaluation on same-shape arrays: device kernel (xsw_gmf_eval) for large inputs of a
+        built-in model, numpy otherwise."""
+        from .. import _lib, options
+        gid = _lib.GMF_IDS.get(self.name) if getattr(self, "_builtin", False) else None
+        mode = options.gmf_on_device
+        if gid is not None and (mode == "device" or (mode == "auto" and inc.size >= options.gmf_device_min_size
+                                                     and _lib.device_count_safe() > 0)):
+            return _lib.default_context(options.device).gmf_eval(gid, inc, wspd, phi)
+        return _array_eval(self._gmf_pyfunc_scalar, inc, wspd, phi)
 
     def _grid(self, inc, wspd, phi):
         """Dense (incidence, wspd[, phi]) evaluation: the fill of gmfs.py:215-232."""

@@ -212,3 +212,9 @@ def _register_vh(name, model):
 
 for _name, _model in _VH_MODELS.items():
     globals()[_name] = _register_vh(_name, _model)
+
+
+# the models above have a device implementation (csrc/xsw_gmf.hpp); a user model that re-registers one of these
+# names with another function does not inherit the flag
+for _name in ("gmf_cmod5", "gmf_cmod5n", "gmf_cmod5n_pr_zhangA", "gmf_cmod5n_pr_mouche1", "gmf_cmodifr2", *_VH_MODELS):
+    GmfModel._registry[_name]._builtin = True
