@@ -21,6 +21,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: required for multi-process RCCL on this host driver
+
 import numpy as np
 import torch
 
@@ -292,6 +294,8 @@ def main():
     if args.stats:
         ctx.stats_enable(True)
         step()
+        gather()
+        fence()
         stats = ctx.stats()
         ctx.stats_enable(False)
 
