@@ -427,49 +427,6 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
     return eI;
 }
 
-// Cross-pol 1-D search (windspeed.py:252-269): screening + exact refine, full speed axis.
-__device__ __forceinline__ int search_cr(const DevTables &L, int i_inc, double s, double dsig, bool have_co,
-                                         double aco, int lane, bool fast_ok)
-{
-    const double inv = 1.0 / dsig;
-    if (!fast_ok || !isfinite(inv) || !isfinite(s) || (have_co && !isfinite(aco)))
-        return exact_scan_cr(L, i_inc, s, dsig, have_co, aco, lane);
-    const double *__restrict__ row = L.cr + (size_t)i_inc * L.wcr_pad;
-    const double sn = -s * inv;
-    const double ach = 0.5 * aco;
-    double best = __builtin_inf(), second = __builtin_inf();
-    int bidx = 0x7fffffff;
-    for (int k0 = 0; k0 < L.n_wcr; k0 += 64) {
-        const int k = k0 + lane;
-        const bool ok = k < L.n_wcr;
-        const int kk = ok ? k : 0;
-        const double dd = fma(row[kk], inv, sn);
-        double J = dd * dd;
-        if (have_co) {
-            const double t = L.wcrh[kk] - ach;
-            J = fma(t, t, J);
-        }
-        J = ok ? J : __builtin_inf();
-        second = fmin(second, fmax(J, best));
-        if (J < best) { best = J; bidx = kk; }
-    }
-    const double gmin = wave_min_d(best);
-    const double T = gmin + 1e-9 * (1.0 + fabs(gmin));
-    if (__ballot(second <= T) != 0ULL || !(gmin < __builtin_inf()))
-        return exact_scan_cr(L, i_inc, s, dsig, have_co, aco, lane);
-    unsigned long long surv = __ballot(best <= T);
-    double eJ = __builtin_inf();
-    int eI = 0x7fffffff;
-    while (surv) {
-        const int l = __ffsll((long long)surv) - 1;
-        surv &= surv - 1;
-        const int k = rd_lane_i(bidx, l);
-        const double J = exact_J_cr(L.wcr[k], row[k], s, dsig, have_co, aco);
-        if (J < eJ || (J == eJ && k < eI)) { eJ = J; eI = k; }
-    }
-    return eI;
-}
-
 // Cross-pol search, one pixel per lane (all 64 pixels of the strip at once).  The speed axis has the same
 // length for every pixel, so the trip count is wave-uniform and nothing diverges; lanes of one incidence
 // bin read the same LUT word (one cache line per wave load).  Each lane sees ALL candidates of its pixel, so

@@ -103,8 +103,7 @@ def invert_from_model(inc, sigma0, sigma0_dual=None, /, ancillary_wind=None, dsi
 
     # cross-pol search disabled for every pixel when all cross sigma0 are NaN (:170) is implicit: NaN pixels skip it
     template = next((v for v in (sigma0, inc, sigma0_dual, ancillary_wind) if _is_xr(v)), None)
-    dsig_in = dsig_cr if np.isscalar(dsig_cr) else dsig_cr
-    args = (inc, sigma0_co, sigma0_cr, dsig_in, ancillary_wind if ancillary_wind is not nan else None)
+    args = (inc, sigma0_co, sigma0_cr, dsig_cr, ancillary_wind if ancillary_wind is not nan else None)
 
     if any(_is_dask(v) for v in args if v is not None and not np.isscalar(v)):
         # dask in -> lazy dask out, one device call per row block (core dimension = last axis, :356-364)
