@@ -155,7 +155,8 @@ int xsw_gmf_eval(xsw_ctx *ctx, int32_t gmf_id, int64_t n, int32_t mem, const dou
 
 /* Replaces the per-pixel part of sigma0_detrend (detrend.py:63-64):
  * out[l][s] = sigma0[l][s] / ratio_row[s], ratio_row = g / nanmean(g) (float64, host pointer).
- * out is float64 (the reference's result dtype) when out_dtype == XSW_F64. */
+ * out is float64 (the reference's result dtype) when out_dtype == XSW_F64.  Host rasters: synchronous; device
+ * rasters: asynchronous on the context's stream (ratio_row is consumed before the call returns). */
 int xsw_detrend(xsw_ctx *ctx, int64_t lines, int64_t samples, int32_t dtype, int32_t out_dtype, int32_t mem,
                 const void *sigma0, const double *ratio_row, void *out);
 

@@ -221,13 +221,23 @@ def test_errors(gpu_ctx):
 
 
 def test_detrend_kernel(gpu_ctx):
+    """out = sigma0 / ratio[sample] must be the IEEE quotient bit for bit: both the fused-multiply path (ordinary
+    divisors) and the true-division path (a divisor that fails the host's check), vector and scalar layouts,
+    inf / NaN / zero / tiny pixels."""
     rng = np.random.default_rng(3)
-    for dt in (np.float32, np.float64):
-        s = rng.uniform(0.001, 0.3, (37, 211)).astype(dt)
-        ratio = rng.uniform(0.5, 2.0, 211)
-        out = gpu_ctx.detrend_host(s, ratio)
-        ref = s / ratio[None, :]
-        assert out.dtype == np.float64 and np.array_equal(out, ref.astype(np.float64))
+    for samples in (211, 212, 4096):
+        for dt in (np.float32, np.float64):
+            s = (10 ** rng.uniform(-6, 1, (37, samples))).astype(dt)
+            s[0, :8] = [0.0, np.inf, -np.inf, np.nan, 1e-38, -1.5, 3e38 if dt == np.float32 else 1e300, 1e-45 if dt == np.float32 else 5e-324]
+            for special in (False, True):
+                ratio = 10 ** rng.uniform(-3, 3, samples)
+                if special:
+                    ratio[5] = np.float64(2.0) - np.finfo(np.float64).eps   # significand all ones -> division path
+                out = gpu_ctx.detrend_host(s, ratio)
+                with np.errstate(all="ignore"):
+                    ref = (s.astype(np.float64) / ratio[None, :])
+                assert out.dtype == np.float64
+                assert np.array_equal(out.view(np.int64), ref.view(np.int64)), (samples, dt, special)
 
 
 def _axis_case_lut(rng, phi_axis, w_axis=None, inc_axis=None):

@@ -25,6 +25,8 @@ struct xsw_ctx {
     bool have_co = false, have_cr = false;
     unsigned long long *d_stats = nullptr;
     bool stats_on = false;
+    double *d_ratio = nullptr;  // detrend ratio row (context-owned, grown on demand)
+    size_t ratio_cap = 0;
     std::string err;
 };
 
@@ -94,6 +96,7 @@ extern "C" int xsw_ctx_destroy(xsw_ctx *c)
     free_all(c->co_allocs);
     free_all(c->cr_allocs);
     if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->d_ratio) (void)hipFree(c->d_ratio);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return XSW_OK;
@@ -586,12 +589,22 @@ extern "C" int xsw_gmf_eval(xsw_ctx *c, int32_t gmf_id, int64_t n, int32_t mem, 
 
 // ---------------------------------------------------------------------------------------- detrend
 template <typename T, typename TO>
-static void launch_detrend(hipStream_t s, const void *in, const double *ratio, void *out, long long lines, long long samples)
+static void launch_detrend(hipStream_t s, const void *in, const double *ratio, const double *rinv, bool fast, void *out,
+                           long long lines, long long samples)
 {
-    const long long n = lines * samples;
-    long long blocks = (n + 255) / 256;
-    if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL((k_detrend<T, TO>), dim3((unsigned)blocks), dim3(256), 0, s, (const T *)in, ratio, (TO *)out, lines, samples);
+    const long long quads = (samples + 3) / 4;
+    const unsigned gx = (unsigned)((quads + 255) / 256);
+    long long gy = (256LL * 16 + gx - 1) / gx;  // ~16 workgroups per CU
+    if (gy > lines) gy = lines;
+    if (gy > 65535) gy = 65535;
+    if (gy < 1) gy = 1;
+    const long long lpb = (lines + gy - 1) / gy;
+    gy = (lines + lpb - 1) / lpb;
+    const dim3 grid(gx, (unsigned)gy);
+    if (fast)
+        hipLaunchKernelGGL((k_detrend<T, TO, 1>), grid, dim3(256), 0, s, (const T *)in, ratio, rinv, (TO *)out, lines, samples, lpb);
+    else
+        hipLaunchKernelGGL((k_detrend<T, TO, 0>), grid, dim3(256), 0, s, (const T *)in, ratio, rinv, (TO *)out, lines, samples, lpb);
 }
 
 extern "C" int xsw_detrend(xsw_ctx *c, int64_t lines, int64_t samples, int32_t dtype, int32_t out_dtype, int32_t mem,
@@ -603,9 +616,29 @@ extern "C" int xsw_detrend(xsw_ctx *c, int64_t lines, int64_t samples, int32_t d
     if (n == 0) return XSW_OK;
     HIPCHK(c, hipSetDevice(c->device));
     const size_t es = dtype == XSW_F32 ? 4 : 8, os = out_dtype == XSW_F32 ? 4 : 8;
-    double *d_ratio = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d_ratio, samples * sizeof(double)));
-    hipError_t e = hipMemcpyAsync(d_ratio, ratio_row, samples * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    // the ratio row lives in a context-owned buffer (grown on demand): no allocation on the steady-state path
+    if ((size_t)samples > c->ratio_cap) {
+        if (c->d_ratio) (void)hipFree(c->d_ratio);
+        c->d_ratio = nullptr;
+        c->ratio_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_ratio, 2 * (size_t)samples * sizeof(double) + 64));
+        c->ratio_cap = (size_t)samples;
+    }
+    // [ratio | RN(1/ratio)]; the fused-multiply quotient is exact only for "ordinary" divisors: check them all
+    std::vector<double> both(2 * (size_t)samples);
+    bool fast = true;
+    for (int64_t k = 0; k < samples; ++k) {
+        const double r = ratio_row[k];
+        both[(size_t)k] = r;
+        both[(size_t)samples + k] = 1.0 / r;
+        uint64_t bits;
+        memcpy(&bits, &r, 8);
+        const double ar = std::fabs(r);
+        if (!(ar > 0x1p-500 && ar < 0x1p500) || (bits & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull) fast = false;
+    }
+    double *d_rinv = c->d_ratio + samples;
+    hipError_t e = hipMemcpyAsync(c->d_ratio, both.data(), 2 * (size_t)samples * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // `both` is a local
     const void *d_in = sigma0;
     void *d_out = out, *t_in = nullptr, *t_out = nullptr;
     if (e == hipSuccess && mem == XSW_MEM_HOST) {
@@ -616,19 +649,19 @@ extern "C" int xsw_detrend(xsw_ctx *c, int64_t lines, int64_t samples, int32_t d
         d_out = t_out;
     }
     if (e == hipSuccess) {
-        if (dtype == XSW_F32 && out_dtype == XSW_F32) launch_detrend<float, float>(c->stream, d_in, d_ratio, d_out, lines, samples);
-        else if (dtype == XSW_F32) launch_detrend<float, double>(c->stream, d_in, d_ratio, d_out, lines, samples);
-        else if (out_dtype == XSW_F32) launch_detrend<double, float>(c->stream, d_in, d_ratio, d_out, lines, samples);
-        else launch_detrend<double, double>(c->stream, d_in, d_ratio, d_out, lines, samples);
+        if (dtype == XSW_F32 && out_dtype == XSW_F32) launch_detrend<float, float>(c->stream, d_in, c->d_ratio, d_rinv, fast, d_out, lines, samples);
+        else if (dtype == XSW_F32) launch_detrend<float, double>(c->stream, d_in, c->d_ratio, d_rinv, fast, d_out, lines, samples);
+        else if (out_dtype == XSW_F32) launch_detrend<double, float>(c->stream, d_in, c->d_ratio, d_rinv, fast, d_out, lines, samples);
+        else launch_detrend<double, double>(c->stream, d_in, c->d_ratio, d_rinv, fast, d_out, lines, samples);
         e = hipGetLastError();
     }
-    if (e == hipSuccess && mem == XSW_MEM_HOST) e = hipMemcpyAsync(out, t_out, n * os, hipMemcpyDeviceToHost, c->stream);
-    // the ratio row is a temporary: the call is synchronous in both memory modes
-    hipError_t se = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = se;
-    (void)hipFree(d_ratio);
-    if (t_in) (void)hipFree(t_in);
-    if (t_out) (void)hipFree(t_out);
+    if (mem == XSW_MEM_HOST) {  // host rasters: synchronous; device rasters: asynchronous on the context's stream
+        if (e == hipSuccess) e = hipMemcpyAsync(out, t_out, n * os, hipMemcpyDeviceToHost, c->stream);
+        hipError_t se = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = se;
+        if (t_in) (void)hipFree(t_in);
+        if (t_out) (void)hipFree(t_out);
+    }
     if (e != hipSuccess) return fail(c, XSW_EHIP, "detrend failed: %s", hipGetErrorString(e));
     return XSW_OK;
 }

@@ -789,15 +789,78 @@ __global__ __launch_bounds__(256) void k_lut_interp(InterpArgs a)
     }
 }
 
-// sigma0_detrend's per-pixel work (detrend.py:64): out = sigma0 / ratio[sample]
-template <typename T, typename TO>
-__global__ __launch_bounds__(256) void k_detrend(const T *__restrict__ sigma0, const double *__restrict__ ratio,
-                                                 TO *__restrict__ out, long long lines, long long samples)
+// sigma0_detrend's per-pixel work (detrend.py:64): out = sigma0 / ratio[sample].  Purely HBM-bound:
+// 16-B vector loads/stores (4 samples per thread), the ratio row stays in L2; no integer division per pixel.
+template <typename T, int N> struct VecOf;
+template <> struct VecOf<float, 4> { typedef float4 type; };
+template <> struct VecOf<double, 4> { typedef double4 type; };
+
+// FAST = 1: x / r as q0 = x*y, q = fma(fma(-q0, r, x), y, q0) with y = RN(1/r) prepared on the host: the
+// correctly rounded quotient (Markstein) whenever r is finite, non-zero, within 2^+-500 and its significand is not
+// all ones -- the host checks every r and otherwise launches FAST = 0 (IEEE division sequence, ~10x the VALU work).
+// Non-finite q0 (x = +-inf or NaN) is returned as is, which is what the division gives.
+template <int FAST>
+__device__ __forceinline__ double div_by(double x, double r, double y)
 {
-    const long long n = lines * samples;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const long long sidx = i % samples;
-        out[i] = (TO)((double)sigma0[i] / ratio[sidx]);
+    if (!FAST) return x / r;
+    const double q0 = x * y;
+    const double q1 = fma(fma(-q0, r, x), y, q0);
+    return isfinite(q0) ? q1 : q0;
+}
+
+// grid.x tiles the sample axis in quads (4 samples per thread, 16-B accesses), grid.y tiles the lines; a thread
+// keeps its 4 divisors (and reciprocals) in registers and streams down its lines: per pixel only the sigma0 load
+// and the store touch memory.  Samples not divisible by 4: the last (partial) quad is handled element-wise.
+template <typename T, typename TO, int FAST>
+__global__ __launch_bounds__(256) void k_detrend(const T *__restrict__ sigma0, const double *__restrict__ ratio,
+                                                 const double *__restrict__ rinv, TO *__restrict__ out, long long lines,
+                                                 long long samples, long long lines_per_block)
+{
+    const long long quad = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long s0 = quad * 4;
+    if (s0 >= samples) return;
+    const long long l0 = (long long)blockIdx.y * lines_per_block;
+    const long long l1 = l0 + lines_per_block < lines ? l0 + lines_per_block : lines;
+    const bool full = s0 + 4 <= samples && (samples & 3) == 0;  // aligned 16-B accesses need samples % 4 == 0
+    double r[4], y[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long sk = s0 + k < samples ? s0 + k : samples - 1;
+        r[k] = ratio[sk];
+        y[k] = FAST ? rinv[sk] : 0.0;
+    }
+    if (full) {
+        typedef typename VecOf<T, 4>::type vin_t;
+        typedef typename VecOf<TO, 4>::type vout_t;
+        const vin_t *in = (const vin_t *)(sigma0 + l0 * samples + s0);
+        vout_t *o = (vout_t *)(out + l0 * samples + s0);
+        const long long stride = samples >> 2;
+        long long l = l0;
+        for (; l + 4 <= l1; l += 4) {  // four lines in flight (64 B of loads per lane before the first use)
+            vin_t a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = in[u * stride];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                vout_t ou;
+                ou.x = (TO)div_by<FAST>((double)a[u].x, r[0], y[0]); ou.y = (TO)div_by<FAST>((double)a[u].y, r[1], y[1]);
+                ou.z = (TO)div_by<FAST>((double)a[u].z, r[2], y[2]); ou.w = (TO)div_by<FAST>((double)a[u].w, r[3], y[3]);
+                o[u * stride] = ou;
+            }
+            in += 4 * stride; o += 4 * stride;
+        }
+        for (; l < l1; ++l) {
+            const vin_t a = in[0];
+            vout_t oa;
+            oa.x = (TO)div_by<FAST>((double)a.x, r[0], y[0]); oa.y = (TO)div_by<FAST>((double)a.y, r[1], y[1]);
+            oa.z = (TO)div_by<FAST>((double)a.z, r[2], y[2]); oa.w = (TO)div_by<FAST>((double)a.w, r[3], y[3]);
+            o[0] = oa;
+            in += stride; o += stride;
+        }
+    } else {
+        for (long long l = l0; l < l1; ++l)
+            for (int k = 0; k < 4 && s0 + k < samples; ++k)
+                out[l * samples + s0 + k] = (TO)div_by<FAST>((double)sigma0[l * samples + s0 + k], r[k], y[k]);
     }
 }
 
