@@ -308,3 +308,50 @@ def test_cmod7_shaped_lut(gpu_ctx, tmp_path):
         got = windspeed.invert_from_model(inc, s_vv, ancillary_wind=anc, model="gmf_cmod7")
     o = oracle_full(inc, s_vv, None, None, anc, lco, None)
     assert_complex_close(got, o[0], what="cmod7")
+
+
+@pytest.mark.parametrize("kind", ["constant", "plateaus"])
+def test_exact_ties_resolve_to_first_index(gpu_ctx, kind):
+    """numpy argmin returns the FIRST minimum.  A constant (or piecewise-constant) LUT on binary-fraction axes
+    with ancillary winds placed exactly midway between grid points produces genuinely tied costs in float64;
+    every kernel must pick the same (lowest flat index) candidate as the oracle."""
+    from oracle import lut as olut
+    rng = np.random.default_rng(5)
+    inc_ax = np.array([20.0, 30.0, 40.0])
+    w_ax = 0.5 * np.arange(1, 65)            # 0.5 .. 32.0, exact in binary
+    phi_ax = np.arange(0, 181, 11.25)        # 17 directions incl. 0, 45, 90, 135, 180
+    vals = np.full((3, 64, 17), -20.0)
+    if kind == "plateaus":
+        vals = vals + np.floor(w_ax / 4.0)[None, :, None] * 0.5 + np.floor(phi_ax / 45.0)[None, None, :] * 0.25
+    lco = olut.Lut(vals, inc_ax, w_ax, phi_ax, "dB", "x", "co", "VV")
+    co, _ = lut_dicts(lco, None)
+    gpu_ctx.upload_luts(co=co)
+    n = 4096
+    inc = rng.choice([19.0, 25.0, 30.0, 35.0, 41.0], n)          # 25 and 35: exactly between incidence bins
+    kw = rng.integers(1, 63, n)
+    a = 0.5 * kw + rng.choice([0.0, 0.25], n)                     # on a grid speed, or exactly midway
+    ang = rng.choice([0.0, 45.0, 90.0, 135.0, 180.0, 22.5, -45.0, -90.0], n)
+    anc = a * np.exp(1j * np.deg2rad(ang))
+    anc[ang == 0.0] = a[ang == 0.0] + 0j                          # exact real axis
+    anc[ang == 90.0] = 1j * a[ang == 90.0]
+    s = 10 ** (rng.choice([-20.0, -19.75, -18.0, -21.0], n) / 10.0)
+    shape = (32, 128)
+    inc, s, anc = inc.reshape(shape), s.reshape(shape), anc.reshape(shape)
+    from oracle import invert as oinv
+    sdb = oinv.to_db(s)
+    o = oracle_full(inc, s, None, None, anc, lco, None)
+    for algo in ALGOS_ALL + ["exhaustive", "exhaustive_f64"]:
+        got = gpu_ctx.invert_host(inc, sigma0_co=sdb, anc=anc, sigma0_is_db=True, algo=algo, want_idx=True)
+        assert np.array_equal(got[2][..., :2], o[2][..., :2]), (kind, algo)
+    # the ties are real: the oracle's minimum is attained by several candidates for a large share of the pixels
+    p = oinv.Prepared(lco, None)
+    tied = 0
+    for k in range(0, n, 16):
+        i, j = divmod(k, shape[1])
+        if o[2][i, j, 0] < 0:
+            continue
+        ii = np.argmin(np.abs(inc_ax - inc[i, j]))
+        J = ((p.lut_co_antenna - anc[i, j].real) / 2) ** 2 + ((p.lut_co_azi - abs(anc[i, j].imag)) / 2) ** 2 \
+            + ((p.co_lut[:, :, ii] - sdb[i, j]) / 0.1) ** 2
+        tied += int(np.sum(J == J.min()) > 1)
+    assert tied > 20 or kind != "constant"
