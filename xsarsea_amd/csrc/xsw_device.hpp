@@ -385,9 +385,8 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
                     double J = fma(dd, dd, pw);
                     if (masked.value) J = (w_base + r0 + k * G + grp) < L.n_w ? J : inf;
                     second = vmin(second, vmax(J, best));
-                    const bool lt = J < best;
-                    best = lt ? J : best;
-                    code = lt ? (r0 + k * G) : code;
+                    code = J < best ? (r0 + k * G) : code;
+                    best = vmin(best, J);
                     pw += dp;
                     dp += ddp;
                 }
