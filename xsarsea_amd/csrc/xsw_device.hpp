@@ -370,15 +370,17 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
         const double wh = fma((double)(w_base + grp), whs, wh0);
         double pw = act ? wh * (wh - U) : inf, dp = act ? dG * (2.0 * wh - U) + dG * dG : 0.0;  // inactive lanes: +inf
         const double ddp = 2.0 * dG * dG;
-        const double *ptr = slice + (size_t)(w_base + grp) * L.phi_pad + ip;
-        const size_t pstep = (size_t)G * L.phi_pad;
+        // wave-uniform slice base (SGPR pair) + 32-bit per-lane byte offsets: no 64-bit address arithmetic
+        const char *__restrict__ sbase = (const char *)slice;
+        unsigned off = (unsigned)(((w_base + grp) * L.phi_pad + ip) * 8);
+        const unsigned pstepB = (unsigned)(G * L.phi_pad * 8);
         int code = -1;  // iteration slot of this lane's best within the chunk
         auto sweep = [&](auto masked) {
             for (int r0 = 0; r0 < rows_r; r0 += step) {
                 double v[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = ptr[k * pstep];
-                ptr += 4 * pstep;
+                for (int k = 0; k < 4; ++k) v[k] = *(const double *)(sbase + (off + (unsigned)k * pstepB));
+                off += 4u * pstepB;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const double dd = fma(v[k], inv_dsig, sn);
