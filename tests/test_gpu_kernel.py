@@ -355,3 +355,59 @@ def test_exact_ties_resolve_to_first_index(gpu_ctx, kind):
             + ((p.co_lut[:, :, ii] - sdb[i, j]) / 0.1) ** 2
         tied += int(np.sum(J == J.min()) > 1)
     assert tied > 20 or kind != "constant"
+
+
+def test_random_configurations(gpu_ctx):
+    """150 random problem instances (LUT shape and ranges, dsig_co, dtype, rough or smooth LUT, NaN/inf/zero inputs)
+    through every kernel; indices must equal the oracle's, dual-pol included."""
+    from oracle import gmf, lut as olut
+    from oracle import invert as oinv
+    rng = np.random.default_rng(2026)
+    for case in range(150):
+        n_inc, n_w, n_phi = int(rng.integers(2, 12)), int(rng.integers(2, 90)), int(rng.integers(2, 75))
+        inc_ax = np.sort(rng.uniform(17, 60, 2))
+        inc_ax = np.linspace(inc_ax[0], inc_ax[1] + 1.0, n_inc)
+        w_ax = np.linspace(rng.uniform(0.1, 3.0), rng.uniform(15, 60), n_w)
+        phi_ax = np.linspace(0.0, float(rng.choice([90.0, 180.0, 270.0, 360.0])), n_phi)
+        co = 10 * np.log10(gmf.gmf_cmod5n(inc_ax[:, None, None], w_ax[None, :, None], phi_ax[None, None, :]) + 1e-15)
+        co = co + rng.choice([0.0, 0.02, 1.0]) * rng.standard_normal(co.shape)
+        n_wcr = int(rng.integers(2, 120))
+        wcr_ax = np.linspace(3.0, rng.uniform(20, 80), n_wcr)
+        cr = 10 * np.log10(gmf.GMFS["gmf_s1_v2"][0](inc_ax[:, None], wcr_ax[None, :]) + 1e-15)
+        cr = cr + rng.choice([0.0, 0.5]) * rng.standard_normal(cr.shape)
+        lco = olut.Lut(co, inc_ax, w_ax, phi_ax, "dB", "x", "co", "VV")
+        lcr = olut.Lut(cr, inc_ax, wcr_ax, None, "dB", "x", "cr", "VH")
+        c, r = lut_dicts(lco, lcr)
+        gpu_ctx.upload_luts(co=c, cr=r)
+        shape = (int(rng.integers(1, 9)), int(rng.integers(1, 150)))
+        n = shape[0] * shape[1]
+        dt = rng.choice([np.float32, np.float64])
+        inc = rng.uniform(inc_ax[0] - 3, inc_ax[-1] + 3, n)
+        wt, pt = rng.uniform(0.2, 45, n), rng.uniform(-180, 180, n)
+        s_vv = gmf.gmf_cmod5n(np.clip(inc, 17, 65), wt, pt) * rng.gamma(50, 1 / 50, n)
+        s_vh = gmf.GMFS["gmf_s1_v2"][0](np.clip(inc, 17, 65), np.maximum(wt, 3.0)) * rng.gamma(50, 1 / 50, n)
+        anc = wt * np.exp(1j * np.deg2rad(pt)) + rng.normal(0, 3, n) + 1j * rng.normal(0, 3, n)
+        dsig = 10 ** rng.uniform(-3, 1, n)
+        for arr, vals in ((inc, [np.nan]), (s_vv, [np.nan, 0.0, np.inf, -1.0]), (s_vh, [np.nan, 0.0]),
+                          (dsig, [np.nan, 0.0, np.inf])):
+            k = rng.integers(0, n, max(1, n // 20))
+            arr[k] = rng.choice(vals, len(k))
+        anc[rng.integers(0, n, max(1, n // 25))] = complex(np.nan, 0)
+        anc[rng.integers(0, n, max(1, n // 25))] = 0j
+        cdt = np.complex64 if dt == np.float32 else np.complex128
+        inc, s_vv, s_vh, dsig = (a.reshape(shape).astype(dt) for a in (inc, s_vv, s_vh, dsig))
+        anc = anc.reshape(shape).astype(cdt)
+        dsig_co = float(rng.choice([0.1, 0.05, 0.37, 2.0]))
+        p = oinv.Prepared(lco, lcr, dsig_co)
+        with np.errstate(all="ignore"):
+            sco, scr = oinv.to_db(s_vv), oinv.to_db(s_vh)
+        o = oinv.invert_numpy(p, inc, sco, scr, dsig, anc, return_idx=True)
+        for algo in ALGOS_ALL:
+            got = gpu_ctx.invert_host(inc, sigma0_co=sco, sigma0_cr=scr, dsig_cr=dsig, anc=anc, dsig_co=dsig_co,
+                                      sigma0_is_db=True, algo=algo, want_idx=True)
+            assert np.array_equal(got[2], o[2]), (case, algo, co.shape, shape, dt)
+            assert_complex_close(got[0], o[0], what=f"case {case} {algo} co")
+            assert_complex_close(got[1], o[1], rtol=1e-9, what=f"case {case} {algo} cr")
+        for algo in ("exhaustive", "exhaustive_f64"):
+            got = gpu_ctx.invert_host(inc, sigma0_co=sco, anc=anc, dsig_co=dsig_co, sigma0_is_db=True, algo=algo, want_idx=True)
+            assert np.array_equal(got[2][..., :2], o[2][..., :2]), (case, algo, co.shape, shape, dt)
