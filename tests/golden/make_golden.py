@@ -22,6 +22,7 @@ grid from the reference's scalar GMF is cross-checked against it in gmf_lattice.
 explicit arrays stored inside the fixture.
 
 Usage:  python tests/golden/make_golden.py            (writes tests/golden/*.npz, ~2 min)
+        python tests/golden/make_golden.py phi90_f64  (only the named kernel_small_* fixtures)
 """
 import importlib.util
 import os
@@ -239,13 +240,14 @@ def main():
     models_mod, ws, gmfs = load_reference()
     from oracle import lut as olut
 
+    only = set(sys.argv[1:])
     # ---- G1: scalar GMF lattice from the reference's own scalar functions
     inc_l = np.array([16.0, 20.3, 27.5, 35.0, 40.0, 47.7, 58.2, 66.0])
     wspd_l = np.array([0.2, 1.1, 3.0, 5.7, 10.0, 15.3, 24.9, 37.0, 50.0, 80.0])
     phi_l = np.array([0.0, 12.5, 45.0, 90.0, 133.0, 180.0, 225.0, 270.0, 359.0])
     lattice = {"inc": inc_l, "wspd": wspd_l, "phi": phi_l}
     with np.errstate(all="ignore"):
-        for name, f in gmfs.items():
+        for name, f in (gmfs.items() if not only else ()):
             vals = np.empty((len(inc_l), len(wspd_l), len(phi_l)))
             for i, a in enumerate(inc_l):
                 for j, b in enumerate(wspd_l):
@@ -254,11 +256,12 @@ def main():
             lattice[name] = vals
     # CMOD5.N branch boundaries (s ~ s0 and v2 ~ y0): dense wspd sweep at two incidences
     wd = np.linspace(0.2, 50.0, 499)
-    for tag, a in (("17", 17.0), ("60", 60.0)):
+    for tag, a in ((("17", 17.0), ("60", 60.0)) if not only else ()):
         lattice["cmod5n_sweep_inc" + tag] = np.array([gmfs["gmf_cmod5n"](a, float(w), 37.0) for w in wd])
     lattice["sweep_wspd"] = wd
-    np.savez_compressed(os.path.join(HERE, "gmf_lattice.npz"), **lattice)
-    print("gmf_lattice.npz:", sorted(gmfs))
+    if not only:
+        np.savez_compressed(os.path.join(HERE, "gmf_lattice.npz"), **lattice)
+        print("gmf_lattice.npz:", sorted(gmfs))
 
     # ---- G2: reference-scalar low-res CMOD5.N raw LUT sample + the same for gmf_s1_v2
     rng = np.random.default_rng(20260320)
@@ -268,21 +271,29 @@ def main():
     ii = rng.integers(0, len(inc_lr), 2000)
     jj = rng.integers(0, len(wspd_lr), 2000)
     kk = rng.integers(0, len(phi_lr), 2000)
+    if only:
+        ii = ii[:0]
     samp = np.array([gmfs["gmf_cmod5n"](float(inc_lr[i]), float(wspd_lr[j]), float(phi_lr[k]))
                      for i, j, k in zip(ii, jj, kk)])
     wspd_cr_lr = olut.grid([3.0, 80.0], 0.2)
     jc = rng.integers(0, len(wspd_cr_lr), 2000)
     samp_cr = np.array([gmfs["gmf_s1_v2"](float(inc_lr[i]), float(wspd_cr_lr[j]), None)
                         for i, j in zip(ii, jc)])
-    np.savez_compressed(os.path.join(HERE, "raw_lut_samples.npz"), ii=ii, jj=jj, kk=kk, cmod5n=samp,
-                        jc=jc, s1_v2=samp_cr)
-    print("raw_lut_samples.npz")
+    if not only:
+        np.savez_compressed(os.path.join(HERE, "raw_lut_samples.npz"), ii=ii, jj=jj, kk=kk, cmod5n=samp,
+                            jc=jc, s1_v2=samp_cr)
+        print("raw_lut_samples.npz")
 
     # ---- G-small: self-contained kernel goldens (LUT arrays stored in the fixture)
+    # phi90: the direction axis spans < 178 deg, the only way to reach the reference's phi_180 == False branch
+    # (windspeed.py:152-156 makes every axis of >= 178 deg "symmetrical", a 0..360 one included)
+    only = set(sys.argv[1:])
     for tag, phi_max, dtype in (("phi180_f64", 180.0, np.float64), ("phi360_f64", 360.0, np.float64),
-                                ("phi180_f32", 180.0, np.float32)):
-        rng = np.random.default_rng({"phi180_f64": 11, "phi360_f64": 12, "phi180_f32": 13}[tag])
-        luts = synth_small_lut(rng, n_phi=19 if phi_max == 180.0 else 37, phi_max=phi_max)
+                                ("phi180_f32", 180.0, np.float32), ("phi90_f64", 90.0, np.float64)):
+        if only and tag not in only:
+            continue
+        rng = np.random.default_rng({"phi180_f64": 11, "phi360_f64": 12, "phi180_f32": 13, "phi90_f64": 14}[tag])
+        luts = synth_small_lut(rng, n_phi={180.0: 19, 360.0: 37, 90.0: 10}[phi_max], phi_max=phi_max)
         inc, s_vv, s_vh, dsig_cr, anc = synth_pixels(rng, (24, 40), 18.0, 46.0, dtype)
         out = run_reference(ws, models_mod, luts, inc, s_vv, s_vh, dsig_cr, anc)
         np.savez_compressed(os.path.join(HERE, f"kernel_small_{tag}.npz"),
@@ -290,6 +301,9 @@ def main():
                             lut_phi=luts["phi"], lut_wspd_cr=luts["wspd_cr"],
                             inc=inc, sigma0_vv=s_vv, sigma0_vh=s_vh, dsig_cr=dsig_cr, anc=anc, **out)
         print(f"kernel_small_{tag}.npz")
+
+    if only:
+        return
 
     # ---- G-default: default-resolution LUT (rebuilt at test time by oracle.lut.to_lut), 48x48 px
     lut_co = olut.to_lut("gmf_cmod5n")

@@ -40,7 +40,7 @@ def run_gpu(ctx, d, mode, algo, is_db=False, out_dtype=np.complex128):
     raise ValueError(mode)
 
 
-@pytest.mark.parametrize("tag", ["phi180_f64", "phi360_f64", "phi180_f32"])
+@pytest.mark.parametrize("tag", ["phi180_f64", "phi360_f64", "phi180_f32", "phi90_f64"])
 @pytest.mark.parametrize("algo", ALGOS_ALL + ["exhaustive", "exhaustive_f64"])
 def test_small_goldens(gpu_ctx, tag, algo):
     """Self-contained goldens (LUT stored in the fixture) produced by the reference's kernel body."""

@@ -50,7 +50,7 @@ def test_raw_lut_samples():
     assert np.max(np.abs(v - s["s1_v2"]) / s["s1_v2"]) < 1e-13
 
 
-@pytest.mark.parametrize("tag", ["phi180_f64", "phi360_f64", "phi180_f32"])
+@pytest.mark.parametrize("tag", ["phi180_f64", "phi360_f64", "phi180_f32", "phi90_f64"])
 def test_kernel_small_goldens_bit_exact(tag):
     """numpy restatement == the reference's kernel body, bit for bit, on the self-contained goldens
     (mono co-pol, dual-pol with the <5 m/s select, cross-pol only; NaN / clamp / zero edge cases)."""
@@ -64,6 +64,8 @@ def test_kernel_small_goldens_bit_exact(tag):
     assert bits_equal(r2[0], d["dual_co"]) and bits_equal(r2[1], d["dual_dual"])
     assert bits_equal(r3, d["cross_only"])
     assert np.isnan(r1).sum() >= 3  # the edge cases are really in there
+    from oracle.invert import Prepared
+    assert Prepared(lco, None).phi_180 == (tag != "phi90_f64")  # phi90: the reference's phi_180 == False branch
 
 
 def test_kernel_default_golden_and_c_port(default_luts):
@@ -85,7 +87,7 @@ def test_kernel_default_golden_and_c_port(default_luts):
     assert bits_equal(a[0], d["dual_co"])  # co-pol output bit-identical to the reference's
 
 
-@pytest.mark.parametrize("tag", ["phi180_f64", "phi360_f64"])
+@pytest.mark.parametrize("tag", ["phi180_f64", "phi360_f64", "phi90_f64"])
 def test_c_port_small(tag):
     d = golden(f"kernel_small_{tag}.npz")
     lco, lcr = small_luts(d)
