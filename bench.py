@@ -338,6 +338,27 @@ def main():
         if stats:
             res["valu"]["evaluated_candidates_per_pixel"] = round(stats["cand_co"] / max(stats["pixels_co"], 1), 1)
             res["valu"]["pixels_exact_fallback"] = stats["pixels_exact"]
+        if n_gpus == 1 and args.mode == "mono" and args.algo == "pruned" and not args.no_cpu_baseline:
+            # like-for-like figure: the literal exhaustive sweep (every one of the 90319 candidates scored per pixel,
+            # LUT tiled through LDS, float32 screening + float64 settle) on the first lines of the same raster
+            xl = max(4, min(lines, 2000))
+            ex_alg = _lib.ALGOS["exhaustive"]
+
+            def xstep():
+                ctx.invert_raw(xl, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, inc.data_ptr(), s_vv.data_ptr(),
+                               None, None, anc.data_ptr(), out.data_ptr(), None, algo=ex_alg)
+            xstep()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            xstep()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            xms = e0.elapsed_time(e1)
+            res["exhaustive"] = {"value": round(xl * samples / (xms * 1e-3) / 1e6, 3), "unit": "Mpixels/s",
+                                 "workload": f"first {xl} lines x {samples} samples of the same raster, every candidate scored",
+                                 "kernel": "k_invert_exhaustive32", "kernel_ms": round(xms, 3),
+                                 "Gcand_per_s": round(cand_full * xl * samples / (xms * 1e-3) / 1e9, 1)}
         if n_gpus == 1 and not args.no_cpu_baseline and args.mode == "mono":
             cpu, parity = cpu_baseline_and_parity(ctx, inc, s_vv, anc, args.algo)
             res["cpu_baseline"] = cpu
