@@ -290,9 +290,13 @@ __global__ __launch_bounds__(256) void k_invert_exhaustive32(DevTables L, KArgs 
                     }
                     __syncthreads();
                     const float *colp = lds32 + ipc;
-                    int codev = (r0 << 3) | cc;
                     // rows outermost, the 16 pixels of the batch innermost: one LDS read of the LUT word and one
-                    // broadcast read of the row terms serve 16 candidates
+                    // broadcast read of the row terms serve 16 candidates.  Only (best, second) are tracked per
+                    // candidate (v_med3_f32 + v_min_f32); WHERE the best sits is tracked per (chunk, direction
+                    // chunk) -- "did best improve in here?" -- and the row is recovered afterwards (recover_row).
+                    float prev[XB32];
+#pragma unroll
+                    for (int q = 0; q < XB32; ++q) prev[q] = best[q];
                     for (int r = 0; r < rows; ++r) {
                         const float v = colp[r * L.phi_pad];
                         const float2 rt = row_terms[r];
@@ -300,13 +304,13 @@ __global__ __launch_bounds__(256) void k_invert_exhaustive32(DevTables L, KArgs 
                         for (int q = 0; q < XB32; ++q) {
                             const float dd = fmaf(v, inv32, usn[q]);
                             const float J = fmaf(dd, dd, fmaf(U[q], rt.y, rt.x));   // dd^2 + wh*(wh - U)
-                            // two smallest of {best, second, J}: v_med3_f32 + v_min_f32 (best <= second always)
-                            second[q] = __builtin_amdgcn_fmed3f(best[q], second[q], J);
-                            code[q] = J < best[q] ? codev : code[q];
+                            second[q] = __builtin_amdgcn_fmed3f(best[q], second[q], J);  // two smallest of the three
                             best[q] = vminf(best[q], J);
                         }
-                        codev += 8;
                     }
+                    const int here = (r0 << 3) | cc;
+#pragma unroll
+                    for (int q = 0; q < XB32; ++q) code[q] = best[q] < prev[q] ? here : code[q];
                 }
             }
             // wave-level argmin + uniqueness within the float32 error bound, once per pixel
@@ -325,9 +329,27 @@ __global__ __launch_bounds__(256) void k_invert_exhaustive32(DevTables L, KArgs 
                 const bool amb = !(gmin < inff) || __popcll(win) != 1 || __ballot(second[q] <= Tthr) != 0ULL;
                 const int wl = win ? (__ffsll((long long)win) - 1) : 0;
                 const int c = rd_lane_i(code[q], wl);
+                // recover the winner's row: re-score its column inside the chunk where the best last improved, one
+                // row per lane, with the sweep's arithmetic (same operands, same fused steps => same bits)
+                const int rr0 = c >> 3, wip = (c & 7) * 64 + wl;
+                int row = -1;
+                if (!amb) {
+                    const float Uw = (float)(2.0 * (rd_lane_d(ah, pl[q]) * L.cphi[wip] + rd_lane_d(bh, pl[q]) * L.sphi[wip]));
+                    const float usnq = (float)rd_lane_d(sn, pl[q]);
+                    for (int k0 = 0; k0 < rows_per_chunk && row < 0; k0 += 64) {
+                        const int r = rr0 + k0 + lane;
+                        const bool okr = (k0 + lane) < rows_per_chunk && r < L.n_w;
+                        const int rc = okr ? r : rr0;
+                        const float wh = L.wh32[rc];
+                        const float dd = fmaf(slice[(size_t)rc * L.phi_pad + wip], inv32, usnq);
+                        const float J = fmaf(dd, dd, fmaf(Uw, -wh, wh * wh));
+                        const unsigned long long hit = __ballot(okr && J == gmin);
+                        if (hit) row = rr0 + k0 + (__ffsll((long long)hit) - 1);
+                    }
+                }
                 if (lane == pl[q]) {
-                    my_flat = (c >> 3) * L.n_phi + ((c & 7) * 64 + wl);
-                    need_box = amb && (gmin < inff);
+                    my_flat = (row < 0 ? 0 : row) * L.n_phi + wip;
+                    need_box = (amb || row < 0) && (gmin < inff);
                     need_exact = need_exact || (amb && !(gmin < inff));
                     box_jub = ((double)Tthr + (double)m2q) * (1.0 + 1e-6) + 1e-6;  // upper bound of the true minimum
                 }
