@@ -43,7 +43,8 @@ def _to_db(x):
 
 
 def invert_numpy(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_co=0.1):
-    """(ws_co, ws_cr) complex128 for numpy rasters; any of sigma0_co / sigma0_cr / anc may be None.
+    """(ws_co, ws_cr) complex128 for numpy rasters (None for a search that was not requested); any of
+    sigma0_co / sigma0_cr / anc may be None.
 
     Raster dtypes follow the reference: the dB conversion runs in each sigma0's own dtype, then
     everything is handled as float64/complex128 (the gufunc signature, windspeed.py:308-318).  When
@@ -80,5 +81,4 @@ def invert_numpy(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_c
         dsig_cr=dsig_cr if (dsig_cr is None or np.isscalar(dsig_cr)) else cast(dsig_cr, dt),
         anc=cast(anc, np.complex64 if dt == np.float32 else np.complex128), dsig_co=dsig_co, sigma0_is_db=is_db,
         algo=options.algo, out_dtype=np.complex128)
-    nan_c = lambda: np.full(shape, np.nan * 1j, dtype=np.complex128)
-    return (out_co if out_co is not None else nan_c()), (out_cr if out_cr is not None else nan_c())
+    return out_co, out_cr  # None where that search did not run (the caller never reads it)

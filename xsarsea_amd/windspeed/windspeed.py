@@ -64,13 +64,9 @@ def invert_from_model(inc, sigma0, sigma0_dual=None, /, ancillary_wind=None, dsi
     dual-pol: `(wind_co, wind_dual)`.  The container type follows the inputs.
     """
     t0 = time.time()
-    nan = sigma0 * np.nan
-
     models = model if isinstance(model, tuple) else (model, None)
     models = tuple(get_model(m) if m is not None else None for m in models)
-
-    if ancillary_wind is None:
-        ancillary_wind = nan
+    no_ancillary = ancillary_wind is None  # the reference substitutes an all-NaN array (sigma0 * nan, :71-86)
 
     if sigma0_dual is None:
         try:
@@ -84,10 +80,10 @@ def invert_from_model(inc, sigma0, sigma0_dual=None, /, ancillary_wind=None, dsi
             raise ValueError(f"sigma0 pol is {pol}, and model {models[0].name} can only handle {model_pol}")
         if models[0].iscopol:
             sigma0_co, sigma0_cr = sigma0, None
-            assert np.any(~np.isnan(ancillary_wind)), "co-pol inversion needs a valid ancillary wind"
+            assert not no_ancillary and np.any(~np.isnan(ancillary_wind)), "co-pol inversion needs a valid ancillary wind"
         elif models[0].iscrosspol:
             sigma0_co, sigma0_cr = None, sigma0
-            if not np.all(np.isnan(ancillary_wind)):
+            if not no_ancillary and not np.all(np.isnan(ancillary_wind)):
                 warnings.warn("crosspol inversion is best without ancillary wind, but using it as requested.")
             models = (None, models[0])
     else:
@@ -103,7 +99,7 @@ def invert_from_model(inc, sigma0, sigma0_dual=None, /, ancillary_wind=None, dsi
 
     # cross-pol search disabled for every pixel when all cross sigma0 are NaN (:170) is implicit: NaN pixels skip it
     template = next((v for v in (sigma0, inc, sigma0_dual, ancillary_wind) if _is_xr(v)), None)
-    args = (inc, sigma0_co, sigma0_cr, dsig_cr, ancillary_wind if ancillary_wind is not nan else None)
+    args = (inc, sigma0_co, sigma0_cr, dsig_cr, None if no_ancillary else ancillary_wind)
 
     if any(_is_dask(v) for v in args if v is not None and not np.isscalar(v)):
         # dask in -> lazy dask out, one device call per row block (core dimension = last axis, :356-364)
@@ -116,7 +112,9 @@ def invert_from_model(inc, sigma0, sigma0_dual=None, /, ancillary_wind=None, dsi
             for i, v in enumerate(full):
                 if i not in present and v is not None and not np.isscalar(v):
                     full[i] = np.asarray(v)
-            return _numpy(*full)
+            co_b, cr_b = _numpy(*full)
+            nan_c = lambda: np.full(np.shape(full[0]), np.nan * 1j, dtype=np.complex128)
+            return (co_b if co_b is not None else nan_c()), (cr_b if cr_b is not None else nan_c())
 
         ws_co, ws_cr = da.apply_gufunc(_block, ",".join(["(n)"] * len(present)) + "->(n),(n)",
                                        *[getattr(args[i], "data", args[i]) for i in present],
@@ -126,6 +124,8 @@ def invert_from_model(inc, sigma0, sigma0_dual=None, /, ancillary_wind=None, dsi
 
     if template is not None:
         def wrap(values):
+            if values is None:
+                return None
             out = xr.zeros_like(template, dtype=np.complex128)
             out.data = values
             out.name = "windspeed_gmf"
