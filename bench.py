@@ -197,7 +197,9 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
+    import xsarsea_amd
     from xsarsea_amd import _lib
+    xsarsea_amd.options.device = local_rank  # one process per GPU: LUT preparation also runs on this rank's device
     lut, co_dict = build_product_lut()
     ctx = _lib.Context(local_rank)
     stream = torch.cuda.Stream(device=device)  # the kernels, the events and RCCL all use this stream
