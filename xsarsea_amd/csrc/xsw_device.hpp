@@ -1,12 +1,14 @@
 // Device code of libxsw: per-pixel GMF wind inversion for gfx950 (wave64).
 //
 // Work decomposition:
-//   * one wavefront owns a strip of 64 consecutive pixels; lane i loads pixel i (coalesced),
-//     converts sigma0 to dB and finds its incidence bin;
-//   * the wave then walks its pixels one at a time with the pixel's parameters held wave-uniform
-//     (readlane -> SGPRs); the 64 lanes sweep that pixel's candidates and a wave-level argmin
-//     reduction picks the winner; lane i keeps the winner of pixel i;
-//   * lane i finally forms pixel i's complex winds and stores them (coalesced).
+//   * a workgroup (4 waves) owns a raster tile of 4 lines x 64 samples; one wavefront owns a strip of 64
+//     consecutive samples; lane i loads pixel i (coalesced), converts sigma0 to dB, finds its incidence bin;
+//   * PER-LANE stages (64 pixels in flight, wave-uniform trip counts, nothing diverges): upper bound of the
+//     cost along the a-priori direction and the search window it implies (co_window_lanes), the whole
+//     cross-pol search (search_cr_lanes), forming and storing the complex winds (store_pixel);
+//   * COOPERATIVE stage (co_box_search): the wave walks its pixels one at a time with the pixel's window and
+//     parameters wave-uniform (readlane -> SGPRs); the 64 lanes sweep the window's candidates and a
+//     wave-level argmin (DPP butterfly) picks the winner; lane i keeps the winner of pixel i.
 //
 // All decisions are taken in float64.  The reference's argmin (windspeed/windspeed.py:220-232) is
 // reproduced exactly: candidates are screened with a cheap fused form, every candidate within a
