@@ -299,6 +299,13 @@ static int upload_cr(xsw_ctx *c, const xsw_lut *l)
     if ((rc = upload(c, c->cr_allocs, wh.data(), nW, &T.wcrh))) return rc;
     T.n_inc_cr = nI; T.n_wcr = nW; T.wcr_pad = wpad;
     T.cr_finite = all_finite(l->db, (size_t)nI * nW) ? 1 : 0;
+    bool mono = T.cr_finite && nW >= 2 && uniform_axis(l->wspd, nW);
+    for (int r = 0; r < nI && mono; ++r)
+        for (int k = 1; k < nW; ++k)
+            if (l->db[(size_t)r * nW + k] < l->db[(size_t)r * nW + k - 1]) { mono = false; break; }
+    T.cr_monotone = mono ? 1 : 0;
+    T.wcr0 = l->wspd[0];
+    T.inv_wcrstep = nW > 1 ? (nW - 1) / (l->wspd[nW - 1] - l->wspd[0]) : 0.0;
     c->have_cr = true;
     return XSW_OK;
 }

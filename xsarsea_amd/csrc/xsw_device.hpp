@@ -42,6 +42,8 @@ struct DevTables {
     const double *cr;    // [n_inc_cr][wcr_pad]
     const double *inc_cr, *wcr, *wcrh;
     int n_inc_cr, n_wcr, wcr_pad, cr_finite;
+    int cr_monotone;   // every row non-decreasing in wind speed and the speed axis uniform: interval pruning allowed
+    double wcr0, inv_wcrstep;
 };
 
 struct KArgs {
@@ -430,6 +432,72 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
     return eI;
 }
 
+// Cross-pol search with exact interval pruning, one pixel per lane.  Precondition (host-checked, cr_monotone):
+// every LUT row is non-decreasing in wind speed and the speed axis is uniform.  J = Jsig + Jwind with both
+// terms >= 0, so for any candidate k0, J_ub = J(k0), no candidate with Jsig > J_ub can be the argmin:
+// |LUT[k] - s| <= |dsig| sqrt(J_ub) is necessary, which on a monotone row is the index interval
+// [lower_bound(s - d), upper_bound(s + d)) -- a handful of candidates when the cross-pol SNR is high.  k0 = the
+// row entries bracketing s and the speed nearest to |wind_co|.  The lanes then sweep their intervals together
+// (trip count = the longest interval in the wave).  Returns false (nothing done) when some lane's interval is
+// long: the caller then runs the full-axis sweep for the whole wave.
+__device__ __forceinline__ int lower_bound_row(const double *__restrict__ row, int n, double x)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (row[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ bool search_cr_interval(const DevTables &L, bool need, int i_inc, double s, double dsig,
+                                                   bool have_co, double aco, int &icr, bool &undecided)
+{
+    const double inf = __builtin_inf();
+    const double inv = 1.0 / dsig;
+    const bool fast = need && L.cr_finite && isfinite(inv) && isfinite(s) && (!have_co || isfinite(aco));
+    const double *__restrict__ row = L.cr + (size_t)(fast ? i_inc : 0) * L.wcr_pad;
+    const double sn = fast ? -s * inv : 0.0, invf = fast ? inv : 0.0;
+    const double f = (fast && have_co) ? 1.0 : 0.0;
+    const double g = (fast && have_co) ? -0.5 * aco : 0.0;
+    const int n = L.n_wcr;
+    auto score = [&](int k) {
+        const double dd = fma(row[k], invf, sn);
+        const double t = fma(L.wcrh[k], f, g);
+        return fma(t, t, dd * dd);
+    };
+    // upper bound from three candidates
+    const double sq = fast ? s : 0.0;
+    const int kb = lower_bound_row(row, n, sq);
+    const int ka = min(max(kb, 0), n - 1), kp = min(max(kb - 1, 0), n - 1);
+    const int kw = min(max((int)rint(((have_co ? aco : 0.0) - L.wcr0) * L.inv_wcrstep), 0), n - 1);
+    double jub = vmin(score(ka), vmin(score(kp), score(have_co ? kw : ka)));
+    jub = jub * (1.0 + 1e-9) + 1e-300;
+    const double d = fabs(fast ? dsig : 1.0) * sqrt(jub) * (1.0 + 1e-9) + 1e-12 * (1.0 + fabs(sq));
+    int lo = max(lower_bound_row(row, n, sq - d) - 1, 0);
+    int hi = min(lower_bound_row(row, n, sq + d * (1.0 + 1e-15) + 1e-300) + 1, n - 1);  // >= upper_bound(s + d)
+    while (hi < n - 1 && row[hi] <= sq + d) ++hi;  // plateau at exactly s + d (never more than a step or two)
+    const int len = fast ? (hi - lo + 1) : 0;
+    if (__ballot(len > 160) != 0ULL) return false;  // a long interval somewhere in the wave: full sweep instead
+    int maxlen = len;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off));
+    double best = inf, second = inf;
+    int code = 0;
+    for (int t = 0; t < maxlen; ++t) {
+        const bool ok = t < len;
+        const int k = ok ? lo + t : lo;
+        double J = score(k);
+        J = ok ? J : inf;
+        second = vmin(second, vmax(J, best));
+        code = J < best ? k : code;
+        best = vmin(best, J);
+    }
+    const double T = best + 1e-9 * (1.0 + fabs(best));
+    icr = code;
+    undecided = need && (!fast || !(best < inf) || second <= T);
+    return true;
+}
+
 // Cross-pol search, one pixel per lane (all 64 pixels of the strip at once).  The speed axis has the same
 // length for every pixel, so the trip count is wave-uniform and nothing diverges; lanes of one incidence
 // bin read the same LUT word (one cache line per wave load).  Each lane sees ALL candidates of its pixel, so
@@ -713,7 +781,11 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTa
         const bool have_co = (P.flags & F_NEED_CO) != 0;  // |wind_co| is never NaN once a co-pol search ran
         const double aco = have_co ? L.abs_co[my_flat] : nan;  // np.abs(wind_co), table [n_w][n_phi]
         bool undecided = need_cr;
-        if (ALGO == 1) search_cr_lanes(L, need_cr, P.i_inc_cr, P.s_cr, P.dsig, have_co, aco, my_icr, undecided);
+        if (ALGO == 1) {
+            bool done = false;
+            if (L.cr_monotone) done = search_cr_interval(L, need_cr, P.i_inc_cr, P.s_cr, P.dsig, have_co, aco, my_icr, undecided);
+            if (!done) search_cr_lanes(L, need_cr, P.i_inc_cr, P.s_cr, P.dsig, have_co, aco, my_icr, undecided);
+        }
         n_cr = (unsigned)__popcll(__ballot(need_cr));
         unsigned long long und = __ballot(undecided);
         while (und) {
