@@ -198,3 +198,33 @@ def test_lut_kwargs_do_not_leak_between_calls():
     m._lut_cache.clear()
     c = m._lut(units="linear", resolution="low")
     assert np.array_equal(a.values, c.values)
+
+
+def test_pickle_lut_directories(tmp_path):
+    """sarwing LUT layout (pickle_luts.py:26-73): sigma.npy transposed w.r.t. the pickled axes, dB, high resolution."""
+    import pickle
+    from xsarsea_amd.windspeed import pickle_luts
+    rng = np.random.default_rng(2)
+    inc, wspd, phi = np.arange(17.0, 50.05, 0.5), np.arange(0.5, 30.05, 0.5), np.arange(0.0, 180.5, 5.0)
+    co = rng.uniform(-30, -5, (len(inc), len(wspd), len(phi)))   # (incidence, wspd, phi) is what to_lut must return
+    d = tmp_path / "GMF_testco"
+    d.mkdir()
+    np.save(d / "sigma.npy", np.transpose(np.transpose(co, (1, 2, 0))))  # file = transpose of (wspd, phi, incidence)
+    pickle.dump(inc, open(d / "incidence_angle.pkl", "wb"))
+    pickle.dump((phi, wspd), open(d / "wind_speed_and_direction.pkl", "wb"))
+    cr = rng.uniform(-35, -15, (len(inc), len(wspd)))
+    d2 = tmp_path / "GMF_testcr"
+    d2.mkdir()
+    np.save(d2 / "sigma.npy", np.transpose(np.transpose(cr, (1, 0))))
+    pickle.dump(inc, open(d2 / "incidence_angle.pkl", "wb"))
+    pickle.dump(wspd, open(d2 / "wind_speed.pkl", "wb"))
+    pickle_luts.register_pickle_luts(str(tmp_path))
+    mco, mcr = windspeed.get_model("sarwing_lut__testco"), windspeed.get_model("sarwing_lut__testcr")
+    assert mco.pol == "VV" and mcr.pol == "VH" and windspeed.get_model("testco") is mco
+    lco = mco._lut(units="dB")
+    assert lco.dims == ("incidence", "wspd", "phi") and np.array_equal(lco.values, co)
+    assert mco.phi_range == [0.0, 180.0] and mco.wspd_step == 0.5 and mco.inc_range == [17.0, 50.0]
+    lcr = mcr._lut(units="dB")
+    assert np.array_equal(lcr.values, cr) and lcr.phi is None
+    lin = mcr._lut(units="linear")
+    assert np.allclose(lin.values, 10 ** (cr / 10))
