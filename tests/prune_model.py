@@ -10,8 +10,10 @@ observed sigma0 in dB, c = w*(cos phi, sin phi) a candidate and L its LUT value:
 
     J(c) = |c - m|^2 / 4 + ((L - s)/dsig)^2          (windspeed.py:220-225)
 
-1. Upper bound: evaluate J along the ray phi_r nearest to the direction of m, over at most 256 wind
-   speeds centred on |m| (any subset of candidates bounds the minimum from above).  J_ub = min.
+1. Upper bound: along the ray phi_r nearest to the direction of m, J is (nearly always) unimodal in the
+   speed: bisect on the sign of its discrete slope over aligned row pairs; J_ub = the smallest score seen
+   (any subset of candidates bounds the minimum from above; a column that is not unimodal only loosens
+   the bound).
 2. Since both terms are >= 0, a candidate with |c - m|^2/4 > J_ub cannot be the argmin: only the
    disc |c - m| <= R = 2*sqrt(J_ub) matters.  Its polar bounding box is
    w in [|m|-R, |m|+R],  phi in [theta - asin(R/|m|), theta + asin(R/|m|)]  (all phi if R >= |m|).
@@ -79,11 +81,21 @@ def pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig):
     ipr = int(np.clip(np.rint((theta - phi0) * inv_dphi), 0, n_phi - 1))
     wh = 0.5 * wspd
     ur = 2.0 * (ah * cphi[ipr] + bh * sphi[ipr])
-    nray = min(n_w, 256)
-    r_lo = min(max(int((mag - w0) * inv_wstep) - nray // 2, 0), n_w - nray)
-    dd = slice_wp[r_lo:r_lo + nray, ipr] * inv + sn
-    ray = wh[r_lo:r_lo + nray] * (wh[r_lo:r_lo + nray] - ur) + dd * dd
-    j_ub = ray.min() + m2
+    npairs = (n_w + 1) >> 1
+    lo, hi, rbest, nray = 0, npairs, np.inf, 0
+    col = slice_wp[:, ipr]
+    for _ in range(int(npairs).bit_length()):  # the kernel's fixed trip count
+        mid = min((lo + hi) >> 1, npairs - 1)
+        ja = wh[2 * mid] * (wh[2 * mid] - ur) + (col[2 * mid] * inv + sn) ** 2
+        jb = wh[2 * mid + 1] * (wh[2 * mid + 1] - ur) + (col[2 * mid + 1] * inv + sn) ** 2 if 2 * mid + 1 < n_w else np.inf
+        rbest = min(rbest, ja, jb)
+        nray += 2
+        if lo < hi:
+            if jb < ja:
+                lo = mid + 1
+            else:
+                hi = mid
+    j_ub = rbest + m2
     w_lo, w_hi, ip_lo, ip_hi = search_window(mag, theta, j_ub, w0, inv_wstep, n_w, phi0, phi[-1], inv_dphi, n_phi)
     u = 2.0 * (ah * cphi[ip_lo:ip_hi + 1] + bh * sphi[ip_lo:ip_hi + 1])
     whb = wh[w_lo:w_hi + 1, None]

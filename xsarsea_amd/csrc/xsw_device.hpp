@@ -254,8 +254,8 @@ struct Pixel {
 // Branch-and-bound co-pol search (tests/prune_model.py is the executable specification), in two stages.
 //
 // Stage 1, `co_window_lanes`: ONE PIXEL PER LANE (64 pixels at once, wave-uniform trip count).  Upper bound
-// J_ub = min of the score along the direction nearest to the ancillary wind over <= 256 speeds centred on
-// |ancillary| (transposed slice: each lane streams a contiguous run), then the polar bounding box of the disc
+// J_ub = the minimum of the score along the direction nearest to the ancillary wind, found by bisection on the
+// slope of J along that LUT column (transposed slice: a column is contiguous), then the polar bounding box of the disc
 // |c - m| <= 2 sqrt(J_ub) in index space, one grid step of slack on every side.  float32 is ample for the box:
 // every rounding is covered by the 1e-3 inflation of R plus that slack; huge ancillary winds, where float32
 // could not resolve a grid step, take the whole axis.
@@ -301,34 +301,27 @@ __device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pi
     const double mag = fin ? P.mag : 0.0, theta = fin ? P.theta : 0.0;
     const double ah = 0.5 * a, bh = 0.5 * b, m2 = ah * ah + bh * bh, sn = -s * inv_dsig;
     const double wh0 = 0.5 * L.w0, whs = 0.5 / L.inv_wstep;
-    const int nray = min(L.n_w, 256);  // wave-uniform
-    const int r_lo = min(max((int)((mag - L.w0) * L.inv_wstep) - nray / 2, 0), L.n_w - nray);
     const int ipr = fin ? P.ipr : 0;
     const double ur = 2.0 * (ah * L.cphi[ipr] + bh * L.sphi[ipr]);
-    const double *__restrict__ ray = L.coT + ((size_t)(fin ? P.i_inc : 0) * L.n_phi + ipr) * L.w_pad + r_lo;
-    double wh = fma((double)r_lo, whs, wh0);
-    double pw = wh * (wh - ur), dp = whs * (2.0 * wh - ur) + whs * whs;  // p(w) = wh*(wh-U) by forward differences
-    const double ddp = 2.0 * whs * whs;
-    double rb[4] = {inf, inf, inf, inf};  // independent minima: no serial dependency between the four slots
-    int k = 0;
-    for (; k + 4 <= nray; k += 4) {
-        double v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = ray[k + q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const double dd = fma(v[q], inv_dsig, sn);
-            rb[q] = vmin(rb[q], fma(dd, dd, pw));
-            pw += dp;
-            dp += ddp;
-        }
-    }
-    double rbest = vmin(vmin(rb[0], rb[1]), vmin(rb[2], rb[3]));
-    for (; k < nray; ++k) {
-        const double dd = fma(ray[k], inv_dsig, sn);
-        rbest = vmin(rbest, fma(dd, dd, pw));
-        pw += dp;
-        dp += ddp;
+    const double *__restrict__ ray = L.coT + ((size_t)(fin ? P.i_inc : 0) * L.n_phi + ipr) * L.w_pad;
+    // J along the ray is (nearly always) unimodal: a convex wind term plus the squared distance of a monotone
+    // LUT column to the observed sigma0.  Bisect on the sign of its discrete slope, J(2k+1) - J(2k), over aligned
+    // row pairs (one 16-byte load per step); every score seen on the way bounds the minimum from above, so a
+    // column that is not unimodal merely loosens the bound.  For a unimodal column the minimum itself is seen.
+    const int npairs = (L.n_w + 1) >> 1;
+    int lo = 0, hi = npairs;
+    double rbest = inf;
+    for (int it = 32 - __clz(npairs); it > 0; --it) {  // wave-uniform trip count
+        const int mid = min((lo + hi) >> 1, npairs - 1);
+        const double2 v = *(const double2 *)(ray + 2 * mid);  // w_pad is even: the pad row is masked below
+        const double wh_a = fma((double)(2 * mid), whs, wh0), wh_b = wh_a + whs;
+        const double da = fma(v.x, inv_dsig, sn), db = fma(v.y, inv_dsig, sn);
+        const double Ja = fma(da, da, wh_a * (wh_a - ur));
+        const double Jb = (2 * mid + 1 < L.n_w) ? fma(db, db, wh_b * (wh_b - ur)) : inf;
+        const bool open = lo < hi, right = Jb < Ja;
+        rbest = vmin(rbest, vmin(Ja, Jb));
+        lo = (open && right) ? mid + 1 : lo;
+        hi = (open && !right) ? mid : hi;
     }
     const double jub = (rbest + m2) * (1.0 + 1e-9) + 1e-9;
 
@@ -752,7 +745,7 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTa
     unsigned long long todo = __ballot((P.flags & F_NEED_CO) != 0);
     if (use_prune && todo) {
         W = co_window_lanes(L, P, A.inv_dsig_co);
-        cand += (unsigned)__popcll(__ballot((P.flags & F_CO_FINITE) != 0)) * (unsigned)min(L.n_w, 256);
+        cand += (unsigned)__popcll(__ballot((P.flags & F_CO_FINITE) != 0)) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)));
     }
     while (todo) {
         const int p = __ffsll((long long)todo) - 1;
