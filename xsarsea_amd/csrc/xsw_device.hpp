@@ -333,12 +333,22 @@ __device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pi
 // Rows are taken four groups at a time with their loads issued first: the window is rounded up to a multiple
 // of 4*G rows (extra rows are real candidates, scoring them is harmless) and slid down if it would leave the
 // grid, so the main sweep has no per-candidate masking (slack rows after the LUT keep look-ahead loads legal).
+// The screening score carries the row slot of its candidate in the low 16 mantissa bits (a relative
+// perturbation <= 2^-36, far inside the 1e-9 screening budget), so the running minimum knows where it sits and
+// no compare/select pair is spent on the index.  Never tag an infinity (it would become a signalling NaN):
+// excluded lanes / rows score BIG, and pixels are only admitted with |s|, |a|, |b| < 1e100 (no overflow).
 // Returns the flat index iw*n_phi+ip of the reference's argmin.
+__device__ __forceinline__ double tag16(double J, int keep_mask /* 0xffff0000, in a VGPR */, int slot /* uniform */)
+{
+    int lo;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(lo) : "v"(__double2loint(J)), "v"(keep_mask), "s"(slot));
+    return __hiloint2double(__double2hiint(J), lo);
+}
 __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, double s, double a, double b, int w_lo,
                                              int w_hi, int ip_lo, int ip_hi, double dsig, double inv_dsig, int lane,
                                              unsigned &cand, bool &went_exact)
 {
-    const double inf = __builtin_inf();
+    const double inf = __builtin_inf(), BIG = 1e300;
     const double ah = 0.5 * a, bh = 0.5 * b, m2 = ah * ah + bh * bh, sn = -s * inv_dsig;
     const double wh0 = 0.5 * L.w0, whs = 0.5 / L.inv_wstep;
     const int nrows = w_hi - w_lo + 1, ncols = ip_hi - ip_lo + 1;
@@ -365,26 +375,30 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
         if (!mask_rows && w_base + rows_r > L.n_w) w_base = L.n_w - rows_r;
         const double dG = (double)G * whs;
         const double wh = fma((double)(w_base + grp), whs, wh0);
-        double pw = act ? wh * (wh - U) : inf, dp = act ? dG * (2.0 * wh - U) + dG * dG : 0.0;  // inactive lanes: +inf
+        double pw = act ? wh * (wh - U) : BIG, dp = act ? dG * (2.0 * wh - U) + dG * dG : 0.0;  // inactive lanes: BIG
         const double ddp = 2.0 * dG * dG;
-        // wave-uniform slice base (SGPR pair) + 32-bit per-lane byte offsets: no 64-bit address arithmetic
-        const char *__restrict__ sbase = (const char *)slice;
-        unsigned off = (unsigned)(((w_base + grp) * L.phi_pad + ip) * 8);
+        // wave-uniform row bases (SGPR pairs), one per look-ahead slot, + one 32-bit per-lane byte offset
         const unsigned pstepB = (unsigned)(G * L.phi_pad * 8);
-        int code = -1;  // iteration slot of this lane's best within the chunk
+        const char *__restrict__ sb0 = (const char *)slice, *__restrict__ sb1 = sb0 + pstepB,
+                   *__restrict__ sb2 = sb1 + pstepB, *__restrict__ sb3 = sb2 + pstepB;
+        unsigned off = (unsigned)(((w_base + grp) * L.phi_pad + ip) * 8);
+        const double before = best;
+        int keep_mask;
+        asm volatile("v_mov_b32 %0, 0xffff0000" : "=v"(keep_mask));  // kept in a VGPR: VOP3 takes no literal
         auto sweep = [&](auto masked) {
             for (int r0 = 0; r0 < rows_r; r0 += step) {
                 double v[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = *(const double *)(sbase + (off + (unsigned)k * pstepB));
+                v[0] = *(const double *)(sb0 + off);
+                v[1] = *(const double *)(sb1 + off);
+                v[2] = *(const double *)(sb2 + off);
+                v[3] = *(const double *)(sb3 + off);
                 off += 4u * pstepB;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const double dd = fma(v[k], inv_dsig, sn);
-                    double J = fma(dd, dd, pw);
-                    if (masked.value) J = (w_base + r0 + k * G + grp) < L.n_w ? J : inf;
+                    double J = tag16(fma(dd, dd, pw), keep_mask, r0 + k * G);  // the score carries its row slot
+                    if (masked.value) J = (w_base + r0 + k * G + grp) < L.n_w ? J : BIG;
                     second = vmin(second, vmax(J, best));
-                    code = J < best ? (r0 + k * G) : code;
                     best = vmin(best, J);
                     pw += dp;
                     dp += ddp;
@@ -392,7 +406,7 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
             }
         };
         if (mask_rows) sweep(std::true_type{}); else sweep(std::false_type{});
-        if (code >= 0) bidx = ((w_base + code + grp) << 16) | ip;
+        if (best < before) bidx = ((w_base + (__double2loint(best) & 0xffff) + grp) << 16) | ip;
     }
 
     // settle: a unique candidate within eps of the screening minimum IS the reference's argmin; several (in
@@ -400,7 +414,7 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
     // go to the exact full scan.
     const double gmin = wave_min_d(best);
     const double T = gmin + 1e-9 * (1.0 + fabs(gmin) + m2);
-    if (__ballot(second <= T) != 0ULL || !(gmin < inf)) {
+    if (__ballot(second <= T) != 0ULL || !(gmin < 0.5 * BIG)) {
         went_exact = true;
         return exact_scan_co(L, i_inc, s, a, b, dsig, lane);
     }
@@ -627,7 +641,7 @@ __device__ __forceinline__ void load_pixel(const DevTables &L, const KArgs &A, l
             if (P.s_co == P.s_co) {
                 P.flags |= F_NEED_CO;
                 P.i_inc = nearest_index(L.inc, L.n_inc, inc);
-                if (isfinite(P.s_co) && isfinite(P.a_re) && isfinite(P.a_im)) P.flags |= F_CO_FINITE;
+                if (fabs(P.s_co) < 1e100 && fabs(P.a_re) < 1e100 && fabs(P.a_im) < 1e100) P.flags |= F_CO_FINITE;  // NaN/inf/absurd: exact scan
             }
             if (P.s_cr == P.s_cr && P.dsig == P.dsig) {
                 P.flags |= F_NEED_CR;
