@@ -16,7 +16,8 @@ observed sigma0 in dB, c = w*(cos phi, sin phi) a candidate and L its LUT value:
    the bound).
 2. Since both terms are >= 0, a candidate with |c - m|^2/4 > J_ub cannot be the argmin: only the
    disc |c - m| <= R = 2*sqrt(J_ub) matters.  Its polar bounding box is
-   w in [|m|-R, |m|+R],  phi in [theta - asin(R/|m|), theta + asin(R/|m|)]  (all phi if R >= |m|).
+   w in [|m|-R, |m|+R],  phi in [theta - asin(R/|m|), theta + asin(R/|m|)]  (all phi if R >= |m|),
+   taken in index space with ceil/floor and 1e-5 index units of slack.
 3. Every candidate in the box is scored with a cheap float64 screening form
    J_s = wh*(wh - U_phi) + ((L*inv) + sn)^2 (+ const), wh = w/2, U_phi = a*cos + b*sin.
 4. Candidates within eps of the screening minimum are re-evaluated in the reference's exact
@@ -31,26 +32,29 @@ def screening_eps(gmin, m2):
 
 def search_window(mag, theta_deg, j_ub, w0, inv_wstep, n_w, phi0, phi_last, inv_dphi, n_phi):
     """Index box [w_lo, w_hi] x [ip_lo, ip_hi] guaranteed to contain every candidate with
-    |c - m|^2/4 <= j_ub (uniform axes; one index of slack on every side).  theta_deg is the
-    direction of m normalised into [phi0, phi0 + 360)."""
+    |c - m|^2/4 <= j_ub (uniform axes).  Float64; MRG index units of slack cover the 1e-6-of-a-step
+    axis tolerance, the 1e-12 trig tables and the arithmetic.  theta_deg is the direction of m
+    normalised into [phi0, phi0 + 360)."""
+    MRG = 1e-5
     j_ub = j_ub * (1.0 + 1e-9) + 1e-9
-    R = float(np.float32(2.0) * np.sqrt(np.float32(j_ub)) * np.float32(1.001) + np.float32(1e-3))  # kernel: float32
-    lo = np.floor(np.clip((mag - R - w0) * inv_wstep, -4.0, n_w + 4.0)) - 1
-    hi = np.ceil(np.clip((mag + R - w0) * inv_wstep, -4.0, n_w + 4.0)) + 1
-    w_lo = int(max(lo, 0))
-    w_hi = int(min(hi, n_w - 1))
-    if not (mag < 1e4 and R < 1e4):
+    R = 2.0 * np.sqrt(j_ub) * (1.0 + 1e-9) + 1e-9
+    if not (mag < 1e6 and R < 1e6):
         return 0, n_w - 1, 0, n_phi - 1
-    if not (R < mag * 0.9999):
+    xl, xh = (mag - R - w0) * inv_wstep, (mag + R - w0) * inv_wstep
+    w_lo = int(max(np.ceil(np.clip(xl - MRG - 1e-9 * abs(xl), -4.0, n_w + 4.0)), 0))
+    w_hi = int(min(np.floor(np.clip(xh + MRG + 1e-9 * abs(xh), -4.0, n_w + 4.0)), n_w - 1))
+    if not (R < mag * (1.0 - 1e-9)):
         return w_lo, w_hi, 0, n_phi - 1  # the disc contains the origin: every direction
-    half = np.degrees(np.arcsin(R / mag)) + 0.01
-    plo = np.floor((theta_deg - half - phi0) * inv_dphi) - 1
-    phi_hi = np.ceil((theta_deg + half - phi0) * inv_dphi) + 1
+    half = np.degrees(np.arcsin(R / mag)) + 1e-7
+    yl, yh = (theta_deg - half - phi0) * inv_dphi, (theta_deg + half - phi0) * inv_dphi
+    yl, yh = yl - MRG - 1e-9 * abs(yl), yh + MRG + 1e-9 * abs(yh)
+    plo = np.ceil(np.clip(yl, -4.0, n_phi + 4.0))
+    phi_hi = np.floor(np.clip(yh, -4.0, n_phi + 4.0))
     if phi_last - theta_deg <= 179.9 and theta_deg - phi0 <= 179.9:
         # no axis direction is more than 180 deg from theta: |phi - theta| is the true angular
         # distance, so directions outside the window are outside the disc -> clamp to the axis
         return w_lo, w_hi, int(max(plo, 0)), int(min(phi_hi, n_phi - 1))
-    if plo >= 0 and phi_hi <= n_phi - 1:
+    if yl >= 0 and yh <= n_phi - 1:  # the whole (unrounded) window lies on the axis: no seam inside
         return w_lo, w_hi, int(plo), int(phi_hi)
     return w_lo, w_hi, 0, n_phi - 1  # window crosses the axis seam: take every direction
 

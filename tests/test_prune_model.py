@@ -33,3 +33,36 @@ def test_window_contains_argmin(phimax, nphi):
         assert (r[0], r[1]) == (idx[i, 0], idx[i, 1]), (i, r, idx[i])
         evaluated.append(r[2])
     assert np.mean(evaluated) < 0.7 * len(w_ax) * nphi
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_search_window_contains_disc(seed):
+    """Every grid candidate inside the disc |c - m| <= 2 sqrt(j_ub) lies inside the index box -- also when
+    the disc boundary passes exactly through grid points (mag, R multiples of the steps)."""
+    rng = np.random.default_rng(seed)
+    for case in range(300):
+        n_w, n_phi = int(rng.integers(2, 60)), int(rng.integers(2, 90))
+        w0, wstep = rng.choice([0.2, 0.5, 3.0]), rng.choice([0.1, 0.25, 1.0])
+        phi0 = rng.choice([0.0, 0.0, -180.0, 10.0])
+        span = rng.choice([180.0, 360.0, 90.0, 170.0, 359.0])
+        w_ax = w0 + wstep * np.arange(n_w)
+        phi_ax = np.linspace(phi0, phi0 + span, n_phi)
+        inv_wstep, inv_dphi = (n_w - 1) / (w_ax[-1] - w_ax[0]), (n_phi - 1) / (phi_ax[-1] - phi_ax[0])
+        if case % 3 == 0:  # boundary through grid points
+            mag = w_ax[rng.integers(0, n_w)]
+            R = wstep * rng.integers(0, 12)
+            theta = phi_ax[rng.integers(0, n_phi)]
+        else:
+            mag, R, theta = rng.uniform(0, 1.3 * w_ax[-1]), rng.uniform(0, 8) ** 2 / 8, rng.uniform(phi0, phi0 + 360)
+        if theta < phi0:
+            theta += 360.0
+        j_ub = (R / 2) ** 2
+        a, b = mag * np.cos(np.radians(theta)), mag * np.sin(np.radians(theta))
+        w_lo, w_hi, ip_lo, ip_hi = pm.search_window(mag, theta, j_ub, w0, inv_wstep, n_w, phi0, phi_ax[-1], inv_dphi, n_phi)
+        cx = w_ax[:, None] * np.cos(np.radians(phi_ax))[None, :]
+        cy = w_ax[:, None] * np.sin(np.radians(phi_ax))[None, :]
+        inside = ((cx - a) ** 2 + (cy - b) ** 2) / 4 <= j_ub
+        iw, ip = np.nonzero(inside)
+        if iw.size:
+            assert w_lo <= iw.min() and iw.max() <= w_hi, (case, mag, R, theta, w_lo, w_hi, iw.min(), iw.max())
+            assert ip_lo <= ip.min() and ip.max() <= ip_hi, (case, mag, R, theta, ip_lo, ip_hi, ip.min(), ip.max())

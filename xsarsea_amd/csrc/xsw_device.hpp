@@ -256,35 +256,38 @@ struct Pixel {
 // Stage 1, `co_window_lanes`: ONE PIXEL PER LANE (64 pixels at once, wave-uniform trip count).  Upper bound
 // J_ub = the minimum of the score along the direction nearest to the ancillary wind, found by bisection on the
 // slope of J along that LUT column (transposed slice: a column is contiguous), then the polar bounding box of the disc
-// |c - m| <= 2 sqrt(J_ub) in index space, one grid step of slack on every side.  float32 is ample for the box:
-// every rounding is covered by the 1e-3 inflation of R plus that slack; huge ancillary winds, where float32
-// could not resolve a grid step, take the whole axis.
+// |c - m| <= 2 sqrt(J_ub) in index space (box_from_jub).
 struct CoWindow {
     int w_lo, w_hi, ip_lo, ip_hi;
 };
 // Polar bounding box (index space) of the disc |c - m| <= 2 sqrt(jub) around the ancillary wind m = mag*e^{i theta}:
-// every candidate whose wind term alone is <= jub lies inside.  float32 is ample: every rounding is covered by
-// the 1e-3 inflation of R plus one grid step of slack on every side; huge ancillary winds, where float32 could
-// not resolve a grid step, take the whole axis.
+// every candidate whose wind term alone is <= jub lies inside (|c - m| >= | |c| - |m| | for the speeds;
+// a point of the disc is at most asin(R/|m|) away from theta in direction).  Float64 throughout, so the only
+// slack needed is MRG index units: the axes are uniform to 1e-6 of a step (host-checked), the trig tables
+// good to 1e-12, R is inflated by 1e-9, and the arithmetic errs by ~1e-13 -- all far below 1e-5.  One pixel per
+// lane: the cost of the double asin is shared by 64 pixels.
 __device__ __forceinline__ CoWindow box_from_jub(const DevTables &L, double mag, double theta, double jub)
 {
     CoWindow W;
     W.w_lo = 0; W.w_hi = L.n_w - 1; W.ip_lo = 0; W.ip_hi = L.n_phi - 1;
-    const float Rf = 2.0f * sqrtf((float)jub) * 1.001f + 1e-3f;
-    const float magf = (float)mag, thf = (float)theta;
-    const float nwf = (float)L.n_w, w0f = (float)L.w0, iwsf = (float)L.inv_wstep;
-    if (magf < 1e4f && Rf < 1e4f) {
-        W.w_lo = max((int)floorf(fminf(fmaxf((magf - Rf - w0f) * iwsf, -4.0f), nwf + 4.0f)) - 1, 0);
-        W.w_hi = min((int)ceilf(fminf(fmaxf((magf + Rf - w0f) * iwsf, -4.0f), nwf + 4.0f)) + 1, L.n_w - 1);
-        if (Rf < magf * 0.9999f) {
-            const float half = asinf(Rf / magf) * 57.29578f + 0.01f;
-            const float npf = (float)L.n_phi, p0f = (float)L.phi0, idpf = (float)L.inv_dphi;
-            const int plo = (int)floorf(fminf(fmaxf((thf - half - p0f) * idpf, -4.0f), npf + 4.0f)) - 1;
-            const int phi_i = (int)ceilf(fminf(fmaxf((thf + half - p0f) * idpf, -4.0f), npf + 4.0f)) + 1;
-            if ((float)L.phi_last - thf <= 179.9f && thf - p0f <= 179.9f) {
+    const double MRG = 1e-5;
+    const double R = 2.0 * sqrt(jub) * (1.0 + 1e-9) + 1e-9;
+    if (mag < 1e6 && R < 1e6) {
+        const double nw = (double)L.n_w, np_ = (double)L.n_phi;
+        const double xl = (mag - R - L.w0) * L.inv_wstep, xh = (mag + R - L.w0) * L.inv_wstep;
+        W.w_lo = max((int)ceil(fmin(fmax(xl - MRG - 1e-9 * fabs(xl), -4.0), nw + 4.0)), 0);
+        W.w_hi = min((int)floor(fmin(fmax(xh + MRG + 1e-9 * fabs(xh), -4.0), nw + 4.0)), L.n_w - 1);
+        if (R < mag * (1.0 - 1e-9)) {
+            const double half = asin(R / mag) * 57.29577951308232 + 1e-7;
+            double yl = (theta - half - L.phi0) * L.inv_dphi, yh = (theta + half - L.phi0) * L.inv_dphi;
+            yl -= MRG + 1e-9 * fabs(yl);
+            yh += MRG + 1e-9 * fabs(yh);
+            const int plo = (int)ceil(fmin(fmax(yl, -4.0), np_ + 4.0));
+            const int phi_i = (int)floor(fmin(fmax(yh, -4.0), np_ + 4.0));
+            if (L.phi_last - theta <= 179.9 && theta - L.phi0 <= 179.9) {
                 W.ip_lo = max(plo, 0);
                 W.ip_hi = min(phi_i, L.n_phi - 1);
-            } else if (plo >= 0 && phi_i <= L.n_phi - 1) {
+            } else if (yl >= 0.0 && yh <= np_ - 1.0) {  // the whole (unrounded) window lies on the axis: no seam inside
                 W.ip_lo = plo;
                 W.ip_hi = phi_i;
             }
