@@ -259,7 +259,17 @@ struct Pixel {
 // |c - m| <= 2 sqrt(J_ub) in index space (box_from_jub).
 struct CoWindow {
     int w_lo, w_hi, ip_lo, ip_hi;
+    int geom, mdiv;  // lane layout of the first direction chunk (chunk_geom), precomputed one pixel per lane
 };
+// Lane layout of one direction chunk of `width` (<= 64) columns and `nrows` speed rows: G = 64 / width speed rows
+// side by side (lane = grp * width + col; lanes >= G * width idle), swept two row groups per trip.
+// geom = G | trips << 8;  mdiv = ceil(65536 / width), so that grp = (lane * mdiv) >> 16 exactly for lane < 64.
+__device__ __forceinline__ void chunk_geom(int width, int nrows, int &geom, int &mdiv)
+{
+    const int G = 64 / width, step = 2 * G;
+    geom = G | (((nrows + step - 1) / step) << 8);
+    mdiv = (65536 + width - 1) / width;
+}
 // Polar bounding box (index space) of the disc |c - m| <= 2 sqrt(jub) around the ancillary wind m = mag*e^{i theta}:
 // every candidate whose wind term alone is <= jub lies inside (|c - m| >= | |c| - |m| | for the speeds;
 // a point of the disc is at most asin(R/|m|) away from theta in direction).  Float64 throughout, so the only
@@ -270,6 +280,7 @@ __device__ __forceinline__ CoWindow box_from_jub(const DevTables &L, double mag,
 {
     CoWindow W;
     W.w_lo = 0; W.w_hi = L.n_w - 1; W.ip_lo = 0; W.ip_hi = L.n_phi - 1;
+    W.geom = 0; W.mdiv = 0;
     const double MRG = 1e-5;
     const double R = 2.0 * sqrt(jub) * (1.0 + 1e-9) + 1e-9;
     if (mag < 1e6 && R < 1e6) {
@@ -293,6 +304,7 @@ __device__ __forceinline__ CoWindow box_from_jub(const DevTables &L, double mag,
             }
         }
     }
+    chunk_geom(min(max(W.ip_hi - W.ip_lo + 1, 1), 64), max(W.w_hi - W.w_lo + 1, 1), W.geom, W.mdiv);
     return W;
 }
 
@@ -332,9 +344,9 @@ __device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pi
 }
 
 // Stage 2, `co_box_search`: WAVE-COOPERATIVE, one pixel at a time, every argument wave-uniform (SGPRs).
-// Lanes = directions (<= 64 per chunk); a narrow chunk folds G = 64/W speed rows into one wave iteration.
-// Rows are taken four groups at a time with their loads issued first: the window is rounded up to a multiple
-// of 4*G rows (extra rows are real candidates, scoring them is harmless) and slid down if it would leave the
+// Lanes = directions (<= 64 per chunk); a narrow chunk puts G = 64 / width speed rows side by side (chunk_geom).
+// Rows are taken two groups per trip, the next trip's loads in flight: the window is rounded up to a multiple
+// of 2*G rows (extra rows are real candidates, scoring them is harmless) and slid down if it would leave the
 // grid, so the main sweep has no per-candidate masking (slack rows after the LUT keep look-ahead loads legal).
 // The screening score carries the row slot of its candidate in the low 16 mantissa bits (a relative
 // perturbation <= 2^-36, far inside the 1e-9 screening budget), so the running minimum knows where it sits and
@@ -348,8 +360,8 @@ __device__ __forceinline__ double tag16(double J, int keep_mask /* 0xffff0000, i
     return __hiloint2double(__double2hiint(J), lo);
 }
 __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, double s, double a, double b, int w_lo,
-                                             int w_hi, int ip_lo, int ip_hi, double dsig, double inv_dsig, int lane,
-                                             unsigned &cand, bool &went_exact)
+                                             int w_hi, int ip_lo, int ip_hi, int geom, int mdiv, double dsig,
+                                             double inv_dsig, int lane, unsigned &cand, bool &went_exact)
 {
     const double inf = __builtin_inf(), BIG = 1e300;
     const double ah = 0.5 * a, bh = 0.5 * b, m2 = ah * ah + bh * bh, sn = -s * inv_dsig;
@@ -365,51 +377,51 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
     int bidx = 0;  // (iw << 16) | ip
     for (int c0 = 0; c0 < ncols; c0 += 64) {
         const int width = min(64, ncols - c0);
-        const int sh = (width <= 1) ? 0 : (32 - __clz(width - 1));  // log2(pow2ceil(width))
-        const int G = 64 >> sh;
-        const int col = lane & ((1 << sh) - 1), grp = lane >> sh;
-        const bool act = col < width;
+        if (c0 > 0) chunk_geom(width, nrows, geom, mdiv);  // rare: windows wider than 64 directions
+        const int G = geom & 0xff, trips = geom >> 8;
+        const int grp = (lane * mdiv) >> 16, col = lane - grp * width;
+        const bool act = grp < G;
         const int ip = ip_lo + c0 + (act ? col : 0);
         const double U = 2.0 * (ah * L.cphi[ip] + bh * L.sphi[ip]);
-        const int step = 4 * G;
-        const int rows_r = (nrows + step - 1) & ~(step - 1);  // step = 256 >> sh is a power of two
+        const int step = 2 * G, rows_r = trips * step;
         int w_base = w_lo;
         const bool mask_rows = rows_r > L.n_w;
         if (!mask_rows && w_base + rows_r > L.n_w) w_base = L.n_w - rows_r;
+        const int row0 = w_base + (act ? grp : 0);
         const double dG = (double)G * whs;
-        const double wh = fma((double)(w_base + grp), whs, wh0);
-        double pw = act ? wh * (wh - U) : BIG, dp = act ? dG * (2.0 * wh - U) + dG * dG : 0.0;  // inactive lanes: BIG
+        const double wh = fma((double)row0, whs, wh0);
+        double pw = act ? wh * (wh - U) : BIG, dp = act ? dG * (2.0 * wh - U) + dG * dG : 0.0;  // idle lanes: BIG
         const double ddp = 2.0 * dG * dG;
-        // wave-uniform row bases (SGPR pairs), one per look-ahead slot, + one 32-bit per-lane byte offset
+        // wave-uniform row bases (SGPR pairs) + one 32-bit per-lane byte offset; the loads of the next trip are
+        // issued before the current one is scored (the slack rows after the LUT keep the last look-ahead legal)
         const unsigned pstepB = (unsigned)(G * L.phi_pad * 8);
-        const char *__restrict__ sb0 = (const char *)slice, *__restrict__ sb1 = sb0 + pstepB,
-                   *__restrict__ sb2 = sb1 + pstepB, *__restrict__ sb3 = sb2 + pstepB;
-        unsigned off = (unsigned)(((w_base + grp) * L.phi_pad + ip) * 8);
+        const char *__restrict__ sb0 = (const char *)slice, *__restrict__ sb1 = sb0 + pstepB;
+        unsigned off = (unsigned)((row0 * L.phi_pad + ip) * 8);
         const double before = best;
         int keep_mask;
         asm volatile("v_mov_b32 %0, 0xffff0000" : "=v"(keep_mask));  // kept in a VGPR: VOP3 takes no literal
         auto sweep = [&](auto masked) {
+            double v0 = *(const double *)(sb0 + off), v1 = *(const double *)(sb1 + off);
             for (int r0 = 0; r0 < rows_r; r0 += step) {
-                double v[4];
-                v[0] = *(const double *)(sb0 + off);
-                v[1] = *(const double *)(sb1 + off);
-                v[2] = *(const double *)(sb2 + off);
-                v[3] = *(const double *)(sb3 + off);
-                off += 4u * pstepB;
+                off += 2u * pstepB;
+                const double n0 = *(const double *)(sb0 + off), n1 = *(const double *)(sb1 + off);
+                const double v[2] = {v0, v1};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < 2; ++k) {
                     const double dd = fma(v[k], inv_dsig, sn);
                     double J = tag16(fma(dd, dd, pw), keep_mask, r0 + k * G);  // the score carries its row slot
-                    if (masked.value) J = (w_base + r0 + k * G + grp) < L.n_w ? J : BIG;
+                    if (masked.value) J = (row0 + r0 + k * G) < L.n_w ? J : BIG;
                     second = vmin(second, vmax(J, best));
                     best = vmin(best, J);
                     pw += dp;
                     dp += ddp;
                 }
+                v0 = n0;
+                v1 = n1;
             }
         };
         if (mask_rows) sweep(std::true_type{}); else sweep(std::false_type{});
-        if (best < before) bidx = ((w_base + (__double2loint(best) & 0xffff) + grp) << 16) | ip;
+        if (best < before) bidx = ((row0 + (__double2loint(best) & 0xffff)) << 16) | ip;
     }
 
     // settle: a unique candidate within eps of the screening minimum IS the reference's argmin; several (in
@@ -758,7 +770,7 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTa
     unsigned cand = 0, n_exact = 0, n_co = 0, n_cr = 0;
     const bool use_prune = ALGO == 1 && L.prunable;
     CoWindow W;
-    W.w_lo = W.w_hi = W.ip_lo = W.ip_hi = 0;
+    W.w_lo = W.w_hi = W.ip_lo = W.ip_hi = W.geom = W.mdiv = 0;
     unsigned long long todo = __ballot((P.flags & F_NEED_CO) != 0);
     if (use_prune && todo) {
         W = co_window_lanes(L, P, A.inv_dsig_co);
@@ -774,7 +786,7 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTa
         bool went_exact = false;
         if (use_prune && (uf & F_CO_FINITE))
             flat = co_box_search(L, u_iinc, us, ua, ub, rd_lane_i(W.w_lo, p), rd_lane_i(W.w_hi, p), rd_lane_i(W.ip_lo, p),
-                                 rd_lane_i(W.ip_hi, p), A.dsig_co, A.inv_dsig_co, lane, cand, went_exact);
+                                 rd_lane_i(W.ip_hi, p), rd_lane_i(W.geom, p), rd_lane_i(W.mdiv, p), A.dsig_co, A.inv_dsig_co, lane, cand, went_exact);
         else {
             flat = exact_scan_co(L, u_iinc, us, ua, ub, A.dsig_co, lane);
             went_exact = true;

@@ -371,7 +371,8 @@ __global__ __launch_bounds__(256) void k_invert_exhaustive32(DevTables L, KArgs 
         bool went_exact = false;
         const int flat = co_box_search(L, rd_lane_i(P.i_inc, p), rd_lane_d(P.s_co, p), rd_lane_d(P.a_re, p),
                                        rd_lane_d(P.b_eff, p), rd_lane_i(W.w_lo, p), rd_lane_i(W.w_hi, p),
-                                       rd_lane_i(W.ip_lo, p), rd_lane_i(W.ip_hi, p), A.dsig_co, A.inv_dsig_co, lane,
+                                       rd_lane_i(W.ip_lo, p), rd_lane_i(W.ip_hi, p), rd_lane_i(W.geom, p),
+                                       rd_lane_i(W.mdiv, p), A.dsig_co, A.inv_dsig_co, lane,
                                        cand2, went_exact);
         if (lane == p) my_flat = flat;
         n_box++;
