@@ -23,14 +23,6 @@
 
 namespace xsw {
 
-// Doubles of LDS per workgroup for the shared search window of k_invert (20 KB: four workgroups per CU).
-#ifndef XSW_TILE_DOUBLES
-#define XSW_TILE_DOUBLES 2560
-#endif
-#ifndef PROBE_HOOK
-#define PROBE_HOOK
-#endif
-
 struct DevTables {
     // co-pol LUT, dB
     const double *co;    // [n_inc][n_w][phi_pad]   incidence-major slices (722 KB each at default size)
@@ -154,12 +146,6 @@ __device__ __forceinline__ int wave_min_i(int v)
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
-    return v;
-}
-__device__ __forceinline__ int wave_max_i(int v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
     return v;
 }
 
@@ -367,26 +353,15 @@ __device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pi
 // no compare/select pair is spent on the index.  Never tag an infinity (it would become a signalling NaN):
 // excluded lanes / rows score BIG, and pixels are only admitted with |s|, |a|, |b| < 1e100 (no overflow).
 // Returns the flat index iw*n_phi+ip of the reference's argmin.
-// Speed rows actually swept for a window starting at w_lo with layout `geom`: [w_base, w_base + rows_r).
-__device__ __forceinline__ void sweep_rows(const DevTables &L, int w_lo, int geom, int &w_base, int &rows_r)
-{
-    rows_r = (geom >> 8) * 2 * (geom & 0xff);
-    w_base = w_lo;
-    if (rows_r <= L.n_w && w_base + rows_r > L.n_w) w_base = L.n_w - rows_r;  // slide down instead of masking
-}
 __device__ __forceinline__ double tag16(double J, int keep_mask /* 0xffff0000, in a VGPR */, int slot /* uniform */)
 {
     int lo;
     asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(lo) : "v"(__double2loint(J)), "v"(keep_mask), "s"(slot));
     return __hiloint2double(__double2hiint(J), lo);
 }
-// TILED: the window (one direction chunk, no row masking: the caller checks) is read from an LDS copy
-// tile[(row - t_w0) * t_pitch + (ip - t_ip0)] of the slice shared by the workgroup instead of from L2/L1.
-template <bool TILED = false>
 __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, double s, double a, double b, int w_lo,
                                              int w_hi, int ip_lo, int ip_hi, int geom, int mdiv, double dsig,
-                                             double inv_dsig, int lane, unsigned &cand, bool &went_exact,
-                                             const double *tile = nullptr, int t_w0 = 0, int t_ip0 = 0, int t_pitch = 0)
+                                             double inv_dsig, int lane, unsigned &cand, bool &went_exact)
 {
     const double inf = __builtin_inf(), BIG = 1e300;
     const double ah = 0.5 * a, bh = 0.5 * b, m2 = ah * ah + bh * bh, sn = -s * inv_dsig;
@@ -403,15 +378,15 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
     for (int c0 = 0; c0 < ncols; c0 += 64) {
         const int width = min(64, ncols - c0);
         if (c0 > 0) chunk_geom(width, nrows, geom, mdiv);  // rare: windows wider than 64 directions
-        const int G = geom & 0xff;
+        const int G = geom & 0xff, trips = geom >> 8;
         const int grp = (lane * mdiv) >> 16, col = lane - grp * width;
         const bool act = grp < G;
         const int ip = ip_lo + c0 + (act ? col : 0);
         const double U = 2.0 * (ah * L.cphi[ip] + bh * L.sphi[ip]);
-        const int step = 2 * G;
-        int w_base, rows_r;
-        sweep_rows(L, w_lo, geom, w_base, rows_r);
+        const int step = 2 * G, rows_r = trips * step;
+        int w_base = w_lo;
         const bool mask_rows = rows_r > L.n_w;
+        if (!mask_rows && w_base + rows_r > L.n_w) w_base = L.n_w - rows_r;
         const int row0 = w_base + (act ? grp : 0);
         const double dG = (double)G * whs;
         const double wh = fma((double)row0, whs, wh0);
@@ -445,29 +420,7 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
                 v1 = n1;
             }
         };
-        if (TILED) {
-            const double *p0 = tile + ((row0 - t_w0) * t_pitch + (ip - t_ip0));
-            const int gp = G * t_pitch;
-            double v0 = p0[0], v1 = p0[gp];
-            for (int r0 = 0; r0 < rows_r; r0 += step) {
-                p0 += 2 * gp;
-                double n0 = v0, n1 = v1;
-                if (r0 + step < rows_r) { n0 = p0[0]; n1 = p0[gp]; }  // wave-uniform: next trip in flight
-                const double v[2] = {v0, v1};
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const double dd = fma(v[k], inv_dsig, sn);
-                    const double J = tag16(fma(dd, dd, pw), keep_mask, r0 + k * G);
-                    second = vmin(second, vmax(J, best));
-                    best = vmin(best, J);
-                    pw += dp;
-                    dp += ddp;
-                }
-                v0 = n0;
-                v1 = n1;
-            }
-        } else if (mask_rows) sweep(std::true_type{});
-        else sweep(std::false_type{});
+        if (mask_rows) sweep(std::true_type{}); else sweep(std::false_type{});
         if (best < before) bidx = ((row0 + (__double2loint(best) & 0xffff)) << 16) | ip;
     }
 
@@ -801,12 +754,11 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTa
     const long long cols_per_xcd = (strips_per_line + 7) >> 3;
     const long long xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const long long col = xcd * cols_per_xcd + j / line_groups;
-    const long long line_w = (j % line_groups) * 4 + (threadIdx.x >> 6);
-    if (j / line_groups >= cols_per_xcd || col >= strips_per_line) return;  // workgroup-uniform (barriers below)
-    const long long line = min(line_w, A.lines - 1);
+    const long long line = (j % line_groups) * 4 + (threadIdx.x >> 6);
+    if (j / line_groups >= cols_per_xcd || col >= strips_per_line || line >= A.lines) return;  // wave-uniform
     const long long smp = col * 64 + lane;
-    const bool in = smp < A.samples && line_w < A.lines;
-    const long long i = line * A.samples + min(smp, A.samples - 1);
+    const bool in = smp < A.samples;
+    const long long i = line * A.samples + (in ? smp : A.samples - 1);
     const double nan = __builtin_nan("");
 
     Pixel P;
@@ -820,74 +772,10 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTa
     CoWindow W;
     W.w_lo = W.w_hi = W.ip_lo = W.ip_hi = W.geom = W.mdiv = 0;
     unsigned long long todo = __ballot((P.flags & F_NEED_CO) != 0);
-    if (use_prune) {
-        // The 256 pixels of the workgroup (4 lines x 64 samples) share one or two LUT slices and, the ancillary
-        // wind being smooth, nearly the same window: per slice, the union of their windows is copied ONCE into LDS
-        // and every pixel sweeps from there.
-        __shared__ double tile[XSW_TILE_DOUBLES];
-        __shared__ int sh_bin, sh_box[4];
-        if (todo) {
-            W = co_window_lanes(L, P, A.inv_dsig_co);
-            cand += (unsigned)__popcll(__ballot((P.flags & F_CO_FINITE) != 0)) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)));
-        }
-        int wb = 0, rr = 0;
-        sweep_rows(L, W.w_lo, W.geom, wb, rr);
-        const int ncols_p = W.ip_hi - W.ip_lo + 1;
-        bool pending = (P.flags & F_NEED_CO) && (P.flags & F_CO_FINITE) && ncols_p <= 64 && rr <= L.n_w && rr > 0;
-        if (threadIdx.x == 0) { sh_bin = 0x7fffffff; sh_box[0] = 0x7fffffff; sh_box[1] = 0; sh_box[2] = 0x7fffffff; sh_box[3] = 0; }
-        __syncthreads();
-        for (;;) {
-            const int mb = wave_min_i(pending ? P.i_inc : 0x7fffffff);
-            if (lane == 0 && mb != 0x7fffffff) atomicMin(&sh_bin, mb);
-            __syncthreads();
-            const int cur = sh_bin;
-            if (cur == 0x7fffffff) break;  // workgroup-uniform
-            const bool mine = pending && P.i_inc == cur;
-            {
-                const int r0 = wave_min_i(mine ? wb : 0x7fffffff), r1 = wave_max_i(mine ? wb + rr : 0);
-                const int c0 = wave_min_i(mine ? W.ip_lo : 0x7fffffff), c1 = wave_max_i(mine ? W.ip_hi : 0);
-                if (lane == 0 && r0 != 0x7fffffff) {
-                    atomicMin(&sh_box[0], r0); atomicMax(&sh_box[1], r1);
-                    atomicMin(&sh_box[2], c0); atomicMax(&sh_box[3], c1);
-                }
-            }
-            __syncthreads();
-            const int t_w0 = sh_box[0], t_rows = sh_box[1] - sh_box[0], t_ip0 = sh_box[2], t_cols = sh_box[3] - sh_box[2] + 1;
-            const int t_pitch = t_cols | 1;
-            const bool fits = t_rows * t_pitch <= XSW_TILE_DOUBLES;
-            const double *__restrict__ slice = L.co + (size_t)cur * L.n_w * L.phi_pad;
-            if (fits)
-                for (int r = threadIdx.x >> 6; r < t_rows; r += 4)
-                    for (int c = lane; c < t_cols; c += 64)
-                        tile[r * t_pitch + c] = slice[(size_t)(t_w0 + r) * L.phi_pad + t_ip0 + c];
-            __syncthreads();  // tile ready; everyone has read sh_bin / sh_box
-            if (threadIdx.x == 0) { sh_bin = 0x7fffffff; sh_box[0] = 0x7fffffff; sh_box[1] = 0; sh_box[2] = 0x7fffffff; sh_box[3] = 0; }
-            unsigned long long bin = __ballot(mine);
-            todo &= ~bin;
-            while (bin) {
-                const int p = __ffsll((long long)bin) - 1;
-                bin &= bin - 1;
-                const double us = rd_lane_d(P.s_co, p), ua = rd_lane_d(P.a_re, p), ub = rd_lane_d(P.b_eff, p);
-                bool went_exact = false;
-                int flat;
-                if (fits)
-                    flat = co_box_search<true>(L, cur, us, ua, ub, rd_lane_i(W.w_lo, p), rd_lane_i(W.w_hi, p), rd_lane_i(W.ip_lo, p),
-                                               rd_lane_i(W.ip_hi, p), rd_lane_i(W.geom, p), rd_lane_i(W.mdiv, p), A.dsig_co,
-                                               A.inv_dsig_co, lane, cand, went_exact, tile, t_w0, t_ip0, t_pitch);
-                else
-                    flat = co_box_search<false>(L, cur, us, ua, ub, rd_lane_i(W.w_lo, p), rd_lane_i(W.w_hi, p), rd_lane_i(W.ip_lo, p),
-                                                rd_lane_i(W.ip_hi, p), rd_lane_i(W.geom, p), rd_lane_i(W.mdiv, p), A.dsig_co,
-                                                A.inv_dsig_co, lane, cand, went_exact);
-                n_exact += went_exact ? 1u : 0u;
-                n_co += 1u;
-                PROBE_HOOK
-                if (lane == p) my_flat = flat;
-            }
-            if (mine) pending = false;
-            __syncthreads();  // tile free
-        }
+    if (use_prune && todo) {
+        W = co_window_lanes(L, P, A.inv_dsig_co);
+        cand += (unsigned)__popcll(__ballot((P.flags & F_CO_FINITE) != 0)) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)));
     }
-    // the rest: not finite (exact full scan), windows wider than 64 directions or taller than the axis, ALGO 3
     while (todo) {
         const int p = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
@@ -897,8 +785,8 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTa
         int flat;
         bool went_exact = false;
         if (use_prune && (uf & F_CO_FINITE))
-            flat = co_box_search<false>(L, u_iinc, us, ua, ub, rd_lane_i(W.w_lo, p), rd_lane_i(W.w_hi, p), rd_lane_i(W.ip_lo, p),
-                                        rd_lane_i(W.ip_hi, p), rd_lane_i(W.geom, p), rd_lane_i(W.mdiv, p), A.dsig_co, A.inv_dsig_co, lane, cand, went_exact);
+            flat = co_box_search(L, u_iinc, us, ua, ub, rd_lane_i(W.w_lo, p), rd_lane_i(W.w_hi, p), rd_lane_i(W.ip_lo, p),
+                                 rd_lane_i(W.ip_hi, p), rd_lane_i(W.geom, p), rd_lane_i(W.mdiv, p), A.dsig_co, A.inv_dsig_co, lane, cand, went_exact);
         else {
             flat = exact_scan_co(L, u_iinc, us, ua, ub, A.dsig_co, lane);
             went_exact = true;
