@@ -330,8 +330,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel": {"exhaustive": "k_invert_exhaustive32", "exhaustive_f64": "k_invert_exhaustive"}.get(args.algo, "k_invert"),
                          "kernel_ms": round(kernel_ms, 3), "bytes_per_pixel": bytes_px,
-                         "note": "algorithmic raster bytes (16 B read + 8 B written per pixel) / mean kernel time "
-                                 "(HIP events on the launch stream); the search itself is VALU/L1-bound, see valu"},
+                         "note": f"algorithmic raster bytes ({bytes_px} B read+written per pixel) / mean kernel time "
+                                 "(HIP events on the launch stream); the search itself is VALU-issue bound, see valu"},
         }
         # the honest binding resource: float64 VALU issue
         cand_full = lut.shape[1] * lut.shape[2]
