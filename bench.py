@@ -105,9 +105,10 @@ def make_scene(lines, samples, total_lines, line0, seed, device, chunk=500):
 
 
 # ------------------------------------------------------------------------------------------ helpers
-def build_product_lut():
+def build_product_lut(resolution=None):
     from xsarsea_amd.windspeed import _engine, get_model
-    lut = get_model("gmf_cmod5n")._lut(units="dB")
+    kwargs = {} if resolution in (None, "high") else {"resolution": resolution}
+    lut = get_model("gmf_cmod5n")._lut(units="dB", **kwargs)
     return lut, _engine._co_dict(lut)
 
 
@@ -180,6 +181,9 @@ def main():
     ap.add_argument("--algo", default="pruned", choices=["pruned", "exhaustive", "exhaustive_f64", "exact"])
     ap.add_argument("--mode", default="mono", choices=["mono", "dual"],
                     help="mono: CMOD5.N VV (the metric's workload); dual: + Sentinel-1 VH GMF cross-pol refinement (config 3)")
+    ap.add_argument("--resolution", default="high", choices=["high", "low"],
+                    help="LUT resolution passed to Model.to_lut: high = the reference default 501x499x181, low = 51x250x73 "
+                         "(a parity-test configuration, SURVEY 8d; implies no CPU baseline / exhaustive figure)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stats", action="store_true", help="also report evaluated candidates per pixel (extra pass)")
     args = ap.parse_args()
@@ -200,7 +204,9 @@ def main():
     import xsarsea_amd
     from xsarsea_amd import _lib
     xsarsea_amd.options.device = local_rank  # one process per GPU: LUT preparation also runs on this rank's device
-    lut, co_dict = build_product_lut()
+    lut, co_dict = build_product_lut(args.resolution)
+    if args.resolution != "high":
+        args.no_cpu_baseline = True
     ctx = _lib.Context(local_rank)
     stream = torch.cuda.Stream(device=device)  # the kernels, the events and RCCL all use this stream
     torch.cuda.set_stream(stream)
@@ -312,7 +318,7 @@ def main():
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                key = f"{args.algo}_{lines}x{samples}" if args.mode == "mono" else "-"
+                key = f"{args.algo}_{lines}x{samples}" if (args.mode == "mono" and args.resolution == "high") else "-"
                 traffic = tj.get(key)
             except Exception:
                 traffic = None
@@ -322,7 +328,8 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"CMOD5.N mono-VV inversion, {lines}x{samples} float32 sigma0/incidence + complex64 "
-                                   f"ancillary per GPU, default LUT 501x499x181 (90319 candidates/pixel), "
+                                   f"ancillary per GPU, {'default' if args.resolution == 'high' else 'resolution=low'} LUT "
+                                   f"{'x'.join(str(int(x)) for x in lut.shape)} ({int(lut.shape[1] * lut.shape[2])} candidates/pixel), "
                                    f"complex64 out, algo={args.algo}, mode={args.mode}",
                        "lines_per_gpu": lines, "samples": samples, "lut": [int(x) for x in lut.shape],
                        "parallelism": f"row tiles x{n_gpus}" + (", RCCL gather to rank 0 in the step" if n_gpus > 1 else "")},

@@ -411,3 +411,38 @@ def test_random_configurations(gpu_ctx):
         for algo in ("exhaustive", "exhaustive_f64"):
             got = gpu_ctx.invert_host(inc, sigma0_co=sco, anc=anc, dsig_co=dsig_co, sigma0_is_db=True, algo=algo, want_idx=True)
             assert np.array_equal(got[2][..., :2], o[2][..., :2]), (case, algo, co.shape, shape, dt)
+
+
+def test_random_configurations_large_axes(gpu_ctx):
+    """Windows wider than one 64-direction chunk, taller than the lane layout's trip granularity, clipped at the axis
+    ends and covering whole axes: large direction / speed axes with loose dsig_co and far-off ancillary winds."""
+    from oracle import gmf, lut as olut
+    from oracle import cport
+    from oracle import invert as oinv
+    rng = np.random.default_rng(77)
+    for case in range(24):
+        n_inc, n_w, n_phi = 3, int(rng.integers(60, 500)), int(rng.integers(65, 380))
+        inc_ax = np.linspace(25.0, 40.0, n_inc)
+        w_ax = np.linspace(rng.uniform(0.1, 1.0), rng.uniform(25, 60), n_w)
+        phi_ax = np.linspace(0.0, float(rng.choice([180.0, 360.0])), n_phi)
+        co = 10 * np.log10(gmf.gmf_cmod5n(inc_ax[:, None, None], w_ax[None, :, None], phi_ax[None, None, :]) + 1e-15)
+        co = co + rng.choice([0.0, 0.02]) * rng.standard_normal(co.shape)
+        lco = olut.Lut(co, inc_ax, w_ax, phi_ax, "dB", "x", "co", "VV")
+        c, _ = lut_dicts(lco, None)
+        gpu_ctx.upload_luts(co=c)
+        shape = (3, int(rng.integers(60, 200)))
+        n = shape[0] * shape[1]
+        inc = rng.uniform(24, 41, n)
+        wt, pt = rng.uniform(0.2, 45, n), rng.uniform(-180, 180, n)
+        s_vv = gmf.gmf_cmod5n(inc, wt, pt) * rng.gamma(20, 1 / 20, n)
+        anc = wt * np.exp(1j * np.deg2rad(pt)) + rng.normal(0, 4, n) + 1j * rng.normal(0, 4, n)
+        anc[: n // 4] = rng.uniform(0, 70, n // 4) * np.exp(1j * rng.uniform(-np.pi, np.pi, n // 4))  # far off
+        inc, s_vv = inc.reshape(shape), s_vv.reshape(shape)
+        anc = anc.reshape(shape)
+        dsig_co = float(rng.choice([0.1, 1.0, 5.0]))
+        p = oinv.Prepared(lco, None, dsig_co)
+        sco = oinv.to_db(s_vv)
+        nan = np.full(shape, np.nan)
+        o = cport.invert_numpy(p, inc, sco, nan, nan, anc, return_idx=True, reference_layout=False)
+        got = gpu_ctx.invert_host(inc, sigma0_co=sco, anc=anc, dsig_co=dsig_co, sigma0_is_db=True, algo="pruned", want_idx=True)
+        assert np.array_equal(got[2][..., :2], o[2][..., :2]), (case, co.shape, shape, dsig_co)
