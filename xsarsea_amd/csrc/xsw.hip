@@ -601,7 +601,10 @@ static void launch_detrend(hipStream_t s, const void *in, const double *ratio, c
 {
     const long long quads = (samples + 3) / 4;
     const unsigned gx = (unsigned)((quads + 255) / 256);
-    long long gy = (256LL * 16 + gx - 1) / gx;  // ~16 workgroups per CU
+#ifndef XSW_DETREND_WG_PER_CU
+#define XSW_DETREND_WG_PER_CU 16
+#endif
+    long long gy = (256LL * XSW_DETREND_WG_PER_CU + gx - 1) / gx;  // workgroups per CU
     if (gy > lines) gy = lines;
     if (gy > 65535) gy = 65535;
     if (gy < 1) gy = 1;

@@ -888,9 +888,24 @@ __global__ __launch_bounds__(256) void k_lut_interp(InterpArgs a)
 
 // sigma0_detrend's per-pixel work (detrend.py:64): out = sigma0 / ratio[sample].  Purely HBM-bound:
 // 16-B vector loads/stores (4 samples per thread), the ratio row stays in L2; no integer division per pixel.
+// streaming accesses of k_detrend: every byte is touched once.  Non-temporal hints measured no gain on MI355X
+// (bit 0 = loads, bit 1 = stores: f32->f64 1.00 ms plain / 1.00 ms nt loads / 1.40 ms nt loads+stores), so plain.
+#ifndef XSW_DETREND_NT
+#define XSW_DETREND_NT 0
+#endif
+#if XSW_DETREND_NT & 1
+#define XSW_DETREND_LD(p) __builtin_nontemporal_load(p)
+#else
+#define XSW_DETREND_LD(p) (*(p))
+#endif
+#if XSW_DETREND_NT & 2
+#define XSW_DETREND_ST(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define XSW_DETREND_ST(v, p) (*(p) = (v))
+#endif
 template <typename T, int N> struct VecOf;
-template <> struct VecOf<float, 4> { typedef float4 type; };
-template <> struct VecOf<double, 4> { typedef double4 type; };
+template <> struct VecOf<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct VecOf<double, 4> { typedef double type __attribute__((ext_vector_type(4))); };
 
 // FAST = 1: x / r as q0 = x*y, q = fma(fma(-q0, r, x), y, q0) with y = RN(1/r) prepared on the host: the
 // correctly rounded quotient (Markstein) whenever r is finite, non-zero, within 2^+-500 and its significand is not
@@ -936,13 +951,13 @@ __global__ __launch_bounds__(256) void k_detrend(const T *__restrict__ sigma0, c
         for (; l + 4 <= l1; l += 4) {  // four lines in flight (64 B of loads per lane before the first use)
             vin_t a[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] = in[u * stride];
+            for (int u = 0; u < 4; ++u) a[u] = XSW_DETREND_LD(&in[u * stride]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 vout_t ou;
                 ou.x = (TO)div_by<FAST>((double)a[u].x, r[0], y[0]); ou.y = (TO)div_by<FAST>((double)a[u].y, r[1], y[1]);
                 ou.z = (TO)div_by<FAST>((double)a[u].z, r[2], y[2]); ou.w = (TO)div_by<FAST>((double)a[u].w, r[3], y[3]);
-                o[u * stride] = ou;
+                XSW_DETREND_ST(ou, &o[u * stride]);
             }
             in += 4 * stride; o += 4 * stride;
         }
