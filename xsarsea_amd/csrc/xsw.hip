@@ -265,6 +265,7 @@ static int upload_co(xsw_ctx *c, const xsw_lut *l)
     T.prunable = (nW >= 2 && nP >= 2 && nW < 32768 && nP < 65536 && (int64_t)nW * ppad < ((int64_t)1 << 30) && uniform_axis(l->wspd, nW) && uniform_axis(l->phi, nP) && trig_ok &&
                   (l->phi[nP - 1] - l->phi[0]) <= 360.0 + 1e-9 && all_finite(l->db, (size_t)nI * nW * nP))
                      ? 1 : 0;
+    T.co_off32 = ((uint64_t)nI * nW + 260) * (uint64_t)ppad * 8u < ((uint64_t)1 << 32) ? 1 : 0;
     // transposed slices for the ray scan
     double *dT = nullptr;
     HIPCHK(c, hipMalloc((void **)&dT, (size_t)nI * nP * wpad * sizeof(double) + 512 * sizeof(double)));

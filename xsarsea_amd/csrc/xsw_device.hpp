@@ -37,6 +37,7 @@ struct DevTables {
     int n_inc, n_w, n_phi, phi_pad, w_pad;
     int phi_180;   // windspeed.py:152-156
     int prunable;  // uniform axes, finite LUT: branch-and-bound allowed
+    int co_off32;  // the padded co table is < 4 GB: 32-bit byte offsets from its base address every word
     double w0, inv_wstep, phi0, phi_last, inv_dphi;
     // cross-pol LUT, dB
     const double *cr;    // [n_inc_cr][wcr_pad]
@@ -261,12 +262,15 @@ struct CoWindow {
     int w_lo, w_hi, ip_lo, ip_hi;
     int geom, mdiv;  // lane layout of the first direction chunk (chunk_geom), precomputed one pixel per lane
 };
-// Lane layout of one direction chunk of `width` (<= 64) columns and `nrows` speed rows: G = 64 / width speed rows
-// side by side (lane = grp * width + col; lanes >= G * width idle), swept two row groups per trip.
-// geom = G | trips << 8;  mdiv = ceil(65536 / width), so that grp = (lane * mdiv) >> 16 exactly for lane < 64.
-__device__ __forceinline__ void chunk_geom(int width, int nrows, int &geom, int &mdiv)
+// Lane layout of one direction chunk of `width` (<= S) columns and `nrows` speed rows on a segment of S lanes:
+// G = S / width speed rows side by side (lane = grp * width + col; lanes >= G * width idle), swept two row groups
+// per trip.  geom = G | trips << 8;  mdiv = ceil(65536 / width), so that grp = (lane * mdiv) >> 16 exactly for
+// lane < 64.  A window of <= 16 / <= 32 directions is laid out for a 16- / 32-lane segment (co_seg_pass), wider
+// ones for the whole wave (co_box_search).
+__device__ __forceinline__ int seg_lanes(int width) { return width <= 16 ? 16 : (width <= 32 ? 32 : 64); }
+__device__ __forceinline__ void chunk_geom(int width, int nrows, int S, int &geom, int &mdiv)
 {
-    const int G = 64 / width, step = 2 * G;
+    const int G = S / width, step = 2 * G;
     geom = G | (((nrows + step - 1) / step) << 8);
     mdiv = (65536 + width - 1) / width;
 }
@@ -304,7 +308,10 @@ __device__ __forceinline__ CoWindow box_from_jub(const DevTables &L, double mag,
             }
         }
     }
-    chunk_geom(min(max(W.ip_hi - W.ip_lo + 1, 1), 64), max(W.w_hi - W.w_lo + 1, 1), W.geom, W.mdiv);
+    {
+        const int width = min(max(W.ip_hi - W.ip_lo + 1, 1), 64);
+        chunk_geom(width, max(W.w_hi - W.w_lo + 1, 1), L.co_off32 ? seg_lanes(width) : 64, W.geom, W.mdiv);
+    }
     return W;
 }
 
@@ -361,7 +368,8 @@ __device__ __forceinline__ double tag16(double J, int keep_mask /* 0xffff0000, i
 }
 __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, double s, double a, double b, int w_lo,
                                              int w_hi, int ip_lo, int ip_hi, int geom, int mdiv, double dsig,
-                                             double inv_dsig, int lane, unsigned &cand, bool &went_exact)
+                                             double inv_dsig, int lane, unsigned &cand, bool &went_exact,
+                                             bool relayout = false /* geom was made for a narrower segment */)
 {
     const double inf = __builtin_inf(), BIG = 1e300;
     const double ah = 0.5 * a, bh = 0.5 * b, m2 = ah * ah + bh * bh, sn = -s * inv_dsig;
@@ -377,7 +385,7 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
     int bidx = 0;  // (iw << 16) | ip
     for (int c0 = 0; c0 < ncols; c0 += 64) {
         const int width = min(64, ncols - c0);
-        if (c0 > 0) chunk_geom(width, nrows, geom, mdiv);  // rare: windows wider than 64 directions
+        if (c0 > 0 || relayout) chunk_geom(width, nrows, 64, geom, mdiv);  // rare: wider than 64 directions / re-done pixel
         const int G = geom & 0xff, trips = geom >> 8;
         const int grp = (lane * mdiv) >> 16, col = lane - grp * width;
         const bool act = grp < G;
@@ -452,6 +460,106 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
         }
     }
     return eI;
+}
+
+// Stage 2 for narrow windows, `co_seg_pass<S>`: the wave takes 64/S pixels at a time, one per segment of S lanes
+// (S = 16: windows of <= 16 directions, S = 32: <= 32).  What is wave-uniform in co_box_search is per-lane here,
+// fetched once from the owner lanes (ds_bpermute), so the fixed cost of a pass -- lane layout, U, forward-difference
+// set-up, argmin, settle -- is shared by 4 or 2 pixels.  All segments run the trip count of the longest; a segment
+// that has covered its window keeps scoring the rows that follow (real candidates: harmless), its start slid down
+// so that it never leaves the axis.  Pixels the pass cannot decide (near-ties, several survivors, trip count
+// exceeding the axis) are returned in `redo` for co_box_search.
+template <int S> __device__ __forceinline__ double seg_min_d(double v)
+{
+    v = vmin(v, dpp_d<0xB1, 0xF>(v));   // lane ^ 1
+    v = vmin(v, dpp_d<0x4E, 0xF>(v));   // lane ^ 2
+    v = vmin(v, dpp_d<0x141, 0xF>(v));  // 8-lane halves mirrored
+    v = vmin(v, dpp_d<0x140, 0xF>(v));  // 16-lane rows mirrored: every lane of a row holds the row minimum
+    if (S == 32) v = vmin(v, __shfl_xor(v, 16));
+    return v;
+}
+template <int S>
+__device__ __forceinline__ void co_seg_pass(const DevTables &L, const Pixel &P, const CoWindow &W, double inv_dsig, int lane,
+                                            unsigned long long &pend, int &my_flat, unsigned long long &redo)
+{
+    constexpr int NP = 64 / S;
+    const double BIG = 1e300;
+    int o[NP], t_max = 0;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        o[q] = pend ? (__ffsll((long long)pend) - 1) : -1;
+        if (pend) pend &= pend - 1;
+        if (o[q] >= 0) t_max = max(t_max, rd_lane_i(W.geom, o[q]) >> 8);
+    }
+    const int q = lane / S, sl = lane & (S - 1);
+    int own = o[0];
+#pragma unroll
+    for (int k = 1; k < NP; ++k) own = (q == k) ? o[k] : own;
+    const bool valid = own >= 0;
+    const int src = valid ? own : 0;
+    const double s = __shfl(P.s_co, src), a = __shfl(P.a_re, src), b = __shfl(P.b_eff, src);
+    const int i_inc = __shfl(P.i_inc, src), w_lo = __shfl(W.w_lo, src), ip_lo = __shfl(W.ip_lo, src);
+    const int ncols = __shfl(W.ip_hi - W.ip_lo + 1, src), geom = __shfl(W.geom, src), mdiv = __shfl(W.mdiv, src);
+
+    const double ah = 0.5 * a, bh = 0.5 * b, m2 = ah * ah + bh * bh, sn = -s * inv_dsig;
+    const double wh0 = 0.5 * L.w0, whs = 0.5 / L.inv_wstep;
+    const int G = geom & 0xff;
+    const int grp = (sl * mdiv) >> 16, col = sl - grp * ncols;
+    const int rows_pass = t_max * 2 * G;
+    const bool fits = rows_pass <= L.n_w;
+    const bool act = valid && fits && grp < G;
+    const int w_base = min(w_lo, L.n_w - rows_pass);
+    const int row0 = act ? w_base + grp : 0, ip = act ? ip_lo + col : 0;
+    const double U = 2.0 * (ah * L.cphi[ip] + bh * L.sphi[ip]);
+    const double dG = (double)G * whs;
+    const double wh = fma((double)row0, whs, wh0);
+    double pw = act ? wh * (wh - U) : BIG, dp = act ? dG * (2.0 * wh - U) + dG * dG : 0.0;  // idle lanes: BIG
+    const double ddp = 2.0 * dG * dG;
+    const char *__restrict__ base = (const char *)L.co;
+    const unsigned pstepB = (unsigned)(G * L.phi_pad) * 8u;
+    unsigned off0 = (act ? ((unsigned)(i_inc * L.n_w + row0) * (unsigned)L.phi_pad + (unsigned)ip) : 0u) * 8u;
+    unsigned off1 = off0 + (act ? pstepB : 0u);
+    const unsigned adv = act ? 2u * pstepB : 0u;
+    int keep_mask;
+    asm volatile("v_mov_b32 %0, 0xffff0000" : "=v"(keep_mask));
+    double best = __builtin_inf(), second = __builtin_inf();
+    double v0 = *(const double *)(base + off0), v1 = *(const double *)(base + off1);
+    for (int t = 0; t < t_max; ++t) {
+        off0 += adv;
+        off1 += adv;
+        double n0 = v0, n1 = v1;
+        if (t + 1 < t_max) { n0 = *(const double *)(base + off0); n1 = *(const double *)(base + off1); }  // wave-uniform
+        const double v[2] = {v0, v1};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double dd = fma(v[k], inv_dsig, sn);
+            const double J = tag16(fma(dd, dd, pw), keep_mask, 2 * t + k);  // the score carries its step
+            second = vmin(second, vmax(J, best));
+            best = vmin(best, J);
+            pw += dp;
+            dp += ddp;
+        }
+        v0 = n0;
+        v1 = n1;
+    }
+    const int row = row0 + (__double2loint(best) & 0xffff) * G;
+    const double gmin = seg_min_d<S>(best);
+    const double T = gmin + 1e-9 * (1.0 + fabs(gmin) + m2);
+    const unsigned long long amb = __ballot(act && second <= T), surv = __ballot(act && best <= T);
+    const unsigned long long bad = __ballot(valid && !fits);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        if (o[k] < 0) continue;
+        const unsigned long long bits = (S == 64 ? ~0ULL : ((1ULL << (S & 63)) - 1ULL)) << (k * S);
+        const unsigned long long sv = surv & bits;
+        if ((bad & bits) || (amb & bits) || __popcll(sv) != 1 || !(rd_lane_d(gmin, k * S) < 0.5 * BIG)) {
+            redo |= 1ULL << o[k];
+        } else {
+            const int wl = __ffsll((long long)sv) - 1;
+            const int flat = rd_lane_i(row, wl) * L.n_phi + rd_lane_i(ip, wl);
+            if (lane == o[k]) my_flat = flat;
+        }
+    }
 }
 
 // Cross-pol search with exact interval pruning, one pixel per lane.  Precondition (host-checked, cr_monotone):
@@ -772,9 +880,27 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTa
     CoWindow W;
     W.w_lo = W.w_hi = W.ip_lo = W.ip_hi = W.geom = W.mdiv = 0;
     unsigned long long todo = __ballot((P.flags & F_NEED_CO) != 0);
+    unsigned long long relay = 0;  // pixels laid out for a 16/32-lane segment that co_box_search has to lay out again
     if (use_prune && todo) {
         W = co_window_lanes(L, P, A.inv_dsig_co);
-        cand += (unsigned)__popcll(__ballot((P.flags & F_CO_FINITE) != 0)) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)));
+        const unsigned long long fin_m = __ballot((P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0);
+        cand += (unsigned)__popcll(fin_m) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)));
+        if (L.co_off32) {
+            const int ncols_p = W.ip_hi - W.ip_lo + 1;
+            const bool elig = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0;
+            unsigned long long m16 = __ballot(elig && ncols_p <= 16), m32 = __ballot(elig && ncols_p > 16 && ncols_p <= 32);
+            relay = m16 | m32;
+            if (A.stats) {
+                unsigned c = (elig && ncols_p <= 32) ? (unsigned)((W.w_hi - W.w_lo + 1) * ncols_p) : 0u;
+                for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+                cand += c;
+            }
+            unsigned long long redo = 0;
+            while (m16) co_seg_pass<16>(L, P, W, A.inv_dsig_co, lane, m16, my_flat, redo);
+            while (m32) co_seg_pass<32>(L, P, W, A.inv_dsig_co, lane, m32, my_flat, redo);
+            n_co += (unsigned)__popcll(relay & ~redo);
+            todo = (todo & ~relay) | redo;
+        }
     }
     while (todo) {
         const int p = __ffsll((long long)todo) - 1;
@@ -786,7 +912,8 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTa
         bool went_exact = false;
         if (use_prune && (uf & F_CO_FINITE))
             flat = co_box_search(L, u_iinc, us, ua, ub, rd_lane_i(W.w_lo, p), rd_lane_i(W.w_hi, p), rd_lane_i(W.ip_lo, p),
-                                 rd_lane_i(W.ip_hi, p), rd_lane_i(W.geom, p), rd_lane_i(W.mdiv, p), A.dsig_co, A.inv_dsig_co, lane, cand, went_exact);
+                                 rd_lane_i(W.ip_hi, p), rd_lane_i(W.geom, p), rd_lane_i(W.mdiv, p), A.dsig_co, A.inv_dsig_co, lane, cand, went_exact,
+                                 ((relay >> p) & 1ULL) != 0);
         else {
             flat = exact_scan_co(L, u_iinc, us, ua, ub, A.dsig_co, lane);
             went_exact = true;

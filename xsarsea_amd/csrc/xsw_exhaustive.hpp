@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void k_invert_exhaustive32(DevTables L, KArgs 
                                        rd_lane_d(P.b_eff, p), rd_lane_i(W.w_lo, p), rd_lane_i(W.w_hi, p),
                                        rd_lane_i(W.ip_lo, p), rd_lane_i(W.ip_hi, p), rd_lane_i(W.geom, p),
                                        rd_lane_i(W.mdiv, p), A.dsig_co, A.inv_dsig_co, lane,
-                                       cand2, went_exact);
+                                       cand2, went_exact, true /* W may be laid out for a 16/32-lane segment */);
         if (lane == p) my_flat = flat;
         n_box++;
         n_exact += went_exact ? 1u : 0u;
