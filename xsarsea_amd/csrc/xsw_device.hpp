@@ -267,7 +267,13 @@ struct CoWindow {
 // per trip.  geom = G | trips << 8;  mdiv = ceil(65536 / width), so that grp = (lane * mdiv) >> 16 exactly for
 // lane < 64.  A window of <= 16 / <= 32 directions is laid out for a 16- / 32-lane segment (co_seg_pass), wider
 // ones for the whole wave (co_box_search).
-__device__ __forceinline__ int seg_lanes(int width) { return width <= 16 ? 16 : (width <= 32 ? 32 : 64); }
+// 32-lane segments (two pixels per pass, windows of 17..32 directions) measured slower than the whole-wave layout on the
+// default LUT (234 ms vs 220 ms: G drops from 3 rows side by side to 1); 16-lane segments are a clear gain on narrow
+// windows (resolution="low": 136 -> 110 ms).
+#ifndef XSW_SEG32
+#define XSW_SEG32 0
+#endif
+__device__ __forceinline__ int seg_lanes(int width) { return width <= 16 ? 16 : ((XSW_SEG32 && width <= 32) ? 32 : 64); }
 __device__ __forceinline__ void chunk_geom(int width, int nrows, int S, int &geom, int &mdiv)
 {
     const int G = S / width, step = 2 * G;
@@ -888,10 +894,10 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTa
         if (L.co_off32) {
             const int ncols_p = W.ip_hi - W.ip_lo + 1;
             const bool elig = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0;
-            unsigned long long m16 = __ballot(elig && ncols_p <= 16), m32 = __ballot(elig && ncols_p > 16 && ncols_p <= 32);
+            unsigned long long m16 = __ballot(elig && ncols_p <= 16), m32 = __ballot(XSW_SEG32 && elig && ncols_p > 16 && ncols_p <= 32);
             relay = m16 | m32;
             if (A.stats) {
-                unsigned c = (elig && ncols_p <= 32) ? (unsigned)((W.w_hi - W.w_lo + 1) * ncols_p) : 0u;
+                unsigned c = ((relay >> lane) & 1ULL) ? (unsigned)((W.w_hi - W.w_lo + 1) * ncols_p) : 0u;
                 for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
                 cand += c;
             }
