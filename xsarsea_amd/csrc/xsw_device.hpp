@@ -270,6 +270,9 @@ struct CoWindow {
 // 32-lane segments (two pixels per pass, windows of 17..32 directions) measured slower than the whole-wave layout on the
 // default LUT (234 ms vs 220 ms: G drops from 3 rows side by side to 1); 16-lane segments are a clear gain on narrow
 // windows (resolution="low": 136 -> 110 ms).
+#ifndef XSW_MAX_FD_TRIPS
+#define XSW_MAX_FD_TRIPS 256
+#endif
 #ifndef XSW_SEG32
 #define XSW_SEG32 0
 #endif
@@ -321,7 +324,11 @@ __device__ __forceinline__ CoWindow box_from_jub(const DevTables &L, double mag,
     return W;
 }
 
-__device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pixel &P, double inv_dsig)
+// `loose` is set when the upper bound is so far above the scale of the pixel's own scores (J_ub > 500 (1 + |m|^2/4))
+// that the rounding error the forward differences of stage 2 pick up on the far rows of the window (<= n u 2 (m2 + J_ub)
+// after n <= 2 XSW_MAX_FD_TRIPS steps, u = 2^-53) could come near the 1e-9 (1 + |J_min| + m2) screening budget: such
+// a pixel (sigma0 wildly at odds with the ancillary wind, or a pathological LUT) takes the exact full scan.
+__device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pixel &P, double inv_dsig, bool &loose)
 {
     const double inf = __builtin_inf();
     const bool fin = (P.flags & F_CO_FINITE) != 0;
@@ -352,7 +359,7 @@ __device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pi
         hi = (open && !right) ? mid : hi;
     }
     const double jub = (rbest + m2) * (1.0 + 1e-9) + 1e-9;
-
+    loose = fin && !(jub <= 500.0 * (1.0 + m2));
     return box_from_jub(L, mag, theta, jub);
 }
 
@@ -381,7 +388,9 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
     const double ah = 0.5 * a, bh = 0.5 * b, m2 = ah * ah + bh * bh, sn = -s * inv_dsig;
     const double wh0 = 0.5 * L.w0, whs = 0.5 / L.inv_wstep;
     const int nrows = w_hi - w_lo + 1, ncols = ip_hi - ip_lo + 1;
-    if (nrows <= 0 || ncols <= 0) {  // cannot happen in exact arithmetic; stay safe
+    // nrows/ncols <= 0 cannot happen in exact arithmetic (stay safe).  More than XSW_MAX_FD_TRIPS trips: the forward
+    // differences would accumulate too much rounding error (see co_window_lanes) -> exact full scan.
+    if (nrows <= 0 || ncols <= 0 || (geom >> 8) > XSW_MAX_FD_TRIPS) {
         went_exact = true;
         return exact_scan_co(L, i_inc, s, a, b, dsig, lane);
     }
@@ -512,7 +521,7 @@ __device__ __forceinline__ void co_seg_pass(const DevTables &L, const Pixel &P, 
     const int G = geom & 0xff;
     const int grp = (sl * mdiv) >> 16, col = sl - grp * ncols;
     const int rows_pass = t_max * 2 * G;
-    const bool fits = rows_pass <= L.n_w;
+    const bool fits = rows_pass <= L.n_w && t_max <= XSW_MAX_FD_TRIPS;
     const bool act = valid && fits && grp < G;
     const int w_base = min(w_lo, L.n_w - rows_pass);
     const int row0 = act ? w_base + grp : 0, ip = act ? ip_lo + col : 0;
@@ -888,7 +897,9 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTa
     unsigned long long todo = __ballot((P.flags & F_NEED_CO) != 0);
     unsigned long long relay = 0;  // pixels laid out for a 16/32-lane segment that co_box_search has to lay out again
     if (use_prune && todo) {
-        W = co_window_lanes(L, P, A.inv_dsig_co);
+        bool loose = false;
+        W = co_window_lanes(L, P, A.inv_dsig_co, loose);
+        if (loose) P.flags &= ~F_CO_FINITE;  // -> exact_scan_co
         const unsigned long long fin_m = __ballot((P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0);
         cand += (unsigned)__popcll(fin_m) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)));
         if (L.co_off32) {
