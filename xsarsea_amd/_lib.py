@@ -5,7 +5,7 @@ import os
 
 import numpy as np
 
-from . import _build
+from . import _build, _host
 
 XSW_F32, XSW_F64 = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -271,8 +271,8 @@ class Context:
             else:
                 dsig_arr = prep(dsig_cr, dt)
         out_dtype = np.dtype(out_dtype)
-        out_co = np.empty(shape, dtype=out_dtype) if s_co is not None else None
-        out_cr = np.empty(shape, dtype=out_dtype) if s_cr is not None else None
+        out_co = _host.empty_touched(shape, out_dtype) if s_co is not None else None
+        out_cr = _host.empty_touched(shape, out_dtype) if s_cr is not None else None
         idx = np.empty(shape + (3,), dtype=np.int32) if want_idx else None
         if n:
             self.invert_raw(lines, samples, XSW_F32 if dt == np.float32 else XSW_F64,

@@ -2,6 +2,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -16,6 +19,9 @@
 
 using namespace xsw;
 
+#ifndef XSW_ARENA_KEEP
+#define XSW_ARENA_KEEP ((size_t)24 << 30)
+#endif
 struct xsw_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -27,6 +33,8 @@ struct xsw_ctx {
     bool stats_on = false;
     double *d_ratio = nullptr;  // detrend ratio row (context-owned, grown on demand)
     size_t ratio_cap = 0;
+    char *arena = nullptr;      // device staging of the host-memory path (context-owned, grown on demand, kept between
+    size_t arena_cap = 0;       // calls up to XSW_ARENA_KEEP bytes: hipMalloc/hipFree of GBs per call cost more than the copies)
     std::string err;
 };
 
@@ -97,6 +105,7 @@ extern "C" int xsw_ctx_destroy(xsw_ctx *c)
     free_all(c->cr_allocs);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_ratio) (void)hipFree(c->d_ratio);
+    if (c->arena) (void)hipFree(c->arena);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return XSW_OK;
@@ -392,50 +401,79 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
 
     // Host rasters: device buffers for the whole raster, work cut into chunks of whole lines and software-
     // pipelined so that the GPU inverts chunk k while the host side moves chunk k+1 in and chunk k-1 out
-    // (pageable hipMemcpyAsync blocks the host but not the device).  Two streams + one event per chunk.
+    // (pageable hipMemcpyAsync blocks the host but not the device).  Three streams (uploads, kernels, downloads) and two
+    // events per chunk.
     const size_t es = a->dtype == XSW_F32 ? 4 : 8, os = a->out_dtype == XSW_F32 ? 8 : 16;
-    std::vector<void *> tmp;
     int rc = XSW_OK;
-    auto dev_alloc = [&](bool want, size_t bytes, void **d) {
-        *d = nullptr;
-        if (rc || !want) return;
-        if (hipMalloc(d, bytes) != hipSuccess) { rc = fail(c, XSW_ENOMEM, "hipMalloc(%zu) failed", bytes); *d = nullptr; return; }
-        tmp.push_back(*d);
-    };
-    void *d_inc, *d_co, *d_cr, *d_dsig, *d_anc, *d_oco, *d_ocr, *d_idx;
-    dev_alloc(true, n * es, &d_inc);
-    dev_alloc(a->sigma0_co != nullptr, n * es, &d_co);
-    dev_alloc(a->sigma0_cr != nullptr, n * es, &d_cr);
-    dev_alloc(a->dsig_cr != nullptr, n * es, &d_dsig);
-    dev_alloc(a->anc != nullptr, n * es * 2, &d_anc);
-    dev_alloc(a->out_co != nullptr, n * os, &d_oco);
-    dev_alloc(a->out_cr != nullptr, n * os, &d_ocr);
-    dev_alloc(a->out_idx != nullptr, n * 12, &d_idx);
+    // one arena for all staging rasters, 256-byte aligned slots
+    size_t need = 0;
+    auto slot = [&](bool want, size_t bytes) { const size_t o = need; if (want) need += (bytes + 255) & ~(size_t)255; return want ? o : (size_t)-1; };
+    const size_t o_inc = slot(true, n * es), o_co = slot(a->sigma0_co != nullptr, n * es), o_cr = slot(a->sigma0_cr != nullptr, n * es),
+                 o_dsig = slot(a->dsig_cr != nullptr, n * es), o_anc = slot(a->anc != nullptr, n * es * 2),
+                 o_oco = slot(a->out_co != nullptr, n * os), o_ocr = slot(a->out_cr != nullptr, n * os),
+                 o_idx = slot(a->out_idx != nullptr, n * 12);
+    if (need > c->arena_cap) {
+        if (c->arena) (void)hipFree(c->arena);
+        c->arena = nullptr;
+        c->arena_cap = 0;
+        if (hipMalloc((void **)&c->arena, need) != hipSuccess) return fail(c, XSW_ENOMEM, "hipMalloc(%zu) failed", need);
+        c->arena_cap = need;
+    }
+    auto at = [&](size_t o) -> void * { return o == (size_t)-1 ? nullptr : (void *)(c->arena + o); };
+    void *d_inc = at(o_inc), *d_co = at(o_co), *d_cr = at(o_cr), *d_dsig = at(o_dsig), *d_anc = at(o_anc), *d_oco = at(o_oco),
+         *d_ocr = at(o_ocr), *d_idx = at(o_idx);
 
     const long long target_px = 8LL << 20;  // ~8 Mpx per chunk
     long long lines_per_chunk = a->samples > 0 ? (target_px + a->samples - 1) / a->samples : a->lines;
     if (lines_per_chunk < 4) lines_per_chunk = 4;
     lines_per_chunk = (lines_per_chunk + 3) & ~3LL;  // whole 4-line tile rows
     const long long nchunks = (a->lines + lines_per_chunk - 1) / lines_per_chunk;
-    hipStream_t s_out = nullptr;
-    std::vector<hipEvent_t> done((size_t)nchunks, nullptr);
-    if (!rc && hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking) != hipSuccess) rc = fail(c, XSW_EHIP, "stream create failed");
+    hipStream_t s_out = nullptr, s_in = nullptr;
+    std::vector<hipEvent_t> done((size_t)nchunks, nullptr), ready((size_t)nchunks, nullptr);
+    if (!rc && (hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking) != hipSuccess ||
+                hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking) != hipSuccess))
+        rc = fail(c, XSW_EHIP, "stream create failed");
     auto h2d = [&](void *d, const void *h, size_t off, size_t bytes) {
-        if (!rc && h && hipMemcpyAsync((char *)d + off, (const char *)h + off, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        if (!rc && h && hipMemcpyAsync((char *)d + off, (const char *)h + off, bytes, hipMemcpyHostToDevice, s_in) != hipSuccess)
             rc = fail(c, XSW_EHIP, "H2D copy failed");
     };
-    auto d2h = [&](void *h, const void *d, size_t off, size_t bytes) {
-        if (!rc && h && hipMemcpyAsync((char *)h + off, (const char *)d + off, bytes, hipMemcpyDeviceToHost, s_out) != hipSuccess)
-            rc = fail(c, XSW_EHIP, "D2H copy failed");
-    };
+    // Downloads: pageable hipMemcpyAsync blocks the calling host thread for the length of the copy, so with more than
+    // two chunks they are issued by a second host thread -- uploads + launches and downloads then proceed side by side
+    // (one thread doing both is host-bound as soon as the outputs are as large as the inputs, e.g. complex128).
+    int drc = XSW_OK;          // downloader's status, merged after the join
+    std::string derr;
     auto drain = [&](long long k) {  // outputs of chunk k -> host, once its kernel has finished
         const long long l0 = k * lines_per_chunk, l1 = std::min((long long)a->lines, l0 + lines_per_chunk);
         const size_t px0 = (size_t)l0 * a->samples, npx = (size_t)(l1 - l0) * a->samples;
-        if (!rc && hipStreamWaitEvent(s_out, done[(size_t)k], 0) != hipSuccess) rc = fail(c, XSW_EHIP, "stream wait failed");
+        auto d2h = [&](void *h, const void *d, size_t off, size_t bytes) {
+            if (!drc && h && hipMemcpyAsync((char *)h + off, (const char *)d + off, bytes, hipMemcpyDeviceToHost, s_out) != hipSuccess) {
+                drc = XSW_EHIP;
+                derr = "D2H copy failed";
+            }
+        };
+        if (!drc && hipStreamWaitEvent(s_out, done[(size_t)k], 0) != hipSuccess) { drc = XSW_EHIP; derr = "stream wait failed"; }
         d2h(a->out_co, d_oco, px0 * os, npx * os);
         d2h(a->out_cr, d_ocr, px0 * os, npx * os);
         d2h(a->out_idx, d_idx, px0 * 12, npx * 12);
     };
+    std::mutex mu;
+    std::condition_variable cv;
+    long long launched = 0;   // chunks whose kernel and `done` event are enqueued (guarded by mu)
+    bool stop = false;
+    const bool threaded = nchunks > 2 && !rc;
+    std::thread downloader;
+    if (threaded)
+        downloader = std::thread([&] {
+            if (hipSetDevice(c->device) != hipSuccess) { drc = XSW_EHIP; derr = "hipSetDevice failed in the download thread"; }
+            for (long long k = 0; k < nchunks; ++k) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return launched > k || stop; });
+                    if (launched <= k) return;  // the launch loop gave up
+                }
+                drain(k);
+            }
+        });
     for (long long k = 0; k < nchunks && !rc; ++k) {
         const long long l0 = k * lines_per_chunk, l1 = std::min((long long)a->lines, l0 + lines_per_chunk);
         const size_t px0 = (size_t)l0 * a->samples, npx = (size_t)(l1 - l0) * a->samples;
@@ -444,6 +482,12 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
         h2d(d_cr, a->sigma0_cr, px0 * es, npx * es);
         h2d(d_dsig, a->dsig_cr, px0 * es, npx * es);
         h2d(d_anc, a->anc, px0 * es * 2, npx * es * 2);
+        // the uploads ride their own stream (in the kernels' stream they would queue up behind the previous chunk's
+        // kernel instead of overlapping it); the kernel of chunk k waits for its inputs only
+        if (!rc && (hipEventCreateWithFlags(&ready[(size_t)k], hipEventDisableTiming) != hipSuccess ||
+                    hipEventRecord(ready[(size_t)k], s_in) != hipSuccess ||
+                    hipStreamWaitEvent(c->stream, ready[(size_t)k], 0) != hipSuccess))
+            rc = fail(c, XSW_EHIP, "event record failed");
         KArgs B = A;
         B.lines = l1 - l0;
         B.n = (long long)npx;
@@ -459,16 +503,38 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
         if (!rc && (hipEventCreateWithFlags(&done[(size_t)k], hipEventDisableTiming) != hipSuccess ||
                     hipEventRecord(done[(size_t)k], c->stream) != hipSuccess))
             rc = fail(c, XSW_EHIP, "event record failed");
-        if (k > 0) drain(k - 1);  // overlaps with the kernel of chunk k
+        if (threaded) {
+            if (!rc) {
+                std::lock_guard<std::mutex> lk(mu);
+                launched = k + 1;
+            }
+            cv.notify_one();
+        } else if (k > 0 && !rc) drain(k - 1);  // overlaps with the kernel of chunk k
     }
-    if (!rc && nchunks > 0) drain(nchunks - 1);
+    if (threaded) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_one();
+        downloader.join();
+    } else if (!rc && nchunks > 0) drain(nchunks - 1);
+    if (!rc && drc) rc = fail(c, drc, "%s", derr.c_str());
     hipError_t se = hipStreamSynchronize(c->stream);
     hipError_t so = s_out ? hipStreamSynchronize(s_out) : hipSuccess;
     if (!rc && (se != hipSuccess || so != hipSuccess))
         rc = fail(c, XSW_EHIP, "kernel execution failed: %s", hipGetErrorString(se != hipSuccess ? se : so));
+    hipError_t si = s_in ? hipStreamSynchronize(s_in) : hipSuccess;
+    if (!rc && si != hipSuccess) rc = fail(c, XSW_EHIP, "upload failed: %s", hipGetErrorString(si));
     for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ready) if (e) (void)hipEventDestroy(e);
     if (s_out) (void)hipStreamDestroy(s_out);
-    for (void *p : tmp) (void)hipFree(p);
+    if (s_in) (void)hipStreamDestroy(s_in);
+    if (c->arena_cap > XSW_ARENA_KEEP) {  // do not sit on a huge staging area
+        (void)hipFree(c->arena);
+        c->arena = nullptr;
+        c->arena_cap = 0;
+    }
     return rc;
 }
 

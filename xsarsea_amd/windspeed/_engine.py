@@ -2,7 +2,7 @@
 stands where the reference's `_invert_from_model_numpy` stands (windspeed/windspeed.py:132-331)."""
 import numpy as np
 
-from .. import _lib, options
+from .. import _host, _lib, options
 
 
 def host_tables(wspd, phi):
@@ -37,9 +37,40 @@ def ensure_luts(ctx, lut_co, lut_cr):
         ctx.lut_key = (lut_co if up_co else key_co, lut_cr if up_cr else key_cr)
 
 
+_BLOCK = _host.BLOCK
+_pool = _host.pool
+
+
 def _to_db(x):
+    """10*log10(x + 1e-15) in x's dtype (windspeed.py:126-130).  Large rasters are cut into blocks handled by host
+    threads: every element goes through the same numpy ufuncs, so the bits are those of the one-shot expression."""
+    x = np.asarray(x)
     with np.errstate(all="ignore"):
-        return 10 * np.log10(x + 1e-15)  # windspeed.py:126-130, dtype follows x
+        if x.size < 4 * _BLOCK or not x.flags.c_contiguous:
+            return 10 * np.log10(x + 1e-15)
+        out = np.empty(x.shape, dtype=(x[:1].ravel() + 1e-15).dtype)
+        xf, of = x.reshape(-1), out.reshape(-1)
+
+        def work(i):
+            with np.errstate(all="ignore"):
+                of[i:i + _BLOCK] = 10 * np.log10(xf[i:i + _BLOCK] + 1e-15)
+
+        list(_pool().map(work, range(0, x.size, _BLOCK)))
+        return out
+
+
+def any_valid(a):
+    """`np.any(~np.isnan(a))` without materialising two rasters: block-wise with early exit."""
+    a = np.asarray(a)
+    if a.size <= _BLOCK or not a.flags.c_contiguous:
+        return bool(np.any(~np.isnan(a)))
+    flat = a.reshape(-1)
+    return any(not np.isnan(flat[i:i + _BLOCK]).all() for i in range(0, a.size, _BLOCK))
+
+
+def all_nan(a):
+    """`np.all(np.isnan(a))`, block-wise with early exit."""
+    return not any_valid(a)
 
 
 def invert_numpy(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_co=0.1):

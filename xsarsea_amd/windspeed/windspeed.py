@@ -27,6 +27,13 @@ except ImportError:  # pragma: no cover - dask is absent from the build image
     da = None
 
 
+def _valid(v):
+    """np.any(~np.isnan(v)) (windspeed.py:107, :112); numpy rasters are scanned block-wise with early exit."""
+    if isinstance(v, np.ndarray):
+        return _engine.any_valid(v)
+    return bool(np.any(~np.isnan(v)))
+
+
 def _is_xr(v):
     return xr is not None and isinstance(v, xr.DataArray)
 
@@ -80,10 +87,10 @@ def invert_from_model(inc, sigma0, sigma0_dual=None, /, ancillary_wind=None, dsi
             raise ValueError(f"sigma0 pol is {pol}, and model {models[0].name} can only handle {model_pol}")
         if models[0].iscopol:
             sigma0_co, sigma0_cr = sigma0, None
-            assert not no_ancillary and np.any(~np.isnan(ancillary_wind)), "co-pol inversion needs a valid ancillary wind"
+            assert not no_ancillary and _valid(ancillary_wind), "co-pol inversion needs a valid ancillary wind"
         elif models[0].iscrosspol:
             sigma0_co, sigma0_cr = None, sigma0
-            if not no_ancillary and not np.all(np.isnan(ancillary_wind)):
+            if not no_ancillary and _valid(ancillary_wind):
                 warnings.warn("crosspol inversion is best without ancillary wind, but using it as requested.")
             models = (None, models[0])
     else:
