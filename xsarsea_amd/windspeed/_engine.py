@@ -59,6 +59,40 @@ def _to_db(x):
         return out
 
 
+def dual_select(ws_co, ws_cr):
+    """np.where((np.abs(ws_co) < 5) | (np.abs(ws_cr) < 5), ws_co, ws_cr)  (windspeed.py:426-428), block-wise on the host
+    pool for large rasters: the same numpy calls on every element, so the same bits (numpy's complex abs is not libm's
+    hypot, which is why this select is not left to the device for numpy inputs)."""
+    with np.errstate(all="ignore"):
+        if ws_co.size < 4 * _BLOCK or not (ws_co.flags.c_contiguous and ws_cr.flags.c_contiguous):
+            return np.where((np.abs(ws_co) < 5) | (np.abs(ws_cr) < 5), ws_co, ws_cr)
+        out = _host.empty_touched(ws_co.shape, np.result_type(ws_co, ws_cr))
+        a, b, o = ws_co.reshape(-1), ws_cr.reshape(-1), out.reshape(-1)
+
+        def work(i):
+            with np.errstate(all="ignore"):
+                x, y = a[i:i + _BLOCK], b[i:i + _BLOCK]
+                o[i:i + _BLOCK] = np.where((np.abs(x) < 5) | (np.abs(y) < 5), x, y)
+
+        list(_pool().map(work, range(0, a.size, _BLOCK)))
+        return out
+
+
+def abs_blocks(z):
+    """np.abs(z), block-wise on the host pool for large rasters (same bits)."""
+    if z.size < 4 * _BLOCK or not z.flags.c_contiguous:
+        return np.abs(z)
+    out = _host.empty_touched(z.shape, np.abs(z.reshape(-1)[:1]).dtype)
+    a, o = z.reshape(-1), out.reshape(-1)
+
+    def work(i):
+        with np.errstate(all="ignore"):
+            o[i:i + _BLOCK] = np.abs(a[i:i + _BLOCK])
+
+    list(_pool().map(work, range(0, a.size, _BLOCK)))
+    return out
+
+
 def any_valid(a):
     """`np.any(~np.isnan(a))` without materialising two rasters: block-wise with early exit."""
     a = np.asarray(a)

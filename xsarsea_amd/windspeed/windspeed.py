@@ -149,7 +149,7 @@ def invert_from_model(inc, sigma0, sigma0_dual=None, /, ancillary_wind=None, dsi
     if sigma0_dual is None:
         if models[0] is not None:
             return ws_co  # mono co-pol
-        ws = np.abs(ws_cr)  # mono cross-pol: speed only
+        ws = np.abs(ws_cr) if template is not None else _engine.abs_blocks(ws_cr)  # mono cross-pol: speed only
         if template is not None:
             ws.attrs["comment"] = f"wind speed inverted from model {models[1].name} ({models[1].pol})"
             ws.attrs["model"] = models[1].name
@@ -163,6 +163,5 @@ def invert_from_model(inc, sigma0, sigma0_dual=None, /, ancillary_wind=None, dsi
                                       f" and {models[1].name} ({models[1].pol})")
         wspd_dual.attrs["model"] = f"{models[0].name} {models[1].name}"
     else:
-        with np.errstate(all="ignore"):
-            wspd_dual = np.where((np.abs(ws_co) < 5) | (np.abs(ws_cr) < 5), ws_co, ws_cr)
+        wspd_dual = _engine.dual_select(ws_co, ws_cr)
     return ws_co, wspd_dual
