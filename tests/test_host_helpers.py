@@ -1,0 +1,54 @@
+"""CPU: the block-parallel host passes of the drop-in API return exactly the bits of the one-shot numpy expressions
+of the reference (windspeed.py:107, :126-130, :417, :426-428)."""
+import numpy as np
+import pytest
+
+from xsarsea_amd import _host
+from xsarsea_amd.windspeed import _engine
+
+N = 4 * _host.BLOCK + 12345  # just above the threshold that switches the block path on
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_to_db_blocks_bit_identical(dtype):
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-0.01, 2.0, N).astype(dtype)
+    x[::1000] = np.nan
+    x[5], x[6], x[7] = 0.0, np.inf, -1.0
+    with np.errstate(all="ignore"):
+        ref = 10 * np.log10(x + 1e-15)
+    got = _engine._to_db(x)
+    assert got.dtype == ref.dtype
+    u = np.uint32 if dtype == np.float32 else np.uint64
+    assert np.array_equal(ref.view(u), got.view(u))
+    x2 = x[: 3000 * 1400].reshape(3000, 1400)
+    with np.errstate(all="ignore"):
+        assert np.array_equal(_engine._to_db(x2).view(u), (10 * np.log10(x2 + 1e-15)).view(u))
+
+
+def test_dual_select_and_abs_blocks_bit_identical():
+    rng = np.random.default_rng(4)
+    a = rng.uniform(0, 10, N) * np.exp(1j * rng.uniform(-3, 3, N))
+    b = rng.uniform(0, 10, N) * np.exp(1j * rng.uniform(-3, 3, N))
+    a[::7] = np.nan
+    b[::11] = complex(np.nan, 0)
+    a[5], b[6] = 5.0, 3 + 4j  # |.| exactly 5: not < 5
+    with np.errstate(all="ignore"):
+        ref = np.where((np.abs(a) < 5) | (np.abs(b) < 5), a, b)
+    got = _engine.dual_select(a, b)
+    assert got.dtype == ref.dtype and np.array_equal(ref.view(np.uint64), got.view(np.uint64))
+    assert np.array_equal(np.abs(a).view(np.uint64), _engine.abs_blocks(a).view(np.uint64))
+
+
+def test_any_valid_early_exit_semantics():
+    a = np.full(N, np.nan + 0j, dtype=np.complex64)
+    assert not _engine.any_valid(a) and _engine.all_nan(a)
+    a[-1] = 1
+    assert _engine.any_valid(a) and not _engine.all_nan(a)
+    assert _engine.any_valid(np.array([np.nan, 2.0])) and not _engine.any_valid(np.array([np.nan]))
+
+
+def test_empty_touched_shape_dtype():
+    out = _host.empty_touched((3000, 3000), np.complex128)  # 144 MB: above the touch threshold
+    assert out.shape == (3000, 3000) and out.dtype == np.complex128 and out.flags.c_contiguous
+    assert _host.empty_touched((4, 5), np.float32).shape == (4, 5)
