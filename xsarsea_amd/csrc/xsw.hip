@@ -33,6 +33,7 @@ struct xsw_ctx {
     bool stats_on = false;
     double *d_ratio = nullptr;  // detrend ratio row (context-owned, grown on demand)
     size_t ratio_cap = 0;
+    hipStream_t s_in = nullptr, s_out = nullptr;  // upload / download streams of the host-memory path (lazily created)
     char *arena = nullptr;      // device staging of the host-memory path (context-owned, grown on demand, kept between
     size_t arena_cap = 0;       // calls up to XSW_ARENA_KEEP bytes: hipMalloc/hipFree of GBs per call cost more than the copies)
     std::string err;
@@ -106,6 +107,8 @@ extern "C" int xsw_ctx_destroy(xsw_ctx *c)
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_ratio) (void)hipFree(c->d_ratio);
     if (c->arena) (void)hipFree(c->arena);
+    if (c->s_in) (void)hipStreamDestroy(c->s_in);
+    if (c->s_out) (void)hipStreamDestroy(c->s_out);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return XSW_OK;
@@ -423,16 +426,17 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
     void *d_inc = at(o_inc), *d_co = at(o_co), *d_cr = at(o_cr), *d_dsig = at(o_dsig), *d_anc = at(o_anc), *d_oco = at(o_oco),
          *d_ocr = at(o_ocr), *d_idx = at(o_idx);
 
-    const long long target_px = 8LL << 20;  // ~8 Mpx per chunk
+    // ~8 Mpx per chunk for large rasters; mid-size ones are still cut in ~8 chunks (>= 0.5 Mpx) so that they pipeline too
+    const long long target_px = std::min<long long>(8LL << 20, std::max<long long>(1LL << 19, (long long)(n / 8)));
     long long lines_per_chunk = a->samples > 0 ? (target_px + a->samples - 1) / a->samples : a->lines;
     if (lines_per_chunk < 4) lines_per_chunk = 4;
     lines_per_chunk = (lines_per_chunk + 3) & ~3LL;  // whole 4-line tile rows
     const long long nchunks = (a->lines + lines_per_chunk - 1) / lines_per_chunk;
-    hipStream_t s_out = nullptr, s_in = nullptr;
     std::vector<hipEvent_t> done((size_t)nchunks, nullptr), ready((size_t)nchunks, nullptr);
-    if (!rc && (hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking) != hipSuccess ||
-                hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking) != hipSuccess))
+    if (!rc && ((!c->s_out && hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking) != hipSuccess) ||
+                (!c->s_in && hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking) != hipSuccess)))
         rc = fail(c, XSW_EHIP, "stream create failed");
+    const hipStream_t s_out = c->s_out, s_in = c->s_in;
     auto h2d = [&](void *d, const void *h, size_t off, size_t bytes) {
         if (!rc && h && hipMemcpyAsync((char *)d + off, (const char *)h + off, bytes, hipMemcpyHostToDevice, s_in) != hipSuccess)
             rc = fail(c, XSW_EHIP, "H2D copy failed");
@@ -528,8 +532,6 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
     if (!rc && si != hipSuccess) rc = fail(c, XSW_EHIP, "upload failed: %s", hipGetErrorString(si));
     for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ready) if (e) (void)hipEventDestroy(e);
-    if (s_out) (void)hipStreamDestroy(s_out);
-    if (s_in) (void)hipStreamDestroy(s_in);
     if (c->arena_cap > XSW_ARENA_KEEP) {  // do not sit on a huge staging area
         (void)hipFree(c->arena);
         c->arena = nullptr;
