@@ -861,10 +861,10 @@ __device__ __forceinline__ void store_pixel(const DevTables &L, const KArgs &A, 
 }
 
 // Production kernel.  ALGO: 1 = branch-and-bound, 3 = exact full sweep for every pixel.
-// 6 waves per SIMD (<= 80 VGPRs: 79 used, three dwords spilled outside the loops) measured 1.4 % faster than the 5 the
-// unconstrained allocation gives (86 VGPRs); 8 (<= 64 VGPRs) spills in the sweep and is slower.
+// The unconstrained allocation (86 VGPRs, 5 waves per SIMD, no scratch) is kept: forcing 6 waves (<= 80 VGPRs) measured
+// 1.4 % faster but spills three dwords per lane (+0.7 GB of HBM writes per 4e8-pixel launch); 8 spills in the sweep.
 #ifndef XSW_INVERT_WAVES_PER_SIMD
-#define XSW_INVERT_WAVES_PER_SIMD 6
+#define XSW_INVERT_WAVES_PER_SIMD 1
 #endif
 template <typename T, typename TO, int ALGO>
 __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTables L, KArgs A)
