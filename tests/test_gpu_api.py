@@ -1,14 +1,16 @@
 """GPU: the drop-in Python API (numpy in -> numpy out) against the oracle's restatement of the
 reference's `invert_from_model` / `sigma0_detrend`; reads like the reference's own test_inversion."""
+import os
 import warnings
 
 import numpy as np
 import pytest
 
-from util import bits_equal
+from util import assert_complex_close, bits_equal
 from test_gpu_kernel import synthetic_scene
 
 pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -150,3 +152,54 @@ def test_forward_gmf_device(gpu_ctx):
     small = np.asarray(m(inc2[:2], w2[:2], p2[:2]))
     assert big.shape == inc2.shape and np.allclose(big[:2], small, rtol=1e-12, atol=0)
     assert np.allclose(big, ogmf.gmf_cmod5n(inc2, w2, p2), rtol=1e-12, atol=0)
+
+
+def test_plain_c_caller(tmp_path):
+    """The boundary is a flat C ABI: a C99 program (tests/abi_c/abi_smoke.c: no Python, no torch) linked against libxsw
+    inverts a dual-pol problem on host buffers; indices equal the oracle's, winds agree to 1e-9 (the optional libm
+    tables are left NULL there, so the last bit of cos/sin may differ from numpy's)."""
+    import shutil
+    import subprocess
+    from oracle import gmf, lut as olut
+    from oracle import invert as oinv
+    from xsarsea_amd import _build
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    lib = _build.LIB
+    exe = tmp_path / "abi_smoke"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-I", os.path.join(REPO, "include"), "-o", str(exe),
+                    os.path.join(REPO, "tests", "abi_c", "abi_smoke.c"), "-L", os.path.dirname(lib), "-lxsw",
+                    "-Wl,-rpath," + os.path.dirname(lib)], check=True)
+    rng = np.random.default_rng(11)
+    inc_ax, w_ax, phi_ax = np.linspace(20, 45, 6), np.linspace(0.5, 40, 80), np.linspace(0, 180, 37)
+    wcr_ax = np.linspace(3, 60, 58)
+    co = 10 * np.log10(gmf.gmf_cmod5n(inc_ax[:, None, None], w_ax[None, :, None], phi_ax[None, None, :]) + 1e-15)
+    cr = 10 * np.log10(gmf.GMFS["gmf_s1_v2"][0](inc_ax[:, None], wcr_ax[None, :]) + 1e-15)
+    n = 333
+    inc = rng.uniform(19, 46, n)
+    wt, pt = rng.uniform(1, 35, n), rng.uniform(-180, 180, n)
+    sco = oinv.to_db(gmf.gmf_cmod5n(inc, wt, pt) * rng.gamma(50, 1 / 50, n))
+    scr = oinv.to_db(gmf.GMFS["gmf_s1_v2"][0](inc, np.maximum(wt, 3)) * rng.gamma(50, 1 / 50, n))
+    dsig = 10 ** rng.uniform(-2, 0, n)
+    anc = wt * np.exp(1j * np.deg2rad(pt)) + rng.normal(0, 2, n) + 1j * rng.normal(0, 2, n)
+    sco[3], scr[4], inc[5], anc[6] = np.nan, np.nan, np.nan, complex(np.nan, 0)
+    prob = tmp_path / "problem.bin"
+    with open(prob, "wb") as f:
+        np.array([len(inc_ax), len(w_ax), len(phi_ax), len(wcr_ax), n], dtype=np.int32).tofile(f)
+        np.array([0.1]).tofile(f)
+        for arr in (inc_ax, w_ax, phi_ax, co, wcr_ax, cr, inc, sco, scr, dsig):
+            np.ascontiguousarray(arr, dtype=np.float64).tofile(f)
+        np.ascontiguousarray(anc, dtype=np.complex128).view(np.float64).tofile(f)
+    res = tmp_path / "result.bin"
+    env = dict(os.environ)
+    r = subprocess.run([str(exe), str(prob), str(res)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    raw = np.fromfile(res, dtype=np.uint8)
+    out_co = raw[: 16 * n].view(np.complex128)
+    out_cr = raw[16 * n: 32 * n].view(np.complex128)
+    idx = raw[32 * n:].view(np.int32).reshape(n, 3)
+    p = oinv.Prepared(olut.Lut(co, inc_ax, w_ax, phi_ax, "dB", "x", "co", "VV"), olut.Lut(cr, inc_ax, wcr_ax, None, "dB", "x", "cr", "VH"))
+    o = oinv.invert_numpy(p, inc, sco, scr, dsig, anc, return_idx=True)
+    assert np.array_equal(idx, o[2])
+    assert_complex_close(out_co, o[0], rtol=1e-9, what="C caller co")
+    assert_complex_close(out_cr, o[1], rtol=1e-9, what="C caller cr")
