@@ -405,7 +405,8 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
         const int grp = (lane * mdiv) >> 16, col = lane - grp * width;
         const bool act = grp < G;
         const int ip = ip_lo + c0 + (act ? col : 0);
-        const double U = 2.0 * (ah * L.cphi[ip] + bh * L.sphi[ip]);
+        const unsigned ipB = (unsigned)ip * 8u;  // uniform table base + 32-bit byte offset: no 64-bit address arithmetic
+        const double U = 2.0 * (ah * *(const double *)((const char *)L.cphi + ipB) + bh * *(const double *)((const char *)L.sphi + ipB));
         const int step = 2 * G, rows_r = trips * step;
         int w_base = w_lo;
         const bool mask_rows = rows_r > L.n_w;
@@ -413,8 +414,9 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
         const int row0 = w_base + (act ? grp : 0);
         const double dG = (double)G * whs;
         const double wh = fma((double)row0, whs, wh0);
-        double pw = act ? wh * (wh - U) : BIG, dp = act ? dG * (2.0 * wh - U) + dG * dG : 0.0;  // idle lanes: BIG
+        double pw = wh * (wh - U), dp = dG * (2.0 * wh - U) + dG * dG;
         const double ddp = 2.0 * dG * dG;
+        const double snl = act ? sn : 1e150;  // idle lanes: dd ~ 1e150, score ~ 1e300 (finite: tags stay legal)
         // wave-uniform row bases (SGPR pairs) + one 32-bit per-lane byte offset; the loads of the next trip are
         // issued before the current one is scored (the slack rows after the LUT keep the last look-ahead legal)
         const unsigned pstepB = (unsigned)(G * L.phi_pad * 8);
@@ -422,7 +424,7 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
         unsigned off = (unsigned)((row0 * L.phi_pad + ip) * 8);
         const double before = best;
         int keep_mask;
-        asm volatile("v_mov_b32 %0, 0xffff0000" : "=v"(keep_mask));  // kept in a VGPR: VOP3 takes no literal
+        asm("v_mov_b32 %0, 0xffff0000" : "=v"(keep_mask));  // kept in a VGPR: VOP3 takes no literal
         auto sweep = [&](auto masked) {
             double v0 = *(const double *)(sb0 + off), v1 = *(const double *)(sb1 + off);
             for (int r0 = 0; r0 < rows_r; r0 += step) {
@@ -431,7 +433,7 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
                 const double v[2] = {v0, v1};
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const double dd = fma(v[k], inv_dsig, sn);
+                    const double dd = fma(v[k], inv_dsig, snl);
                     double J = tag16(fma(dd, dd, pw), keep_mask, r0 + k * G);  // the score carries its row slot
                     if (masked.value) J = (row0 + r0 + k * G) < L.n_w ? J : BIG;
                     second = vmin(second, vmax(J, best));
@@ -525,10 +527,12 @@ __device__ __forceinline__ void co_seg_pass(const DevTables &L, const Pixel &P, 
     const bool act = valid && fits && grp < G;
     const int w_base = min(w_lo, L.n_w - rows_pass);
     const int row0 = act ? w_base + grp : 0, ip = act ? ip_lo + col : 0;
-    const double U = 2.0 * (ah * L.cphi[ip] + bh * L.sphi[ip]);
+    const unsigned ipB = (unsigned)ip * 8u;
+    const double U = 2.0 * (ah * *(const double *)((const char *)L.cphi + ipB) + bh * *(const double *)((const char *)L.sphi + ipB));
     const double dG = (double)G * whs;
     const double wh = fma((double)row0, whs, wh0);
-    double pw = act ? wh * (wh - U) : BIG, dp = act ? dG * (2.0 * wh - U) + dG * dG : 0.0;  // idle lanes: BIG
+    double pw = wh * (wh - U), dp = dG * (2.0 * wh - U) + dG * dG;
+    const double snl = act ? sn : 1e150;  // idle lanes: dd ~ 1e150, score ~ 1e300 (finite: tags stay legal)
     const double ddp = 2.0 * dG * dG;
     const char *__restrict__ base = (const char *)L.co;
     const unsigned pstepB = (unsigned)(G * L.phi_pad) * 8u;
@@ -536,7 +540,7 @@ __device__ __forceinline__ void co_seg_pass(const DevTables &L, const Pixel &P, 
     unsigned off1 = off0 + (act ? pstepB : 0u);
     const unsigned adv = act ? 2u * pstepB : 0u;
     int keep_mask;
-    asm volatile("v_mov_b32 %0, 0xffff0000" : "=v"(keep_mask));
+    asm("v_mov_b32 %0, 0xffff0000" : "=v"(keep_mask));
     double best = __builtin_inf(), second = __builtin_inf();
     double v0 = *(const double *)(base + off0), v1 = *(const double *)(base + off1);
     for (int t = 0; t < t_max; ++t) {
@@ -547,7 +551,7 @@ __device__ __forceinline__ void co_seg_pass(const DevTables &L, const Pixel &P, 
         const double v[2] = {v0, v1};
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const double dd = fma(v[k], inv_dsig, sn);
+            const double dd = fma(v[k], inv_dsig, snl);
             const double J = tag16(fma(dd, dd, pw), keep_mask, 2 * t + k);  // the score carries its step
             second = vmin(second, vmax(J, best));
             best = vmin(best, J);
