@@ -93,3 +93,19 @@ def test_pruned_equals_exhaustive_and_oracle_on_crops(full_scene, default_luts):
         o = oracle_full(ci, cs, None, None, ca, lco, None)
         st = ctx.invert_host(ci, sigma0_co=oinv.to_db(cs), anc=ca, sigma0_is_db=True, algo="pruned", want_idx=True)
         assert np.array_equal(st[2][..., :2], o[2][..., :2])
+
+
+def test_pruned_equals_exhaustive_on_the_whole_raster(full_scene):
+    """All 4e8 pixels: the branch-and-bound kernel (552 candidates scored per pixel) and the LDS-tiled exhaustive sweep
+    (all 90 319, an independent code path: no window, no forward differences along a window, float32 screening + float64
+    settle) return the same bits."""
+    f = full_scene
+    torch, ctx = f["torch"], f["ctx"]
+    from xsarsea_amd import _lib
+    ex = torch.empty_like(f["out"])
+    ctx.invert_raw(N, N, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, f["inc"].data_ptr(), f["s_vv"].data_ptr(), None, None,
+                   f["anc"].data_ptr(), ex.data_ptr(), None, algo=_lib.ALGOS["exhaustive"])
+    ctx.synchronize()
+    a, b = torch.view_as_real(f["out"]).view(torch.int32), torch.view_as_real(ex).view(torch.int32)
+    diff = int((a != b).any(dim=-1).sum().item())
+    assert diff == 0, f"{diff} of {N * N} pixels differ between the pruned and the exhaustive kernel"
