@@ -191,10 +191,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs (never set by the driver): XSW_BENCH_BACKEND=gloo and XSW_BENCH_ONE_DEVICE=1 let the whole N > 1
+    # code path run as several ranks on a one-GPU box (everything but RCCL itself)
+    backend = os.environ.get("XSW_BENCH_BACKEND", "nccl")
+    if os.environ.get("XSW_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     n_gpus = world
