@@ -344,7 +344,9 @@ static int launch_invert(xsw_ctx *c, const KArgs &A, int algo)
     if (algo == XSW_ALGO_EXHAUSTIVE || algo == XSW_ALGO_EXHAUSTIVE_F64)
         return launch_exhaustive<T, TO>(c->T, A, c->stream, algo == XSW_ALGO_EXHAUSTIVE) == hipSuccess
                                                 ? XSW_OK : fail(c, XSW_EHIP, "exhaustive launch failed: %s", hipGetErrorString(hipGetLastError()));
-    if (algo == XSW_ALGO_PRUNED)
+    if (algo == XSW_ALGO_PRUNED && !A.s_cr && !A.out_cr)
+        hipLaunchKernelGGL((k_invert<T, TO, 1, false>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, A);
+    else if (algo == XSW_ALGO_PRUNED)
         hipLaunchKernelGGL((k_invert<T, TO, 1>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, A);
     else
         hipLaunchKernelGGL((k_invert<T, TO, 3>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, A);

@@ -757,14 +757,14 @@ template <typename T> __device__ __forceinline__ double ld(const void *p, long l
 
 // Loads pixel `il` (already clamped in range), converts to dB, classifies it (windspeed.py:198-209,
 // :252) and finds its incidence bins (:212, :254).
-template <typename T>
+template <typename T, bool CR = true>
 __device__ __forceinline__ void load_pixel(const DevTables &L, const KArgs &A, long long il, bool in, Pixel &P)
 {
     const double nan = __builtin_nan("");
     const double inc = ld<T>(A.inc, il);
     P.s_co = nan; P.s_cr = nan; P.dsig = nan; P.a_re = nan; P.a_im = nan;
     if (A.s_co) P.s_co = to_db(((const T *)A.s_co)[il], A.is_db);
-    if (A.s_cr) {
+    if (CR && A.s_cr) {
         const T x = ((const T *)A.s_cr)[il];
         P.s_cr = to_db(x, A.is_db);
         // scalar dsig_cr is broadcast as sigma0_cr*0 + dsig_cr in the raster dtype (windspeed.py:122-123)
@@ -803,7 +803,7 @@ __device__ __forceinline__ void load_pixel(const DevTables &L, const KArgs &A, l
 
 // Forms pixel i's complex winds from the winning indices and stores them (windspeed.py:231-250,
 // :269-281, dual select :426-428).
-template <typename TO>
+template <typename TO, bool CR = true>
 __device__ __forceinline__ void store_pixel(const DevTables &L, const KArgs &A, long long i, const Pixel &P,
                                             int my_flat, int my_icr)
 {
@@ -849,7 +849,7 @@ __device__ __forceinline__ void store_pixel(const DevTables &L, const KArgs &A, 
         cx_t z; z.x = (TO)co_re; z.y = (TO)co_im;
         ((cx_t *)A.out_co)[i] = z;
     }
-    if (A.out_cr) {
+    if (CR && A.out_cr) {
         if (A.dual_select) {  // xr.where((|co| < 5) | (|dual| < 5), co, dual)  (windspeed.py:426-428)
             const double aco = (P.flags & F_NEED_CO) ? L.abs_co[(size_t)o_iw * L.n_phi + o_ip] : hypot_glibc(co_re, co_im);
             if (aco < 5.0 || hypot_glibc(cr_re, cr_im) < 5.0) { cr_re = co_re; cr_im = co_im; }
@@ -865,12 +865,14 @@ __device__ __forceinline__ void store_pixel(const DevTables &L, const KArgs &A, 
 }
 
 // Production kernel.  ALGO: 1 = branch-and-bound, 3 = exact full sweep for every pixel.
-// The unconstrained allocation (86 VGPRs, 5 waves per SIMD, no scratch) is kept: forcing 6 waves (<= 80 VGPRs) measured
-// 1.4 % faster but spills three dwords per lane (+0.7 GB of HBM writes per 4e8-pixel launch); 8 spills in the sweep.
+// The unconstrained allocation is kept (mono instantiation 78 VGPRs = 6 waves per SIMD, dual-pol 88 = 5; no scratch):
+// forcing 6 waves on the dual-pol kernel spills (+0.7 GB of HBM writes per 4e8-pixel launch), 8 spills in the sweep.
 #ifndef XSW_INVERT_WAVES_PER_SIMD
 #define XSW_INVERT_WAVES_PER_SIMD 1
 #endif
-template <typename T, typename TO, int ALGO>
+// CR = false: mono co-pol instantiation (no cross-pol raster, no second output): the cross-pol pixel state is not kept
+// alive through the co-pol search.
+template <typename T, typename TO, int ALGO, bool CR = true>
 __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTables L, KArgs A)
 {
     const int lane = threadIdx.x & 63;
@@ -891,7 +893,7 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTa
     const double nan = __builtin_nan("");
 
     Pixel P;
-    load_pixel<T>(L, A, i, in, P);
+    load_pixel<T, CR>(L, A, i, in, P);
 
     // ---- co-pol search.  Stage 1 (one pixel per lane): upper bound + search window.  Stage 2: the wave
     //      walks its pixels one at a time, window and parameters wave-uniform (readlane -> SGPRs).
@@ -948,7 +950,7 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTa
     }
 
     // ---- cross-pol search (windspeed.py:252-269): one pixel per lane, then the undecided ones cooperatively
-    if (A.s_cr) {
+    if (CR && A.s_cr) {
         const bool need_cr = (P.flags & F_NEED_CR) != 0;
         const bool have_co = (P.flags & F_NEED_CO) != 0;  // |wind_co| is never NaN once a co-pol search ran
         const double aco = have_co ? L.abs_co[my_flat] : nan;  // np.abs(wind_co), table [n_w][n_phi]
@@ -974,7 +976,7 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTa
         atomicAdd(&A.stats[2], (unsigned long long)n_exact);
         atomicAdd(&A.stats[3], (unsigned long long)n_cr);
     }
-    if (in) store_pixel<TO>(L, A, i, P, my_flat, my_icr);
+    if (in) store_pixel<TO, CR>(L, A, i, P, my_flat, my_icr);
 }
 
 // [n_inc][n_w][phi_pad] -> [n_inc][n_phi][w_pad], 32x32 LDS tiles
