@@ -1042,6 +1042,9 @@ __global__ __launch_bounds__(256) void k_lut_interp(InterpArgs a)
 // 16-B vector loads/stores (4 samples per thread), the ratio row stays in L2; no integer division per pixel.
 // streaming accesses of k_detrend: every byte is touched once.  Non-temporal hints measured no gain on MI355X
 // (bit 0 = loads, bit 1 = stores: f32->f64 1.00 ms plain / 1.00 ms nt loads / 1.40 ms nt loads+stores), so plain.
+#ifndef XSW_DETREND_LINES
+#define XSW_DETREND_LINES 4
+#endif
 #ifndef XSW_DETREND_NT
 #define XSW_DETREND_NT 0
 #endif
@@ -1100,18 +1103,18 @@ __global__ __launch_bounds__(256) void k_detrend(const T *__restrict__ sigma0, c
         vout_t *o = (vout_t *)(out + l0 * samples + s0);
         const long long stride = samples >> 2;
         long long l = l0;
-        for (; l + 4 <= l1; l += 4) {  // four lines in flight (64 B of loads per lane before the first use)
-            vin_t a[4];
+        for (; l + XSW_DETREND_LINES <= l1; l += XSW_DETREND_LINES) {  // several lines in flight per lane
+            vin_t a[XSW_DETREND_LINES];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] = XSW_DETREND_LD(&in[u * stride]);
+            for (int u = 0; u < XSW_DETREND_LINES; ++u) a[u] = XSW_DETREND_LD(&in[u * stride]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < XSW_DETREND_LINES; ++u) {
                 vout_t ou;
                 ou.x = (TO)div_by<FAST>((double)a[u].x, r[0], y[0]); ou.y = (TO)div_by<FAST>((double)a[u].y, r[1], y[1]);
                 ou.z = (TO)div_by<FAST>((double)a[u].z, r[2], y[2]); ou.w = (TO)div_by<FAST>((double)a[u].w, r[3], y[3]);
                 XSW_DETREND_ST(ou, &o[u * stride]);
             }
-            in += 4 * stride; o += 4 * stride;
+            in += XSW_DETREND_LINES * stride; o += XSW_DETREND_LINES * stride;
         }
         for (; l < l1; ++l) {
             const vin_t a = in[0];
