@@ -4,11 +4,13 @@
 //   * a workgroup (4 waves) owns a raster tile of 4 lines x 64 samples; one wavefront owns a strip of 64
 //     consecutive samples; lane i loads pixel i (coalesced), converts sigma0 to dB, finds its incidence bin;
 //   * PER-LANE stages (64 pixels in flight, wave-uniform trip counts, nothing diverges): upper bound of the
-//     cost along the a-priori direction and the search window it implies (co_window_lanes), the whole
-//     cross-pol search (search_cr_lanes), forming and storing the complex winds (store_pixel);
-//   * COOPERATIVE stage (co_box_search): the wave walks its pixels one at a time with the pixel's window and
-//     parameters wave-uniform (readlane -> SGPRs); the 64 lanes sweep the window's candidates and a
-//     wave-level argmin (DPP butterfly) picks the winner; lane i keeps the winner of pixel i.
+//     cost along the a-priori direction (bisection) and the search window + lane layout it implies
+//     (co_window_lanes, box_from_jub, chunk_geom), the whole cross-pol search (search_cr_interval /
+//     search_cr_lanes), forming and storing the complex winds (store_pixel);
+//   * COOPERATIVE stage: windows of <= 16 directions go four pixels at a time, one per 16-lane segment
+//     (co_seg_pass); the others one pixel at a time with the pixel's window and parameters wave-uniform
+//     (co_box_search: readlane -> SGPRs); the lanes sweep the window's candidates and a DPP argmin picks the
+//     winner; lane i keeps the winner of pixel i.
 //
 // All decisions are taken in float64.  The reference's argmin (windspeed/windspeed.py:220-232) is
 // reproduced exactly: candidates are screened with a cheap fused form, every candidate within a
