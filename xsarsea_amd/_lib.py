@@ -296,7 +296,7 @@ class Context:
         lines, samples = int(np.prod(sigma0.shape[:-1])), sigma0.shape[-1]
         if ratio_row.shape != (samples,):
             raise ValueError("ratio_row must have one value per sample")
-        out = np.empty(sigma0.shape, dtype=out_dtype)
+        out = _host.empty_touched(sigma0.shape, out_dtype)
         self._check(self._lib.xsw_detrend(self._h, lines, samples, XSW_F32 if sigma0.dtype == np.float32 else XSW_F64,
                                           XSW_F32 if out.dtype == np.float32 else XSW_F64, MEM_HOST,
                                           _ptr(sigma0), _ptr(ratio_row), _ptr(out)), "xsw_detrend")

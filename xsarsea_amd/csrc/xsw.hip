@@ -720,29 +720,98 @@ extern "C" int xsw_detrend(xsw_ctx *c, int64_t lines, int64_t samples, int32_t d
     double *d_rinv = c->d_ratio + samples;
     hipError_t e = hipMemcpyAsync(c->d_ratio, both.data(), 2 * (size_t)samples * sizeof(double), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // `both` is a local
-    const void *d_in = sigma0;
-    void *d_out = out, *t_in = nullptr, *t_out = nullptr;
-    if (e == hipSuccess && mem == XSW_MEM_HOST) {
-        e = hipMalloc(&t_in, n * es);
-        if (e == hipSuccess) e = hipMalloc(&t_out, n * os);
-        if (e == hipSuccess) e = hipMemcpyAsync(t_in, sigma0, n * es, hipMemcpyHostToDevice, c->stream);
-        d_in = t_in;
-        d_out = t_out;
+    auto launch = [&](const void *din, void *dout, long long nl) {
+        if (dtype == XSW_F32 && out_dtype == XSW_F32) launch_detrend<float, float>(c->stream, din, c->d_ratio, d_rinv, fast, dout, nl, samples);
+        else if (dtype == XSW_F32) launch_detrend<float, double>(c->stream, din, c->d_ratio, d_rinv, fast, dout, nl, samples);
+        else if (out_dtype == XSW_F32) launch_detrend<double, float>(c->stream, din, c->d_ratio, d_rinv, fast, dout, nl, samples);
+        else launch_detrend<double, double>(c->stream, din, c->d_ratio, d_rinv, fast, dout, nl, samples);
+        return hipGetLastError();
+    };
+    if (mem == XSW_MEM_DEVICE) {  // device rasters: asynchronous on the context's stream
+        if (e == hipSuccess) e = launch(sigma0, out, lines);
+        if (e != hipSuccess) return fail(c, XSW_EHIP, "detrend failed: %s", hipGetErrorString(e));
+        return XSW_OK;
     }
-    if (e == hipSuccess) {
-        if (dtype == XSW_F32 && out_dtype == XSW_F32) launch_detrend<float, float>(c->stream, d_in, c->d_ratio, d_rinv, fast, d_out, lines, samples);
-        else if (dtype == XSW_F32) launch_detrend<float, double>(c->stream, d_in, c->d_ratio, d_rinv, fast, d_out, lines, samples);
-        else if (out_dtype == XSW_F32) launch_detrend<double, float>(c->stream, d_in, c->d_ratio, d_rinv, fast, d_out, lines, samples);
-        else launch_detrend<double, double>(c->stream, d_in, c->d_ratio, d_rinv, fast, d_out, lines, samples);
-        e = hipGetLastError();
+    // Host rasters (synchronous): the same three-stream pipeline as xsw_invert -- uploads, kernels and downloads of
+    // successive line chunks overlap; the downloads are issued by a second host thread (a pageable copy blocks its caller).
+    if (e != hipSuccess) return fail(c, XSW_EHIP, "detrend failed: %s", hipGetErrorString(e));
+    const size_t in_bytes = ((size_t)n * es + 255) & ~(size_t)255, need = in_bytes + (size_t)n * os;
+    if (need > c->arena_cap) {
+        if (c->arena) (void)hipFree(c->arena);
+        c->arena = nullptr;
+        c->arena_cap = 0;
+        if (hipMalloc((void **)&c->arena, need) != hipSuccess) return fail(c, XSW_ENOMEM, "hipMalloc(%zu) failed", need);
+        c->arena_cap = need;
     }
-    if (mem == XSW_MEM_HOST) {  // host rasters: synchronous; device rasters: asynchronous on the context's stream
-        if (e == hipSuccess) e = hipMemcpyAsync(out, t_out, n * os, hipMemcpyDeviceToHost, c->stream);
-        hipError_t se = hipStreamSynchronize(c->stream);
-        if (e == hipSuccess) e = se;
-        if (t_in) (void)hipFree(t_in);
-        if (t_out) (void)hipFree(t_out);
+    if ((!c->s_out && hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking) != hipSuccess) ||
+        (!c->s_in && hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking) != hipSuccess))
+        return fail(c, XSW_EHIP, "stream create failed");
+    char *t_in = c->arena, *t_out = c->arena + in_bytes;
+    const long long target_px = std::min<long long>(16LL << 20, std::max<long long>(1LL << 19, n / 8));
+    long long lpc = samples > 0 ? (target_px + samples - 1) / samples : lines;
+    if (lpc < 1) lpc = 1;
+    const long long nchunks = (lines + lpc - 1) / lpc;
+    std::vector<hipEvent_t> done((size_t)nchunks, nullptr), ready((size_t)nchunks, nullptr);
+    hipError_t de = hipSuccess;  // downloader's status
+    auto drain = [&](long long k) {
+        const long long l0 = k * lpc, l1 = std::min((long long)lines, l0 + lpc);
+        const size_t px0 = (size_t)l0 * samples, npx = (size_t)(l1 - l0) * samples;
+        if (de == hipSuccess) de = hipStreamWaitEvent(c->s_out, done[(size_t)k], 0);
+        if (de == hipSuccess) de = hipMemcpyAsync((char *)out + px0 * os, t_out + px0 * os, npx * os, hipMemcpyDeviceToHost, c->s_out);
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    long long launched = 0;
+    bool stop = false;
+    const bool threaded = nchunks > 2;
+    std::thread downloader;
+    if (threaded)
+        downloader = std::thread([&] {
+            de = hipSetDevice(c->device);
+            for (long long k = 0; k < nchunks; ++k) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return launched > k || stop; });
+                    if (launched <= k) return;
+                }
+                drain(k);
+            }
+        });
+    for (long long k = 0; k < nchunks && e == hipSuccess; ++k) {
+        const long long l0 = k * lpc, l1 = std::min((long long)lines, l0 + lpc);
+        const size_t px0 = (size_t)l0 * samples, npx = (size_t)(l1 - l0) * samples;
+        e = hipMemcpyAsync(t_in + px0 * es, (const char *)sigma0 + px0 * es, npx * es, hipMemcpyHostToDevice, c->s_in);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ready[(size_t)k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(ready[(size_t)k], c->s_in);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ready[(size_t)k], 0);
+        if (e == hipSuccess) e = launch(t_in + px0 * es, t_out + px0 * os, l1 - l0);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[(size_t)k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(done[(size_t)k], c->stream);
+        if (threaded) {
+            if (e == hipSuccess) {
+                std::lock_guard<std::mutex> lk(mu);
+                launched = k + 1;
+            }
+            cv.notify_one();
+        } else if (e == hipSuccess && k > 0) drain(k - 1);
     }
+    if (threaded) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_one();
+        downloader.join();
+    } else if (e == hipSuccess && nchunks > 0) drain(nchunks - 1);
+    hipError_t s1 = hipStreamSynchronize(c->s_in), s2 = hipStreamSynchronize(c->stream), s3 = hipStreamSynchronize(c->s_out);
+    for (hipEvent_t ev : done) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : ready) if (ev) (void)hipEventDestroy(ev);
+    if (c->arena_cap > XSW_ARENA_KEEP) {
+        (void)hipFree(c->arena);
+        c->arena = nullptr;
+        c->arena_cap = 0;
+    }
+    for (hipError_t x : {de, s1, s2, s3}) if (e == hipSuccess) e = x;
     if (e != hipSuccess) return fail(c, XSW_EHIP, "detrend failed: %s", hipGetErrorString(e));
     return XSW_OK;
 }
