@@ -466,9 +466,9 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
     std::condition_variable cv;
     long long launched = 0;   // chunks whose kernel and `done` event are enqueued (guarded by mu)
     bool stop = false;
-    const bool threaded = nchunks > 2 && !rc;
+    bool threaded = nchunks > 2 && !rc;
     std::thread downloader;
-    if (threaded)
+    if (threaded) try {
         downloader = std::thread([&] {
             if (hipSetDevice(c->device) != hipSuccess) { drc = XSW_EHIP; derr = "hipSetDevice failed in the download thread"; }
             for (long long k = 0; k < nchunks; ++k) {
@@ -480,6 +480,9 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
                 drain(k);
             }
         });
+    } catch (...) {  // no exception crosses the ABI: fall back to issuing the downloads from this thread
+        threaded = false;
+    }
     for (long long k = 0; k < nchunks && !rc; ++k) {
         const long long l0 = k * lines_per_chunk, l1 = std::min((long long)a->lines, l0 + lines_per_chunk);
         const size_t px0 = (size_t)l0 * a->samples, npx = (size_t)(l1 - l0) * a->samples;
@@ -763,9 +766,9 @@ extern "C" int xsw_detrend(xsw_ctx *c, int64_t lines, int64_t samples, int32_t d
     std::condition_variable cv;
     long long launched = 0;
     bool stop = false;
-    const bool threaded = nchunks > 2;
+    bool threaded = nchunks > 2;
     std::thread downloader;
-    if (threaded)
+    if (threaded) try {
         downloader = std::thread([&] {
             de = hipSetDevice(c->device);
             for (long long k = 0; k < nchunks; ++k) {
@@ -777,6 +780,9 @@ extern "C" int xsw_detrend(xsw_ctx *c, int64_t lines, int64_t samples, int32_t d
                 drain(k);
             }
         });
+    } catch (...) {  // no exception crosses the ABI: fall back to issuing the downloads from this thread
+        threaded = false;
+    }
     for (long long k = 0; k < nchunks && e == hipSuccess; ++k) {
         const long long l0 = k * lpc, l1 = std::min((long long)lines, l0 + lpc);
         const size_t px0 = (size_t)l0 * samples, npx = (size_t)(l1 - l0) * samples;
