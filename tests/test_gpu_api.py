@@ -203,3 +203,34 @@ def test_plain_c_caller(tmp_path):
     assert np.array_equal(idx, o[2])
     assert_complex_close(out_co, o[0], rtol=1e-9, what="C caller co")
     assert_complex_close(out_cr, o[1], rtol=1e-9, what="C caller cr")
+
+
+def test_threaded_callers_share_the_context_safely():
+    """dask's threaded scheduler calls the reference's function from several threads; here they share one device
+    context (not thread-safe at the C level), serialised by the Python layer -- also when they alternate between models
+    (= LUT re-uploads).  Results must equal the sequential ones."""
+    from concurrent.futures import ThreadPoolExecutor
+    from xsarsea_amd import windspeed
+    rng = np.random.default_rng(5)
+    jobs = []
+    for k in range(8):
+        shape = (int(rng.integers(20, 60)), int(rng.integers(50, 200)))
+        n = shape[0] * shape[1]
+        inc = rng.uniform(20, 45, n).reshape(shape)
+        wt, pt = rng.uniform(1, 30, n), rng.uniform(-180, 180, n)
+        anc = (wt * np.exp(1j * np.deg2rad(pt)) + rng.normal(0, 2, n)).reshape(shape)
+        model = "gmf_cmod5n" if k % 2 == 0 else "gmf_cmod5"
+        s = (windspeed.get_model(model)(inc.ravel(), wt, pt, broadcast=True) * rng.gamma(50, 1 / 50, n)).reshape(shape)
+        jobs.append((inc, s, anc, model))
+
+    def run(job):
+        inc, s, anc, model = job
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return windspeed.invert_from_model(inc, s, ancillary_wind=anc, model=model, resolution="low")
+
+    seq = [run(j) for j in jobs]
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        par = list(ex.map(run, jobs * 3))
+    for i, r in enumerate(par):
+        assert bits_equal(r, seq[i % len(jobs)]), f"job {i} differs when run from a thread pool"

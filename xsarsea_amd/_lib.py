@@ -1,7 +1,9 @@
 """ctypes binding of libxsw.so (include/xsw.h).  There is no CPU fallback: if the library is missing
 or no GPU is present the calls raise."""
 import ctypes
+import functools
 import os
+import threading
 
 import numpy as np
 
@@ -132,6 +134,17 @@ def _ptr(a):
     return ctypes.c_void_p(a.ctypes.data)
 
 
+def _locked(method):
+    """A libxsw context is not thread-safe (include/xsw.h); the Python layer serialises the calls on one context, so
+    that threaded callers (dask's threaded scheduler runs the reference's function from several threads) stay correct.
+    The lock is re-entrant and is also taken by `windspeed._engine` around "make sure the LUTs are up, then invert"."""
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        with self.lock:
+            return method(self, *args, **kwargs)
+    return wrapper
+
+
 class Context:
     """One device, one stream (include/xsw.h: xsw_ctx)."""
 
@@ -144,6 +157,7 @@ class Context:
         self._h = h
         self.device = int(device)
         self.lut_key = (None, None)
+        self.lock = threading.RLock()
 
     def close(self):
         if getattr(self, "_h", None):
@@ -160,13 +174,16 @@ class Context:
         if rc != 0:
             raise XswError(f"{what} failed ({rc}): {self._lib.xsw_last_error(self._h).decode()}")
 
+    @_locked
     def set_stream(self, stream_handle):
         """Launch on this hipStream_t handle (int; 0 = the device's default stream)."""
         self._check(self._lib.xsw_set_stream(self._h, ctypes.c_void_p(stream_handle or 0)), "xsw_set_stream")
 
+    @_locked
     def use_own_stream(self):
         self._check(self._lib.xsw_use_own_stream(self._h), "xsw_use_own_stream")
 
+    @_locked
     def synchronize(self):
         self._check(self._lib.xsw_synchronize(self._h), "xsw_synchronize")
 
@@ -187,6 +204,7 @@ class Context:
         s = LutStruct(*[_ptr(k) for k in keep], len(keep[1]), n_w, n_phi)
         return s, keep
 
+    @_locked
     def upload_luts(self, co=None, cr=None):
         """co = dict(db[inc,wspd,phi], inc, wspd, phi[, cos_phi, sin_phi]); cr = dict(db[inc,wspd], inc, wspd)."""
         sco = scr = None
@@ -200,6 +218,7 @@ class Context:
         self._check(self._lib.xsw_lut_upload(self._h, ctypes.byref(sco) if sco else None,
                                              ctypes.byref(scr) if scr else None), "xsw_lut_upload")
 
+    @_locked
     def lut_interp(self, raw, inc_raw, wspd_raw, phi_raw, inc, wspd, phi):
         """xsw_lut_interp: (incidence, wspd[, phi]) table -> finer axes, bit-identical to three interp1d passes."""
         raw, inc_raw, wspd_raw, inc, wspd = map(_f64, (raw, inc_raw, wspd_raw, inc, wspd))
@@ -213,6 +232,7 @@ class Context:
             len(phi) if has_phi else 0, _ptr(out)), "xsw_lut_interp")
         return out
 
+    @_locked
     def gmf_eval(self, gmf_id, inc, wspd, phi=None):
         """xsw_gmf_eval on host float64 arrays of one common shape."""
         inc = _f64(inc)
@@ -225,14 +245,17 @@ class Context:
                                            _ptr(out)), "xsw_gmf_eval")
         return out
 
+    @_locked
     def stats_enable(self, on=True):
         self._check(self._lib.xsw_stats_enable(self._h, int(bool(on))), "xsw_stats_enable")
 
+    @_locked
     def stats(self):
         s = Stats()
         self._check(self._lib.xsw_stats_read(self._h, ctypes.byref(s)), "xsw_stats_read")
         return {k: int(getattr(s, k)) for k, _ in Stats._fields_}
 
+    @_locked
     def invert_raw(self, lines, samples, dtype, out_dtype, mem, inc, sigma0_co, sigma0_cr, dsig_cr, anc, out_co,
                    out_cr, out_idx=None, dsig_co=0.1, dsig_cr_scalar=0.1, sigma0_is_db=False, algo=ALGO_AUTO,
                    dual_select=False):
@@ -242,6 +265,7 @@ class Context:
                        float(dsig_cr_scalar), out_co, out_cr, out_idx)
         self._check(self._lib.xsw_invert(self._h, ctypes.byref(a)), "xsw_invert")
 
+    @_locked
     def invert_host(self, inc, sigma0_co=None, sigma0_cr=None, dsig_cr=None, anc=None, dsig_co=0.1,
                     sigma0_is_db=False, algo="auto", dual_select=False, out_dtype=np.complex128, want_idx=False):
         """numpy-in / numpy-out wrapper of xsw_invert for host rasters of one dtype (float32 or float64)."""
@@ -281,6 +305,7 @@ class Context:
                             _ptr(idx), dsig_co, dsig_scalar, sigma0_is_db, ALGOS.get(algo, algo), dual_select)
         return out_co, out_cr, idx
 
+    @_locked
     def detrend_raw(self, lines, samples, dtype, out_dtype, mem, sigma0_ptr, ratio_row, out_ptr):
         """Thin call of xsw_detrend (raster pointers are ints; ratio_row is a host float64 array)."""
         ratio_row = _f64(ratio_row)
@@ -288,6 +313,7 @@ class Context:
                                           ctypes.c_void_p(sigma0_ptr), _ptr(ratio_row), ctypes.c_void_p(out_ptr)),
                     "xsw_detrend")
 
+    @_locked
     def detrend_host(self, sigma0, ratio_row, out_dtype=np.float64):
         sigma0 = np.ascontiguousarray(sigma0)
         if sigma0.dtype not in (np.float32, np.float64):
@@ -304,10 +330,12 @@ class Context:
 
 
 _default_ctx = {}
+_default_ctx_lock = threading.Lock()
 
 
 def default_context(device=0):
     """Process-wide context per device (created on first use)."""
-    if device not in _default_ctx:
-        _default_ctx[device] = Context(device)
-    return _default_ctx[device]
+    with _default_ctx_lock:
+        if device not in _default_ctx:
+            _default_ctx[device] = Context(device)
+        return _default_ctx[device]

@@ -117,7 +117,6 @@ def invert_numpy(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_c
     and widens in registers, which is the same arithmetic.
     """
     ctx = _lib.default_context(options.device)
-    ensure_luts(ctx, lut_co if sigma0_co is not None else None, lut_cr if sigma0_cr is not None else None)
     inc = np.asarray(inc)
     shape = inc.shape
     rasters = [a for a in (inc, sigma0_co, sigma0_cr, None if np.isscalar(dsig_cr) else dsig_cr) if a is not None]
@@ -141,9 +140,15 @@ def invert_numpy(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_c
         elif dt == np.float32:
             dsig_cr = float(np.float32(dsig_cr))
     cast = lambda a, t: None if a is None else np.ascontiguousarray(np.broadcast_to(np.asarray(a), shape), dtype=t)
-    out_co, out_cr, _ = ctx.invert_host(
+    with ctx.lock:  # LUT upload + inversion as one step: another thread may want other LUTs on the same context
+        ensure_luts(ctx, lut_co if sigma0_co is not None else None, lut_cr if sigma0_cr is not None else None)
+        out_co, out_cr, _ = _invert(ctx, cast, dt, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_co, is_db)
+    return out_co, out_cr  # None where that search did not run (the caller never reads it)
+
+
+def _invert(ctx, cast, dt, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_co, is_db):
+    return ctx.invert_host(
         cast(inc, dt), sigma0_co=cast(sigma0_co, dt), sigma0_cr=cast(sigma0_cr, dt),
         dsig_cr=dsig_cr if (dsig_cr is None or np.isscalar(dsig_cr)) else cast(dsig_cr, dt),
         anc=cast(anc, np.complex64 if dt == np.float32 else np.complex128), dsig_co=dsig_co, sigma0_is_db=is_db,
         algo=options.algo, out_dtype=np.complex128)
-    return out_co, out_cr  # None where that search did not run (the caller never reads it)
