@@ -1,0 +1,48 @@
+"""One-off campaign: branch-and-bound kernel vs exhaustive sweep (independent code path) on whole large rasters, several
+LUTs / dsig_co / scenes.  Prints the number of differing pixels per configuration (expected: 0 everywhere)."""
+import sys, os, time, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, bench
+from xsarsea_amd import _lib
+from xsarsea_amd.windspeed import _engine, get_model
+dev = torch.device("cuda", 0)
+ctx = _lib.Context(0)
+
+def run(tag, co, n_lines, n_samples, seed, dsig_co=0.1, algo_ref="exhaustive", scale_anc=1.0, inc_shift=0.0):
+    ctx.upload_luts(co=co)
+    inc, s, anc = bench.make_scene(n_lines, n_samples, n_lines, 0, seed, dev)
+    if inc_shift:
+        inc = inc + inc_shift
+    if scale_anc != 1.0:
+        anc = anc * scale_anc
+    a = torch.empty((n_lines, n_samples), dtype=torch.complex64, device=dev); b = torch.empty_like(a)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for out, algo in ((a, "pruned"), (b, algo_ref)):
+        ctx.invert_raw(n_lines, n_samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, inc.data_ptr(), s.data_ptr(), None, None,
+                       anc.data_ptr(), out.data_ptr(), None, dsig_co=dsig_co, algo=_lib.ALGOS[algo])
+    ctx.synchronize()
+    d = int((torch.view_as_real(a).view(torch.int32) != torch.view_as_real(b).view(torch.int32)).any(dim=-1).sum().item())
+    nan = int(torch.isnan(a.real).sum().item())
+    print(f"{tag}: {n_lines}x{n_samples} px, differing pixels = {d}, NaN = {nan}, {time.perf_counter()-t:.1f} s", flush=True)
+    return d
+
+total = 0
+lut = get_model("gmf_cmod5n")._lut(units="dB"); co = _engine._co_dict(lut)
+for seed in (11, 12):
+    total += run(f"default LUT seed {seed}", co, 20000, 20000, seed)
+total += run("default LUT, dsig_co 0.05", co, 12000, 20000, 13, dsig_co=0.05)
+total += run("default LUT, dsig_co 0.4", co, 8000, 20000, 14, dsig_co=0.4)
+total += run("default LUT, ancillary x0.3 (far from sigma0)", co, 8000, 20000, 15, scale_anc=0.3)
+total += run("default LUT, ancillary x2.5", co, 8000, 20000, 16, scale_anc=2.5)
+total += run("default LUT, incidence +12 deg (42..58)", co, 8000, 20000, 17, inc_shift=12.0)
+low = get_model("gmf_cmod5n")._lut(units="dB", resolution="low"); col = _engine._co_dict(low)
+total += run("low-res LUT", col, 20000, 20000, 18)
+# 0..360 axis (phi_180 False): mirror the default LUT
+v = np.asarray(lut.values); phi = np.asarray(lut.phi)
+v360 = np.concatenate([v, v[..., -2::-1]], axis=-1); phi360 = np.concatenate([phi, 360.0 - phi[-2::-1]])
+co360 = dict(db=np.ascontiguousarray(v360), inc=lut.incidence, wspd=lut.wspd, phi=phi360, **_engine.host_tables(lut.wspd, phi360))
+total += run("0..360 LUT (501x499x361)", co360, 6000, 20000, 19)
+cm5 = get_model("gmf_cmod5")._lut(units="dB")
+total += run("CMOD5 LUT", _engine._co_dict(cm5), 8000, 20000, 20)
+print("TOTAL differing pixels:", total)
