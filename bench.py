@@ -251,7 +251,7 @@ def main():
 
     # N > 1: the tile is inverted in row chunks so that chunk k travels to rank 0 over xGMI while chunk k+1
     # is being inverted (RCCL runs on its own stream; requests are waited for at the end of the step)
-    n_chunks = 4 if world > 1 else 1
+    n_chunks = 8 if world > 1 else 1  # the last chunk's transfer is the only exposed one: 1/8 of a tile
     bounds = [(lines * c // n_chunks, lines * (c + 1) // n_chunks) for c in range(n_chunks)]
     es_in = 4   # float32 rasters
     pending = []
