@@ -281,9 +281,12 @@ struct CoWindow {
 #ifndef XSW_SEG8
 #define XSW_SEG8 1
 #endif
+#ifndef XSW_SEG4
+#define XSW_SEG4 1
+#endif
 __device__ __forceinline__ int seg_lanes(int width)
 {
-    return (XSW_SEG8 && width <= 8) ? 8 : (width <= 16 ? 16 : ((XSW_SEG32 && width <= 32) ? 32 : 64));
+    return (XSW_SEG4 && width <= 4) ? 4 : ((XSW_SEG8 && width <= 8) ? 8 : (width <= 16 ? 16 : ((XSW_SEG32 && width <= 32) ? 32 : 64)));
 }
 __device__ __forceinline__ void chunk_geom(int width, int nrows, int S, int &geom, int &mdiv)
 {
@@ -498,7 +501,7 @@ template <int S> __device__ __forceinline__ double seg_min_d(double v)
 {
     v = vmin(v, dpp_d<0xB1, 0xF>(v));   // lane ^ 1
     v = vmin(v, dpp_d<0x4E, 0xF>(v));   // lane ^ 2
-    v = vmin(v, dpp_d<0x141, 0xF>(v));  // 8-lane halves mirrored: every lane of an 8-lane group holds the group minimum
+    if (S >= 8) v = vmin(v, dpp_d<0x141, 0xF>(v));  // 8-lane halves mirrored: every lane of an 8-lane group holds its minimum
     if (S >= 16) v = vmin(v, dpp_d<0x140, 0xF>(v));  // 16-lane rows mirrored
     if (S == 32) v = vmin(v, __shfl_xor(v, 16));
     return v;
@@ -921,15 +924,17 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTa
         if (L.co_off32) {
             const int ncols_p = W.ip_hi - W.ip_lo + 1;
             const bool elig = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0;
-            unsigned long long m8 = __ballot(XSW_SEG8 && elig && ncols_p <= 8);
-            unsigned long long m16 = __ballot(elig && ncols_p <= 16) & ~m8, m32 = __ballot(XSW_SEG32 && elig && ncols_p > 16 && ncols_p <= 32);
-            relay = m8 | m16 | m32;
+            unsigned long long m4 = __ballot(XSW_SEG4 && elig && ncols_p <= 4);
+            unsigned long long m8 = __ballot(XSW_SEG8 && elig && ncols_p <= 8) & ~m4;
+            unsigned long long m16 = __ballot(elig && ncols_p <= 16) & ~(m8 | m4), m32 = __ballot(XSW_SEG32 && elig && ncols_p > 16 && ncols_p <= 32);
+            relay = m4 | m8 | m16 | m32;
             if (A.stats) {
                 unsigned c = ((relay >> lane) & 1ULL) ? (unsigned)((W.w_hi - W.w_lo + 1) * ncols_p) : 0u;
                 for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
                 cand += c;
             }
             unsigned long long redo = 0;
+            while (m4) co_seg_pass<4>(L, P, W, A.inv_dsig_co, lane, m4, my_flat, redo);
             while (m8) co_seg_pass<8>(L, P, W, A.inv_dsig_co, lane, m8, my_flat, redo);
             while (m16) co_seg_pass<16>(L, P, W, A.inv_dsig_co, lane, m16, my_flat, redo);
             while (m32) co_seg_pass<32>(L, P, W, A.inv_dsig_co, lane, m32, my_flat, redo);
