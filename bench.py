@@ -335,7 +335,7 @@ def main():
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"CMOD5.N mono-VV inversion, {lines}x{samples} float32 sigma0/incidence + complex64 "
+            "config": {"workload": f"CMOD5.N {'mono-VV' if args.mode == 'mono' else 'dual-pol (VV + S1 VH GMF)'} inversion, {lines}x{samples} float32 sigma0/incidence + complex64 "
                                    f"ancillary per GPU, {'default' if args.resolution == 'high' else 'resolution=low'} LUT "
                                    f"{'x'.join(str(int(x)) for x in lut.shape)} ({int(lut.shape[1] * lut.shape[2])} candidates/pixel), "
                                    f"complex64 out, algo={args.algo}, mode={args.mode}",
