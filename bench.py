@@ -171,6 +171,47 @@ def cpu_baseline_and_parity(ctx, inc, s_vv, anc, algo, budget_s=14.0):
     return cpu, parity
 
 
+def bench_detrend(args, ctx, stream, s_vv, lines, samples):
+    """`sigma0 / ratio_row` (detrend.py:63-64) on the resident float32 raster -> float64: 4 B read + 8 B written per pixel."""
+    from xsarsea_amd import _lib
+    det = torch.empty((lines, samples), dtype=torch.float64, device=s_vv.device)
+    ratio = np.random.default_rng(0).uniform(0.5, 2.0, samples)
+
+    def step():
+        ctx.detrend_raw(lines, samples, _lib.XSW_F32, _lib.XSW_F64, _lib.MEM_DEVICE, s_vv.data_ptr(), ratio, det.data_ptr())
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)
+        step()
+        b.record(stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    px = lines * samples
+    achieved = 12.0 * px / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(REPO, "profiles", "r01_f_hbm_traffic_summary.json")
+    if os.path.exists(tfile) and (lines, samples) == (20000, 20000):
+        try:  # k_detrend is the calibration kernel of the traffic passes: WRITE_SIZE is exact, FETCH_SIZE x the gfx950 factor 2
+            raw = json.load(open(tfile))["raw_KiB"]["k_detrend"]
+            traffic = int(raw["WRITE_SIZE"] * 1024 + 2.0 * raw["FETCH_SIZE"] * 1024)
+        except Exception:
+            traffic = None
+    print(json.dumps({
+        "metric": "Mpixels/s sigma0_detrend", "value": round(px * args.steps / dt / 1e6, 1), "unit": "Mpixels/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"sigma0_detrend kernel, {lines}x{samples} float32 sigma0 -> float64, one divisor per sample"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "k_detrend",
+                     "kernel_ms": round(kernel_ms, 4), "bytes_per_pixel": 12}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,8 +220,9 @@ def main():
     ap.add_argument("--lines", type=int, default=20000)
     ap.add_argument("--samples", type=int, default=20000)
     ap.add_argument("--algo", default="pruned", choices=["pruned", "exhaustive", "exhaustive_f64", "exact"])
-    ap.add_argument("--mode", default="mono", choices=["mono", "dual"],
-                    help="mono: CMOD5.N VV (the metric's workload); dual: + Sentinel-1 VH GMF cross-pol refinement (config 3)")
+    ap.add_argument("--mode", default="mono", choices=["mono", "dual", "detrend"],
+                    help="mono: CMOD5.N VV (the metric's workload); dual: + Sentinel-1 VH GMF cross-pol refinement (config 3); "
+                         "detrend: the sigma0_detrend kernel alone (the HBM-bound kernel of the path; N = 1 only)")
     ap.add_argument("--resolution", default="high", choices=["high", "low"],
                     help="LUT resolution passed to Model.to_lut: high = the reference default 501x499x181, low = 51x250x73 "
                          "(a parity-test configuration, SURVEY 8d; implies no CPU baseline / exhaustive figure)")
@@ -223,6 +265,8 @@ def main():
 
     lines, samples = args.lines, args.samples
     inc, s_vv, anc = make_scene(lines, samples, lines * n_gpus, rank * lines, 20260320 + 2 + rank, device)
+    if args.mode == "detrend":
+        return bench_detrend(args, ctx, stream, s_vv, lines, samples)
     out = torch.empty((lines, samples), dtype=torch.complex64, device=device)
     s_vh = dsig = out_dual = None
     if args.mode == "dual":
