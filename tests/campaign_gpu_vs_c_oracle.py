@@ -17,17 +17,19 @@ from xsarsea_amd import _lib  # noqa: E402
 from xsarsea_amd.windspeed import _engine, get_model  # noqa: E402
 
 n = int(os.environ.get("XSW_CAMPAIGN_N", "3200"))
+res = os.environ.get("XSW_CAMPAIGN_RES", "high")  # "low": the 51x250x73 / 51x386 LUTs
+kw = {} if res == "high" else {"resolution": "low"}
 dev = torch.device("cuda", 0)
 ctx = _lib.Context(0)
-lco, lcr = get_model("gmf_cmod5n")._lut(units="dB"), get_model("gmf_s1_v2")._lut(units="dB")
+lco, lcr = get_model("gmf_cmod5n")._lut(units="dB", **kw), get_model("gmf_s1_v2")._lut(units="dB", **kw)
 ctx.upload_luts(co=_engine._co_dict(lco), cr=_engine._cr_dict(lcr))
-inc, s_vv, anc = bench.make_scene(n, n, 20000, 8000, 77, dev)
+inc, s_vv, anc = bench.make_scene(n, n, 20000, 8000, int(os.environ.get("XSW_CAMPAIGN_SEED", "77")), dev)
 inc, s_vv, anc = (t.cpu().numpy() for t in (inc, s_vv, anc))
 rng = np.random.default_rng(7)
 s_vh = (s_vv * 0.02 * rng.gamma(100, 1 / 100, s_vv.shape) + 10 ** -3.5).astype(np.float32)
 dsig = ((1.25 / (s_vh / 10 ** -3.5)) ** 4).astype(np.float32)
 sco, scr = oinv.to_db(s_vv), oinv.to_db(s_vh)  # numpy float32 dB, fed to both sides
-prep = oinv.Prepared(olut.to_lut("gmf_cmod5n"), olut.to_lut("gmf_s1_v2"))
+prep = oinv.Prepared(olut.to_lut("gmf_cmod5n", **kw), olut.to_lut("gmf_s1_v2", **kw))
 bad = 0
 for mode in ("mono", "dual"):
     cr_in = (scr, dsig) if mode == "dual" else (None, None)
