@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
 """Benchmark of the wind-inversion hot path on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--lines L] [--samples S] [--algo pruned|exhaustive]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config metric|2|3|4|5] [--scaling strong|weak] ...
 
-One "step" = one pass of `xsw_invert` (CMOD5.N mono-VV, default 0.1 m/s x 1 deg x 0.1 deg LUT) over a
-synthetic float32 raster that is already resident in HBM (sigma0 + incidence + complex64 ancillary
-wind in, complex64 wind out).  N = 1 workload: the 20000 x 20000 raster BASELINE.json's metric is
-quoted on.  N > 1 (launched by torch.distributed.run, one rank per GPU): the raster is row-tiled,
-every rank inverts a 20000-line tile of a (20000*N) x 20000 raster (weak scaling) and the output
-tiles are gathered on rank 0 over RCCL inside the timed step.
+One "step" = one pass of `xsw_invert` (default: CMOD5.N mono-VV, reference-default 0.1 m/s x 1 deg x 0.1 deg LUT)
+over a synthetic float32 raster that is already resident in HBM (sigma0 + incidence + complex64 ancillary wind in,
+complex64 wind out).  N = 1 workload: the 20000 x 20000 raster BASELINE.json's metric is quoted on.
 
-Prints ONE JSON line (rank 0) with the throughput, the HBM roofline of the dominant kernel, and a CPU
-baseline (the oracle's C restatement of the reference kernel, timed on this box's cores on a
-bounded crop of the same raster).
+N > 1: one process per GPU.  `python bench.py --gpus N` starts the N ranks itself (fresh child processes, spawned
+before this process touches a GPU); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
+the ranks are torchrun's.  Default `--scaling strong`: the SAME raster (20000 x 20000, or `--config 4`'s
+25000 x 17000) is row-tiled over the ranks (`multi_gpu.tile_bounds`, the last rank takes the remainder) and the
+output tiles are gathered on rank 0 over RCCL inside the timed step, chunk by chunk behind the kernel.
+`--scaling weak`: every rank inverts a full-size tile of an N-times taller raster.
+
+Prints ONE JSON line (rank 0): throughput, the HBM roofline of the dominant kernel (algorithmic bytes / HIP-event
+kernel time) with the VALU view of the same kernel next to it, the sigma0_detrend kernel (the HBM-bound kernel of
+the path), LUT build/upload time, the bit-parity configuration (sigma0 already in dB), and a CPU baseline (the
+oracle's C restatement of the reference kernel on this box's cores, on a bounded crop of the same raster).
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,9 +36,20 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-BYTES_READ_PX = 16     # inc f32 + sigma0 f32 + ancillary complex64   
-BYTES_WRITE_PX = 8     # complex64 wind
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+LANE_OPS_PEAK = 7.86e13  # 256 CU x 128 lanes x 2.4 GHz, non-packed
+OPS_PER_CANDIDATE = 6    # sub, scale, square-accumulate, separable wind term, compare, select
+BYTES_READ_PX = 16       # inc f32 + sigma0 f32 + ancillary complex64   
+BYTES_WRITE_PX = 8       # complex64 wind
+PROFILE_ROUND = "r02"
+
+CONFIGS = {  # BASELINE.json configs (1 is the CPU plumbing case: tests/test_gpu_api.py::test_sigma0_detrend)
+    "metric": dict(lines=20000, samples=20000, mode="mono", lut="cmod5n", note="the metric's raster"),
+    "2": dict(lines=10000, samples=10000, mode="mono", lut="cmod5n", note="config 2"),
+    "3": dict(lines=20000, samples=20000, mode="dual", lut="cmod5n", note="config 3"),
+    "4": dict(lines=25000, samples=17000, mode="mono", lut="cmod5n", note="config 4 (S1 IW full swath)"),
+    "5": dict(lines=20000, samples=20000, mode="mono", lut="cmod7", note="config 5 (CMOD7-shaped table)"),
+}
 
 
 # ------------------------------------------------------------------------------------------ synthetic scene
@@ -80,7 +98,7 @@ def make_scene(lines, samples, total_lines, line0, seed, device, chunk=500):
     # smooth ancillary noise: coarse 1/64 grid, bilinear upsampling
     ch, cw = lines // 64 + 2, samples // 64 + 2
     coarse = torch.randn((1, 2, ch, cw), generator=g, device=device, dtype=torch.float32) * 1.5
-    noise = torch.nn.functional.interpolate(coarse, size=(lines, samples), mode="bilinear", align_corners=True)[0]
+    noise = torch.nn.functional.interpolate(coarse, size=(max(lines, 1), samples), mode="bilinear", align_corners=True)[0]
     ss = torch.arange(samples, device=device, dtype=torch.float64)[None, :]
     for l0 in range(0, lines, chunk):
         l1 = min(lines, l0 + chunk)
@@ -104,11 +122,51 @@ def make_scene(lines, samples, total_lines, line0, seed, device, chunk=500):
     return inc, s_vv, anc
 
 
+def make_crosspol(inc, anc, seed, device):
+    """Cross-pol rasters of the dual-pol workload: sigma0_vh = S1 VH GMF(inc, |ancillary|) x speckle + NESZ (10^-3.5),
+    dsig_cr = (1.25 / (sigma0_vh / nesz))^4 (windspeed/utils.py:82-86 of the reference).  float32."""
+    from xsarsea_amd.windspeed import gmfs_impl  # scene synthesis only: coefficients of the S1 VH GMF
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    w_abs = anc.abs().clamp(3.0, 80.0).double()  # cross-pol truth ~ the a-priori speed (synthetic)
+    _vh = gmfs_impl._VH_MODELS["gmf_s1_v2"]
+    z1, z2, cc = _vh.z1, _vh.z2, _vh.logistic
+    incd = inc.double().nan_to_num(35.0)
+    sig1 = z1[0] * w_abs ** (z1[1] + z1[2] * incd)
+    sig2 = (z2[0] + z2[1] * incd + z2[2] * incd ** 2) * w_abs ** (z2[3] + z2[4] * incd + z2[5] * incd ** 2)
+    vh = sig1 * torch.sigmoid(cc[0] * (w_abs - cc[1])) + sig2 * torch.sigmoid(cc[2] * (w_abs - cc[3]))
+    speck = torch._standard_gamma(torch.full(vh.shape, 100.0, device=device, dtype=torch.float32), generator=g) / 100.0
+    s_vh = (vh.float() * speck + 10 ** -3.5).contiguous()
+    dsig = ((1.25 / (s_vh / 10 ** -3.5)) ** 4.0).contiguous()
+    return s_vh, dsig
+
+
 # ------------------------------------------------------------------------------------------ helpers
-def build_product_lut(resolution=None):
+def cmod7_shaped_model(tmpdir):
+    """BASELINE config 5: the real CMOD7 table is not distributable, so a CMOD7-FORMAT file (250 x 73 x 51 float32,
+    Fortran order, record markers; cmod7.py:27-40) is synthesised from CMOD5.N x (1 + 5 % smooth perturbation) and
+    read back through the product's own reader + low->high interpolation."""
+    from xsarsea_amd.windspeed import cmod7, gmfs_impl
+    w, p, i = np.arange(1, 251) * 0.2, np.arange(73) * 2.5, np.arange(16, 67) * 1.0
+    table = gmfs_impl._cmod5_sigma0(gmfs_impl._CMOD5N, i[None, None, :], w[:, None, None], p[None, :, None])
+    table = (table * (1 + 0.05 * np.sin(w[:, None, None] / 7.0) * np.cos(np.radians(p[None, :, None])))).astype(np.float32)
+    os.makedirs(tmpdir, exist_ok=True)
+    cmod7.write_cmod7_table(os.path.join(tmpdir, "gmf_cmod7_vv.dat_little_endian"), table)
+    return cmod7.register_cmod7(tmpdir)
+
+
+def build_product_lut(resolution=None, which="cmod5n", timings=None):
     from xsarsea_amd.windspeed import _engine, get_model
     kwargs = {} if resolution in (None, "high") else {"resolution": resolution}
-    lut = get_model("gmf_cmod5n")._lut(units="dB", **kwargs)
+    if which == "cmod7":
+        import tempfile
+        model = cmod7_shaped_model(os.path.join(tempfile.gettempdir(), f"xsw_cmod7_{os.getpid()}"))
+    else:
+        model = get_model("gmf_cmod5n")
+    t0 = time.perf_counter()
+    lut = model._lut(units="dB", **kwargs)
+    if timings is not None:
+        timings["lut_build_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
     return lut, _engine._co_dict(lut)
 
 
@@ -118,7 +176,6 @@ def cpu_baseline_and_parity(ctx, inc, s_vv, anc, algo, budget_s=14.0):
     from oracle import cport
     from oracle import invert as oinv
     from oracle import lut as olut
-    from xsarsea_amd import _lib
     lco = olut.to_lut("gmf_cmod5n")
     prep = oinv.Prepared(lco, None)
     cores = cport.max_threads()
@@ -167,12 +224,42 @@ def cpu_baseline_and_parity(ctx, inc, s_vv, anc, algo, budget_s=14.0):
         "index_match_host_db": float(np.mean(np.all(g_strict[2][..., :2] == o_idx[..., :2], axis=-1))),
         "index_match_device_db": float(np.mean(np.all(g_fused[2][..., :2] == o_idx[..., :2], axis=-1))),
         "max_rel_err_uv_c64": rel_err(g_strict),
+        "lut_interp": "unpinned vs xarray.interp (restated as sequential scipy interp1d; DESIGN.md 6)",
     }
     return cpu, parity
 
 
-def bench_detrend(args, ctx, stream, s_vv, lines, samples):
-    """`sigma0 / ratio_row` (detrend.py:63-64) on the resident float32 raster -> float64: 4 B read + 8 B written per pixel."""
+def _profile_json(name):
+    try:
+        with open(os.path.join(REPO, "profiles", name)) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def time_steps(step, steps, warmup, stream, after=None):
+    """W untimed + K timed calls of step(); returns (wall seconds of the K steps, mean HIP-event ms of step())."""
+    for _ in range(warmup):
+        step()
+        if after:
+            after()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)
+        step()
+        b.record(stream)
+        if after:
+            after()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dt, float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+
+def detrend_figures(args, ctx, stream, s_vv, lines, samples):
+    """`sigma0 / ratio_row` (detrend.py:63-64) on the resident float32 raster -> float64: 4 B read + 8 B written per
+    pixel -- the one HBM-bound kernel of the path."""
     from xsarsea_amd import _lib
     det = torch.empty((lines, samples), dtype=torch.float64, device=s_vv.device)
     ratio = np.random.default_rng(0).uniform(0.5, 2.0, samples)
@@ -180,36 +267,64 @@ def bench_detrend(args, ctx, stream, s_vv, lines, samples):
     def step():
         ctx.detrend_raw(lines, samples, _lib.XSW_F32, _lib.XSW_F64, _lib.MEM_DEVICE, s_vv.data_ptr(), ratio, det.data_ptr())
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for a, b in ev:
-        a.record(stream)
-        step()
-        b.record(stream)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    dt, kernel_ms = time_steps(step, args.steps, max(args.warmup, 1), stream)
+    del det
     px = lines * samples
     achieved = 12.0 * px / (kernel_ms * 1e-3) / 1e9
     traffic = None
-    tfile = os.path.join(REPO, "profiles", "r01_f_hbm_traffic_summary.json")
-    if os.path.exists(tfile) and (lines, samples) == (20000, 20000):
+    tj = _profile_json(f"{PROFILE_ROUND}_hbm_traffic_summary.json") or _profile_json("r01_f_hbm_traffic_summary.json")
+    if tj and (lines, samples) == (20000, 20000):
         try:  # k_detrend is the calibration kernel of the traffic passes: WRITE_SIZE is exact, FETCH_SIZE x the gfx950 factor 2
-            raw = json.load(open(tfile))["raw_KiB"]["k_detrend"]
+            raw = tj["raw_KiB"]["k_detrend"]
             traffic = int(raw["WRITE_SIZE"] * 1024 + 2.0 * raw["FETCH_SIZE"] * 1024)
         except Exception:
             traffic = None
-    print(json.dumps({
-        "metric": "Mpixels/s sigma0_detrend", "value": round(px * args.steps / dt / 1e6, 1), "unit": "Mpixels/s", "n_gpus": 1,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"sigma0_detrend kernel, {lines}x{samples} float32 sigma0 -> float64, one divisor per sample"},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "k_detrend",
-                     "kernel_ms": round(kernel_ms, 4), "bytes_per_pixel": 12}}))
+    return {"workload": f"sigma0_detrend kernel, {lines}x{samples} float32 sigma0 -> float64, one divisor per sample",
+            "value": round(px * args.steps / dt / 1e6, 1), "unit": "Mpixels/s", "kernel": "k_detrend",
+            "kernel_ms": round(kernel_ms, 4), "bytes_per_pixel": 12,
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_copy_rate_6290": round(achieved / 6290.0, 4),
+                         "traffic": traffic}}
+
+
+# ------------------------------------------------------------------------------------------ rank launcher
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without torchrun: start N fresh rank processes (this process has made no GPU call and
+    makes none: a process that has initialised the GPU must never exec/fork workers on this pool)."""
+    one_dev = os.environ.get("XSW_BENCH_ONE_DEVICE") == "1"
+    have = torch.cuda.device_count()  # does not initialise the GPU
+    if not one_dev and have < n:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    deadline = None
+    while procs:
+        for p in list(procs):
+            code = p.poll()
+            if code is None:
+                continue
+            procs.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                deadline = time.time() + 30.0  # a rank failed: give the others a moment, then stop them
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                p.kill()
+            deadline = None
+        time.sleep(0.05)
+    return rc
 
 
 def main():
@@ -217,27 +332,45 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--lines", type=int, default=20000)
-    ap.add_argument("--samples", type=int, default=20000)
+    ap.add_argument("--config", default="metric", choices=sorted(CONFIGS),
+                    help="BASELINE.json workload: metric = CMOD5.N mono 20000x20000 (default), 2 = 10000x10000 mono, "
+                         "3 = dual-pol 20000x20000, 4 = 25000x17000 mono (row-tiled), 5 = CMOD7-shaped LUT 20000x20000")
+    ap.add_argument("--lines", type=int, default=None)
+    ap.add_argument("--samples", type=int, default=None)
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = the configured raster is row-tiled over the ranks (default); "
+                         "weak = every rank inverts a full-size tile of an N-times taller raster")
     ap.add_argument("--algo", default="pruned", choices=["pruned", "exhaustive", "exhaustive_f64", "exact"])
-    ap.add_argument("--mode", default="mono", choices=["mono", "dual", "detrend"],
-                    help="mono: CMOD5.N VV (the metric's workload); dual: + Sentinel-1 VH GMF cross-pol refinement (config 3); "
-                         "detrend: the sigma0_detrend kernel alone (the HBM-bound kernel of the path; N = 1 only)")
+    ap.add_argument("--mode", default=None, choices=["mono", "dual", "detrend"],
+                    help="override the config's mode; detrend: the sigma0_detrend kernel alone (N = 1 only)")
     ap.add_argument("--resolution", default="high", choices=["high", "low"],
                     help="LUT resolution passed to Model.to_lut: high = the reference default 501x499x181, low = 51x250x73 "
                          "(a parity-test configuration, SURVEY 8d; implies no CPU baseline / exhaustive figure)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--stats", action="store_true", help="also report evaluated candidates per pixel (extra pass)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the detrend / dB-parity / exhaustive side figures")
+    ap.add_argument("--verify-gather", action="store_true",
+                    help="N > 1: rank 0 rebuilds every rank's input tile, inverts the whole raster in ONE launch and compares "
+                         "it bit for bit with the gathered raster (exit code 3 on a mismatch)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
     # rehearsal knobs (never set by the driver): XSW_BENCH_BACKEND=gloo and XSW_BENCH_ONE_DEVICE=1 let the whole N > 1
     # code path run as several ranks on a one-GPU box (everything but RCCL itself)
     backend = os.environ.get("XSW_BENCH_BACKEND", "nccl")
     if os.environ.get("XSW_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -245,86 +378,92 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        if dist.get_world_size() != args.gpus:
+            sys.exit(2)
     n_gpus = world
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
+    cfg = dict(CONFIGS[args.config])
+    mode = args.mode or cfg["mode"]
+    total_lines = args.lines or cfg["lines"]
+    samples = args.samples or cfg["samples"]
+    if args.scaling == "weak":
+        total_lines *= world
+
     import xsarsea_amd
-    from xsarsea_amd import _lib
+    from xsarsea_amd import _lib, multi_gpu
     xsarsea_amd.options.device = local_rank  # one process per GPU: LUT preparation also runs on this rank's device
-    lut, co_dict = build_product_lut(args.resolution)
-    if args.resolution != "high":
+    timings = {}
+    lut, co_dict = build_product_lut(args.resolution, cfg["lut"], timings)
+    if args.resolution != "high" or cfg["lut"] != "cmod5n":
         args.no_cpu_baseline = True
     ctx = _lib.Context(local_rank)
     stream = torch.cuda.Stream(device=device)  # the kernels, the events and RCCL all use this stream
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
+    t0 = time.perf_counter()
     ctx.upload_luts(co=co_dict)
+    ctx.synchronize()
+    timings["lut_upload_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
 
-    lines, samples = args.lines, args.samples
-    inc, s_vv, anc = make_scene(lines, samples, lines * n_gpus, rank * lines, 20260320 + 2 + rank, device)
-    if args.mode == "detrend":
-        return bench_detrend(args, ctx, stream, s_vv, lines, samples)
+    l0, l1 = multi_gpu.tile_bounds(total_lines, world, rank)  # this rank's row tile (windspeed.py:356-364: row blocks)
+    lines = l1 - l0
+    inc, s_vv, anc = make_scene(lines, samples, total_lines, l0, 20260320 + 2 + rank, device)
+    if mode == "detrend":
+        if rank == 0:
+            d = detrend_figures(args, ctx, stream, s_vv, lines, samples)
+            print(json.dumps({
+                "metric": "Mpixels/s sigma0_detrend", "value": d["value"], "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": d["kernel_ms"], "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": d["workload"]},
+                "roofline": dict(d["roofline"], kernel="k_detrend", kernel_ms=d["kernel_ms"], bytes_per_pixel=12)}))
+        return
     out = torch.empty((lines, samples), dtype=torch.complex64, device=device)
     s_vh = dsig = out_dual = None
-    if args.mode == "dual":
+    if mode == "dual":
         from xsarsea_amd.windspeed import _engine, get_model
         ctx.upload_luts(cr=_engine._cr_dict(get_model("gmf_s1_v2")._lut(units="dB")))
-        g = torch.Generator(device=device)
-        g.manual_seed(777 + rank)
-        w_abs = anc.abs().clamp(3.0, 80.0).double()  # cross-pol truth ~ the a-priori speed (synthetic)
-        from xsarsea_amd.windspeed import gmfs_impl  # scene synthesis only: coefficients of the S1 VH GMF
-        _vh = gmfs_impl._VH_MODELS["gmf_s1_v2"]
-        z1, z2, cc = _vh.z1, _vh.z2, _vh.logistic
-        incd = inc.double().nan_to_num(35.0)
-        sig1 = z1[0] * w_abs ** (z1[1] + z1[2] * incd)
-        sig2 = (z2[0] + z2[1] * incd + z2[2] * incd ** 2) * w_abs ** (z2[3] + z2[4] * incd + z2[5] * incd ** 2)
-        vh = sig1 * torch.sigmoid(cc[0] * (w_abs - cc[1])) + sig2 * torch.sigmoid(cc[2] * (w_abs - cc[3]))
-        speck = torch._standard_gamma(torch.full(vh.shape, 100.0, device=device, dtype=torch.float32), generator=g) / 100.0
-        s_vh = (vh.float() * speck + 10 ** -3.5).contiguous()
-        dsig = ((1.25 / (s_vh / 10 ** -3.5)) ** 4.0).contiguous()
+        s_vh, dsig = make_crosspol(inc, anc, 777 + rank, device)
         out_dual = torch.empty((lines, samples), dtype=torch.complex64, device=device)
-        del w_abs, incd, sig1, sig2, vh, speck
-    full = None  # rank 0: the gathered (lines * N) x samples raster
+    full = full_dual = None  # rank 0: the gathered total_lines x samples raster(s)
     if world > 1 and rank == 0:
-        full = torch.empty((lines * world, samples), dtype=torch.complex64, device=device)
+        full = torch.empty((total_lines, samples), dtype=torch.complex64, device=device)
+        if mode == "dual":
+            full_dual = torch.empty((total_lines, samples), dtype=torch.complex64, device=device)
     algo = _lib.ALGOS[args.algo]
-    from xsarsea_amd import multi_gpu
 
     # N > 1: the tile is inverted in row chunks so that chunk k travels to rank 0 over xGMI while chunk k+1
     # is being inverted (RCCL runs on its own stream; requests are waited for at the end of the step)
     n_chunks = 8 if world > 1 else 1  # the last chunk's transfer is the only exposed one: 1/8 of a tile
-    bounds = [(lines * c // n_chunks, lines * (c + 1) // n_chunks) for c in range(n_chunks)]
-    es_in = 4   # float32 rasters
     pending = []
 
-    def step_chunked():
-        for (r0, r1) in bounds:
-            off = r0 * samples
-            ctx.invert_raw(r1 - r0, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, inc.data_ptr() + off * es_in,
-                           s_vv.data_ptr() + off * es_in, None, None, anc.data_ptr() + off * 8, out.data_ptr() + off * 8,
-                           None, algo=algo)
-            pending.extend(multi_gpu.gather_rows_async(out, lines * world, r0, r1, dst=0, out=full))
+    def invert_rows(r0, r1, s0_ptr=None, is_db=False):
+        off = r0 * samples
+        co_ptr = (s0_ptr if s0_ptr is not None else s_vv.data_ptr()) + off * 4
+        if mode == "dual":
+            ctx.invert_raw(r1 - r0, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, inc.data_ptr() + off * 4, co_ptr,
+                           s_vh.data_ptr() + off * 4, dsig.data_ptr() + off * 4, anc.data_ptr() + off * 8,
+                           out.data_ptr() + off * 8, out_dual.data_ptr() + off * 8, algo=algo, dual_select=True,
+                           sigma0_is_db=is_db)
+        else:
+            ctx.invert_raw(r1 - r0, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, inc.data_ptr() + off * 4, co_ptr,
+                           None, None, anc.data_ptr() + off * 8, out.data_ptr() + off * 8, None, algo=algo,
+                           sigma0_is_db=is_db)
 
     def step():
-        if world > 1 and args.mode == "mono":
-            return step_chunked()
-        if args.mode == "dual":
-            ctx.invert_raw(lines, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, inc.data_ptr(), s_vv.data_ptr(),
-                           s_vh.data_ptr(), dsig.data_ptr(), anc.data_ptr(), out.data_ptr(), out_dual.data_ptr(),
-                           algo=algo, dual_select=True)
-        else:
-            ctx.invert_raw(lines, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, inc.data_ptr(), s_vv.data_ptr(),
-                           None, None, anc.data_ptr(), out.data_ptr(), None, algo=algo)
+        for k in range(n_chunks):
+            r0, r1 = multi_gpu.chunk_bounds(lines, n_chunks, k)
+            if r1 > r0:
+                invert_rows(r0, r1)
+            if world > 1:
+                pending.extend(multi_gpu.gather_chunk_async(out, total_lines, k, n_chunks, dst=0, out=full))
+                if mode == "dual":
+                    pending.extend(multi_gpu.gather_chunk_async(out_dual, total_lines, k, n_chunks, dst=0, out=full_dual))
 
     def gather():
-        if world > 1 and args.mode == "mono":
-            while pending:  # the single exchange of the path, started chunk by chunk inside step()
-                pending.pop().wait()
-        elif world > 1:
-            multi_gpu.gather_rows(out, lines * world, dst=0, out=full)
+        while pending:  # the single exchange of the path, started chunk by chunk inside step()
+            pending.pop().wait()
 
     def fence():
         torch.cuda.synchronize()
@@ -345,61 +484,126 @@ def main():
         gather()
     fence()
     dt = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # the step's kernels on this rank (HIP events, launch stream)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    stats = None
-    if args.stats:
-        ctx.stats_enable(True)
-        step()
-        gather()
-        fence()
-        stats = ctx.stats()
-        ctx.stats_enable(False)
+    # evaluated-work counters: one extra, untimed pass with the device-side statistics on
+    ctx.stats_enable(True)
+    step()
+    gather()
+    fence()
+    stats = ctx.stats()
+    ctx.stats_enable(False)
+    if world > 1:
+        t = torch.tensor([stats["pixels_co"], stats["cand_co"], stats["pixels_exact"]], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        stats["pixels_co"], stats["cand_co"], stats["pixels_exact"] = (int(x) for x in t.tolist())
+        t = torch.tensor([kernel_ms], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        kernel_ms_max = float(t.item())
+    else:
+        kernel_ms_max = kernel_ms
+
+    gather_ok = None
+    if args.verify_gather and world > 1 and rank == 0:
+        parts = [make_scene(b1 - b0, samples, total_lines, b0, 20260320 + 2 + r, device)
+                 for r, (b0, b1) in enumerate(multi_gpu.tile_bounds(total_lines, world, r) for r in range(world))]
+        w_inc, w_s, w_anc = (torch.cat([p[i] for p in parts]) for i in range(3))
+        w_vh = w_dsig = w_dual = None
+        if mode == "dual":
+            cps = [make_crosspol(p[0], p[2], 777 + r, device) for r, p in enumerate(parts)]
+            w_vh, w_dsig = torch.cat([c[0] for c in cps]), torch.cat([c[1] for c in cps])
+            w_dual = torch.empty((total_lines, samples), dtype=torch.complex64, device=device)
+        del parts
+        w_out = torch.empty((total_lines, samples), dtype=torch.complex64, device=device)
+        ctx.invert_raw(total_lines, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, w_inc.data_ptr(), w_s.data_ptr(),
+                       w_vh.data_ptr() if mode == "dual" else None, w_dsig.data_ptr() if mode == "dual" else None,
+                       w_anc.data_ptr(), w_out.data_ptr(), w_dual.data_ptr() if mode == "dual" else None, algo=algo,
+                       dual_select=(mode == "dual"))
+        torch.cuda.synchronize()
+        bits = lambda t: torch.view_as_real(t).view(torch.int32)
+        gather_ok = bool(torch.equal(bits(w_out), bits(full)))
+        if mode == "dual":
+            gather_ok = gather_ok and bool(torch.equal(bits(w_dual), bits(full_dual)))
+        del w_inc, w_s, w_anc, w_out, w_vh, w_dsig, w_dual
 
     if rank == 0:
-        px_step = lines * samples * n_gpus
-        value = px_step * args.steps / dt / 1e6
-        bytes_px = (BYTES_READ_PX + BYTES_WRITE_PX) if args.mode == "mono" else (24 + 16)  # dual: +vh, +dsig; 2 outputs
-        achieved = bytes_px * lines * samples / (kernel_ms * 1e-3) / 1e9
+        px_total = total_lines * samples
+        value = px_total * args.steps / dt / 1e6
+        bytes_px = (BYTES_READ_PX + BYTES_WRITE_PX) if mode == "mono" else (24 + 16)  # dual: +vh, +dsig; 2 outputs
+        achieved = bytes_px * lines * samples / (kernel_ms * 1e-3) / 1e9  # rank 0's tile / rank 0's kernel time
+        is_metric_shape = (mode == "mono" and args.resolution == "high" and cfg["lut"] == "cmod5n" and args.algo == "pruned"
+                           and (lines, samples) == (20000, 20000))
         traffic = None
-        tfile = os.path.join(REPO, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile):
+        tj = _profile_json("hbm_traffic.json")
+        if tj and is_metric_shape:
+            traffic = tj.get("pruned_20000x20000")
+        cand_full = int(lut.shape[1] * lut.shape[2])
+        evaluated = stats["cand_co"] / max(stats["pixels_co"], 1)
+        lane_ops = OPS_PER_CANDIDATE * stats["cand_co"] / world / (kernel_ms_max * 1e-3) if args.algo == "pruned" else \
+            OPS_PER_CANDIDATE * cand_full * lines * samples / (kernel_ms * 1e-3)
+        valu = {"bound": "valu", "unit": "lane-ops/s", "peak": LANE_OPS_PEAK,
+                "ops_per_candidate": OPS_PER_CANDIDATE,
+                "candidates_per_pixel_full_grid": cand_full,
+                "evaluated_candidates_per_pixel": round(evaluated, 1),
+                "pixels_exact_fallback": stats["pixels_exact"],
+                "achieved": float(f"{lane_ops:.4g}"), "frac": round(lane_ops / LANE_OPS_PEAK, 5),
+                "note": "useful work only: 6 lane-ops x candidates actually scored / kernel time / (256 CU x 128 lanes x 2.4 GHz); "
+                        "the grid has candidates_per_pixel_full_grid points, all but the evaluated ones are excluded by an exact bound"}
+        sq = _profile_json(f"{PROFILE_ROUND}_pmc_sq_summary.json") or _profile_json("r01_f_pmc_sq_summary.json")
+        if sq and is_metric_shape:
             try:
-                tj = json.load(open(tfile))
-                key = f"{args.algo}_{lines}x{samples}" if (args.mode == "mono" and args.resolution == "high") else "-"
-                traffic = tj.get(key)
+                pp = sq["per_pixel"]
+                valu["issue"] = {"valu_insts_per_pixel": round(pp["SQ_INSTS_VALU"], 1), "salu_insts_per_pixel": round(pp["SQ_INSTS_SALU"], 1),
+                                 "vmem_rd_insts_per_pixel": round(pp["SQ_INSTS_VMEM_RD"], 1),
+                                 "valu_issue_frac_of_simd_cycles": round(sq["SQ_INSTS_VALU"] * 4.0 / (1024.0 * sq["GRBM_GUI_ACTIVE"] / 8.0), 3)
+                                 if sq.get("GRBM_GUI_ACTIVE") else None,
+                                 "source": f"profiles/{PROFILE_ROUND if _profile_json(f'{PROFILE_ROUND}_pmc_sq_summary.json') else 'r01_f'}_pmc_sq_summary.json "
+                                           "(rocprofv3 --pmc SQ_INSTS_*, same workload; 4 issue cycles per wave64 VALU instruction, 1024 SIMDs, cycles = GRBM_GUI_ACTIVE / 8 XCDs)"}
             except Exception:
-                traffic = None
+                pass
+        mode_txt = "mono-VV" if mode == "mono" else "dual-pol (VV + S1 VH GMF)"
+        par = f"row tiles x{n_gpus}" + (f" ({args.scaling} scaling: {'the same raster split' if args.scaling == 'strong' else 'one full tile per rank'}), "
+                                        f"RCCL gather to rank 0 in the step, {n_chunks} chunks behind the kernel" if n_gpus > 1 else "")
         res = {
             "metric": "Mpixels/s wind inversion (CMOD5.N, 20k x 20k sigma0)",
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"CMOD5.N {'mono-VV' if args.mode == 'mono' else 'dual-pol (VV + S1 VH GMF)'} inversion, {lines}x{samples} float32 sigma0/incidence + complex64 "
-                                   f"ancillary per GPU, {'default' if args.resolution == 'high' else 'resolution=low'} LUT "
-                                   f"{'x'.join(str(int(x)) for x in lut.shape)} ({int(lut.shape[1] * lut.shape[2])} candidates/pixel), "
-                                   f"complex64 out, algo={args.algo}, mode={args.mode}",
-                       "lines_per_gpu": lines, "samples": samples, "lut": [int(x) for x in lut.shape],
-                       "parallelism": f"row tiles x{n_gpus}" + (", RCCL gather to rank 0 in the step" if n_gpus > 1 else "")},
+            "config": {"workload": f"{'CMOD7-shaped table' if cfg['lut'] == 'cmod7' else 'CMOD5.N'} {mode_txt} inversion ({cfg['note']}), "
+                                   f"{total_lines}x{samples} float32 sigma0/incidence + complex64 ancillary, "
+                                   f"{'default' if args.resolution == 'high' else 'resolution=low'} LUT "
+                                   f"{'x'.join(str(int(x)) for x in lut.shape)} ({cand_full} candidates/pixel), "
+                                   f"complex64 out, algo={args.algo}, sigma0 -> dB fused on the device",
+                       "baseline_config": args.config, "lines": total_lines, "samples": samples,
+                       "lines_rank0": lines, "lut": [int(x) for x in lut.shape], "parallelism": par},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel": {"exhaustive": "k_invert_exhaustive32", "exhaustive_f64": "k_invert_exhaustive"}.get(args.algo, "k_invert"),
                          "kernel_ms": round(kernel_ms, 3), "bytes_per_pixel": bytes_px,
-                         "note": f"algorithmic raster bytes ({bytes_px} B read+written per pixel) / mean kernel time "
-                                 "(HIP events on the launch stream); the search itself is VALU-issue bound, see valu"},
+                         "note": f"algorithmic raster bytes ({bytes_px} B read+written per pixel x rank 0's {lines * samples} px) / mean "
+                                 "kernel time of a step (HIP events on the launch stream); the search itself is VALU-issue bound: see valu",
+                         "valu": valu},
+            "lut": timings,
         }
-        # the honest binding resource: float64 VALU issue
-        cand_full = lut.shape[1] * lut.shape[2]
-        res["valu"] = {"algorithmic_candidates_per_pixel": int(cand_full),
-                       "algorithmic_Gcand_per_s": round(cand_full * lines * samples / (kernel_ms * 1e-3) / 1e9, 1)}
-        if stats:
-            res["valu"]["evaluated_candidates_per_pixel"] = round(stats["cand_co"] / max(stats["pixels_co"], 1), 1)
-            res["valu"]["pixels_exact_fallback"] = stats["pixels_exact"]
-        if n_gpus == 1 and args.mode == "mono" and args.algo == "pruned" and not args.no_cpu_baseline:
+        extras = n_gpus == 1 and not args.no_extras
+        if extras and mode == "mono":
+            # the bit-parity configuration for float32 rasters: sigma0 converted to dB by numpy on the host (as the
+            # drop-in API does by default, options.db_on_device="auto") and resident in HBM before the timed region
+            from xsarsea_amd.windspeed import _engine
+            t0 = time.perf_counter()
+            s_db = torch.from_numpy(_engine._to_db(s_vv.cpu().numpy())).to(device)
+            host_db_s = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            dbt, db_ms = time_steps(lambda: invert_rows(0, lines, s_db.data_ptr(), True), args.steps, 1, stream)
+            res["parity_config"] = {"db_mode": "host numpy float32 log10 (bit-parity with the reference CPU path), sigma0_is_db=1",
+                                    "value": round(px_total * args.steps / dbt / 1e6, 3), "unit": "Mpixels/s",
+                                    "kernel_ms": round(db_ms, 3), "host_db_conversion_s_untimed": round(host_db_s, 2)}
+            del s_db
+        if extras and mode == "mono" and args.algo == "pruned" and not args.no_cpu_baseline:
             # like-for-like figure: the literal exhaustive sweep (every one of the 90319 candidates scored per pixel,
             # LUT tiled through LDS, float32 screening + float64 settle) on the first lines of the same raster
             xl = max(4, min(lines, 2000))
@@ -408,25 +612,29 @@ def main():
             def xstep():
                 ctx.invert_raw(xl, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, inc.data_ptr(), s_vv.data_ptr(),
                                None, None, anc.data_ptr(), out.data_ptr(), None, algo=ex_alg)
-            xstep()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            xstep()
-            e1.record(stream)
-            torch.cuda.synchronize()
-            xms = e0.elapsed_time(e1)
+            _, xms = time_steps(xstep, 1, 1, stream)
+            xops = OPS_PER_CANDIDATE * cand_full * xl * samples / (xms * 1e-3)
             res["exhaustive"] = {"value": round(xl * samples / (xms * 1e-3) / 1e6, 3), "unit": "Mpixels/s",
                                  "workload": f"first {xl} lines x {samples} samples of the same raster, every candidate scored",
                                  "kernel": "k_invert_exhaustive32", "kernel_ms": round(xms, 3),
-                                 "Gcand_per_s": round(cand_full * xl * samples / (xms * 1e-3) / 1e9, 1)}
-        if n_gpus == 1 and not args.no_cpu_baseline and args.mode == "mono":
+                                 "valu_frac": round(xops / LANE_OPS_PEAK, 4)}
+        if extras:
+            res["detrend"] = detrend_figures(args, ctx, stream, s_vv, lines, samples)
+        if n_gpus == 1 and not args.no_cpu_baseline and mode == "mono":
             cpu, parity = cpu_baseline_and_parity(ctx, inc, s_vv, anc, args.algo)
             res["cpu_baseline"] = cpu
+            parity["db_mode"] = ("timed value: sigma0 -> dB fused on the device (float32 log10 correctly rounded; index_match_device_db "
+                                 "of pixels agree with numpy's few-ulp float32 log10, the rest differ by one grid step); "
+                                 "parity_config: host-converted dB, index_match_host_db")
             res["parity"] = parity
-        print(json.dumps(res))
+        if gather_ok is not None:
+            res["gather_verified"] = gather_ok
+        print(json.dumps(res), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    if gather_ok is False:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -41,3 +41,23 @@ def gpu_ctx():
     ctx = _lib.Context(0)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture
+def xr_env(monkeypatch):
+    """xarray + dask.array for the container tests: the real packages when installed, else the duck-typed stand-ins of
+    tests/xr_standin.py bound into the product modules (which hold `xr = None` / `da = None` when the imports failed)."""
+    import types
+    try:
+        import dask.array as da
+        import xarray as xr
+        standin = False
+    except ImportError:
+        import xr_standin
+        xr, da, standin = xr_standin.make_xarray_module(), xr_standin.make_dask_array_module(), True
+    import xsarsea_amd.detrend as pdet
+    from xsarsea_amd.windspeed import gmfs, lut, models, windspeed
+    for mod in (pdet, gmfs, lut, models, windspeed):
+        monkeypatch.setattr(mod, "xr", xr)
+    monkeypatch.setattr(windspeed, "da", da)
+    return types.SimpleNamespace(xr=xr, da=da, standin=standin)

@@ -55,6 +55,61 @@ def _worker(rank, world, port, lines, samples, ret):
         dist.destroy_process_group()
 
 
+def _chunk_worker(rank, world, port, lines, samples, n_chunks, ret):
+    """bench.py's N > 1 step minus the kernel: uneven row tiles, every tile cut into n_chunks, chunk k gathered while
+    chunk k+1 "computes"; waits deferred to the end of the step."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = torch.arange(lines * samples, dtype=torch.float32).reshape(lines, samples)
+        full = torch.complex(full, -full)
+        l0, l1 = multi_gpu.tile_bounds(lines, world, rank)
+        tile = torch.zeros((l1 - l0, samples), dtype=full.dtype)
+        glob = torch.full_like(full, float("nan")) if rank == 0 else None
+        reqs = []
+        for k in range(n_chunks):
+            c0, c1 = multi_gpu.chunk_bounds(l1 - l0, n_chunks, k)
+            tile[c0:c1] = full[l0 + c0:l0 + c1] * 3  # stand-in for "invert chunk k of my tile"
+            reqs += multi_gpu.gather_chunk_async(tile, lines, k, n_chunks, dst=0, out=glob)
+        for q in reqs:
+            q.wait()
+        if rank == 0:
+            ret["ok"] = bool(torch.equal(glob, full * 3))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,lines,n_chunks", [(2, 25, 8), (3, 10, 8), (2, 3, 8), (3, 64, 4)])
+def test_gather_chunks_uneven_tiles_gloo(world, lines, n_chunks):
+    """tile_bounds gives the last rank the remainder and a tile may hold fewer lines than chunks (empty chunks)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_chunk_worker, args=(world, _free_port(), lines, 7, n_chunks, ret), nprocs=world, join=True)
+    assert ret.get("ok") is True
+
+
+def test_chunk_bounds_cover_exactly():
+    for n in (0, 1, 7, 8, 9, 3125):
+        for c in (1, 3, 8):
+            spans = [multi_gpu.chunk_bounds(n, c, k) for k in range(c)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a1 == b0 and a0 <= a1 for (a0, a1), (b0, b1) in zip(spans, spans[1:]))
+
+
+def test_bench_refuses_a_rank_count_it_cannot_start():
+    """`bench.py --gpus N` must run N ranks or fail: never print an n_gpus it did not use (checked before any GPU call)."""
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "XSW_BENCH_ONE_DEVICE")}
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 2 and "GPU(s) visible" in r.stderr and r.stdout.strip() == ""
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr and r.stdout.strip() == ""
+
+
 @pytest.mark.parametrize("lines", [9, 64])
 def test_gather_rows_gloo_world2(lines):
     world, samples = 2, 5

@@ -85,16 +85,125 @@ def test_sigma0_detrend(gpu_ctx):
         xsarsea_amd.sigma0_detrend(s, inc, wind_speed_gmf=np.array([5.0, 10.0]))
 
 
-def test_xarray_containers(gpu_ctx, scene):
-    xr = pytest.importorskip("xarray")
+def _kw():
+    return dict(model=("gmf_cmod5n", "gmf_s1_v2"), resolution="low")
+
+
+def test_xarray_containers(gpu_ctx, scene, xr_env):
+    """xarray in -> xarray out (windspeed.py:337-343, :395-438 of the reference): name `windspeed_gmf`, dims/coords of the
+    inputs, `comment` / `model` (/ `units`) attrs per routing, values bit-identical to the numpy path."""
+    xr = xr_env.xr
     from xsarsea_amd import windspeed
-    inc, s_vv, s_vh, dsig, anc = (xr.DataArray(a[:8], dims=("line", "sample")) for a in scene)
+    arrs = [a[:8] for a in scene]
+    coords = {"line": np.arange(8) * 10, "sample": np.arange(arrs[0].shape[1]) * 10}
+    inc, s_vv, s_vh, dsig, anc = (xr.DataArray(a, dims=("line", "sample"), coords=coords, attrs={"stale": 1}) for a in arrs)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        co, dual = windspeed.invert_from_model(inc, s_vv, s_vh, ancillary_wind=anc, dsig_cr=dsig,
-                                               model=("gmf_cmod5n", "gmf_s1_v2"), resolution="low")
-    assert isinstance(co, xr.DataArray) and isinstance(dual, xr.DataArray)
-    assert co.name == "windspeed_gmf" and co.attrs["model"] == "gmf_cmod5n" and co.dims == ("line", "sample")
+        n_co, n_dual = windspeed.invert_from_model(*arrs[:3], ancillary_wind=arrs[4], dsig_cr=arrs[3], **_kw())
+        n_cr = windspeed.invert_from_model(arrs[0], arrs[2], dsig_cr=0.1, model="gmf_s1_v2", resolution="low")
+        co, dual = windspeed.invert_from_model(inc, s_vv, s_vh, ancillary_wind=anc, dsig_cr=dsig, **_kw())
+        mono = windspeed.invert_from_model(inc, s_vv, ancillary_wind=anc, model="gmf_cmod5n", resolution="low")
+        cr = windspeed.invert_from_model(inc, s_vh, dsig_cr=0.1, model="gmf_s1_v2", resolution="low")
+    for out in (co, dual, mono, cr):
+        assert isinstance(out, xr.DataArray) and tuple(out.dims) == ("line", "sample") and out.shape == arrs[0].shape
+        assert "stale" not in out.attrs  # attrs.clear() (:340)
+    assert co.name == "windspeed_gmf" and mono.name == "windspeed_gmf"
+    assert co.attrs == {"comment": "wind speed and direction inverted from model gmf_cmod5n (VV)", "model": "gmf_cmod5n"}
+    assert mono.attrs == co.attrs
+    assert dual.attrs == {"comment": "wind speed and direction inverted from model gmf_cmod5n (VV) and gmf_s1_v2 (VH)",
+                          "model": "gmf_cmod5n gmf_s1_v2"}
+    assert cr.attrs == {"comment": "wind speed inverted from model gmf_s1_v2 (VH)", "model": "gmf_s1_v2", "units": "m/s"}
+    assert co.dtype == np.complex128 and dual.dtype == np.complex128 and cr.dtype == np.float64
+    assert bits_equal(np.asarray(co.values), n_co) and bits_equal(np.asarray(dual.values), n_dual)
+    assert bits_equal(np.asarray(mono.values), n_co) and bits_equal(np.asarray(cr.values), n_cr)
+    assert np.array_equal(np.asarray(co["line"] if not xr_env.standin else co.coords["line"]), coords["line"])
+
+
+def test_xarray_pol_check(gpu_ctx, scene, xr_env):
+    """`sigma0.pol` is checked against the model's polarisation for mono-pol calls (windspeed.py:88-101): mismatch ->
+    ValueError, match -> no "Unable to check" warning, absent -> UserWarning."""
+    xr = xr_env.xr
+    from xsarsea_amd import windspeed
+    inc, s_vv, _, _, anc = (a[:4] for a in scene)
+    mk = lambda a, **c: xr.DataArray(a, dims=("line", "sample"), coords=c)
+    with pytest.raises(ValueError, match="sigma0 pol is VH, and model gmf_cmod5n can only handle VV"):
+        windspeed.invert_from_model(mk(inc), mk(s_vv, pol="VH"), ancillary_wind=mk(anc), model="gmf_cmod5n", resolution="low")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        out = windspeed.invert_from_model(mk(inc), mk(s_vv, pol="VV"), ancillary_wind=mk(anc), model="gmf_cmod5n", resolution="low")
+    assert isinstance(out, xr.DataArray)
+    with pytest.warns(UserWarning, match="Unable to check sigma0 pol"):
+        windspeed.invert_from_model(mk(inc), mk(s_vv), ancillary_wind=mk(anc), model="gmf_cmod5n", resolution="low")
+    with pytest.raises(AssertionError):  # co-pol inversion without any valid ancillary wind (:107)
+        windspeed.invert_from_model(mk(inc), mk(s_vv, pol="VV"), ancillary_wind=mk(anc * np.nan), model="gmf_cmod5n", resolution="low")
+
+
+def test_dask_blocks_are_lazy_and_equal_the_numpy_path(gpu_ctx, scene, xr_env):
+    """dask-backed DataArrays (row chunks, sample axis whole: windspeed.py:350-364): the call returns lazily -- no device
+    work before .compute() -- runs once per row block, and gives the numpy path's bits."""
+    xr, da = xr_env.xr, xr_env.da
+    from xsarsea_amd import _lib, windspeed
+    arrs = [a[:24] for a in scene]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        n_co, n_dual = windspeed.invert_from_model(*arrs[:3], ancillary_wind=arrs[4], dsig_cr=arrs[3], **_kw())
+    calls = []
+    real = _lib.Context.invert_host
+
+    def counting(self, *a, **k):
+        calls.append(np.shape(a[0]))
+        return real(self, *a, **k)
+
+    lazy = [xr.DataArray(da.from_array(a, chunks=(7, -1)), dims=("line", "sample")) for a in arrs]
+    try:
+        _lib.Context.invert_host = counting
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            co, dual = windspeed.invert_from_model(lazy[0], lazy[1], lazy[2], ancillary_wind=lazy[4], dsig_cr=lazy[3], **_kw())
+        assert isinstance(co, xr.DataArray) and isinstance(co.data, da.Array) and isinstance(dual.data, da.Array)
+        assert co.name == "windspeed_gmf" and co.attrs["model"] == "gmf_cmod5n" and dual.attrs["model"] == "gmf_cmod5n gmf_s1_v2"
+        assert calls == [], "the dask path must not touch the device before compute()"
+        v_co, v_dual = np.asarray(co.data.compute()), np.asarray(dual.data.compute())
+    finally:
+        _lib.Context.invert_host = real
+    assert sorted(c[0] for c in calls) == [3, 7, 7, 7] and all(c[1] == arrs[0].shape[1] for c in calls)
+    assert bits_equal(v_co, n_co) and bits_equal(v_dual, n_dual)
+    # raw dask arrays (no xarray container): the reference falls through to its numpy path and returns numpy
+    raw = [da.from_array(a, chunks=(7, -1)) for a in arrs]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r_co, r_dual = windspeed.invert_from_model(raw[0], raw[1], raw[2], ancillary_wind=raw[4], dsig_cr=raw[3], **_kw())
+    assert isinstance(r_co, np.ndarray) and isinstance(r_dual, np.ndarray)
+    assert bits_equal(r_co, n_co) and bits_equal(r_dual, n_dual)
+
+
+def test_loop_dimensions_broadcast(gpu_ctx, scene):
+    """The gufunc broadcasts its loop dimensions over all inputs (windspeed.py:307-322): a 1-D incidence row against 2-D
+    sigma0 / ancillary rasters gives (line, sample) outputs."""
+    from xsarsea_amd import windspeed
+    inc, s_vv, _, _, anc = (a[:6] for a in scene)
+    row = inc[0].copy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = windspeed.invert_from_model(row, s_vv, ancillary_wind=anc, model="gmf_cmod5n", resolution="low")
+        b = windspeed.invert_from_model(np.broadcast_to(row, s_vv.shape).copy(), s_vv, ancillary_wind=anc, model="gmf_cmod5n",
+                                        resolution="low")
+    assert a.shape == s_vv.shape and bits_equal(a, b)
+
+
+def test_sigma0_detrend_xarray(gpu_ctx, scene, xr_env):
+    """DataArray in -> DataArray out with the `comment` attr (detrend.py:55-66); incidence row taken with isel(line=0)."""
+    xr = xr_env.xr
+    import xsarsea_amd
+    inc, s_vv = scene[0][:16], scene[1][:16]
+    inc = inc.copy()
+    inc[:, :3] = 30.0  # the scene's leading NaN incidence columns: keep the GMF row finite for an exact comparison
+    ref = xsarsea_amd.sigma0_detrend(s_vv, inc)
+    out = xsarsea_amd.sigma0_detrend(xr.DataArray(s_vv, dims=("line", "sample"), attrs={"units": "linear"}),
+                                     xr.DataArray(inc, dims=("line", "sample")))
+    assert isinstance(out, xr.DataArray) and tuple(out.dims) == ("line", "sample") and out.dtype == np.float64
+    assert out.attrs["comment"] == "detrended with model gmf_cmod5n"
+    assert np.array_equal(np.asarray(out.values), ref, equal_nan=True)
 
 
 def test_lut_interp_device_equals_host(gpu_ctx):

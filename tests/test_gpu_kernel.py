@@ -147,7 +147,7 @@ def test_scene_vs_oracle(gpu_ctx, default_luts, dtype):
     else:
         # numpy's float32 log10 is a few-ulp SIMD routine; the device rounds log10 correctly, so a small
         # fraction of near-ties flips by one grid step.  Bounded and reported (DESIGN.md "float32 dB").
-        assert mism < 0.03, mism
+        assert mism < 1e-4, mism  # measured 2e-5 (bench.py parity.index_match_device_db)
 
 
 def test_bit_exact_vs_numpy_oracle(gpu_ctx, default_luts):

@@ -269,12 +269,14 @@ class Context:
     def invert_host(self, inc, sigma0_co=None, sigma0_cr=None, dsig_cr=None, anc=None, dsig_co=0.1,
                     sigma0_is_db=False, algo="auto", dual_select=False, out_dtype=np.complex128, want_idx=False):
         """numpy-in / numpy-out wrapper of xsw_invert for host rasters of one dtype (float32 or float64)."""
-        inc = np.ascontiguousarray(inc)
+        inc = np.asarray(inc)
         dt = inc.dtype
         if dt not in (np.float32, np.float64):
             raise TypeError("raster dtype must be float32 or float64")
         cdt = np.complex64 if dt == np.float32 else np.complex128
-        shape = inc.shape
+        shape = np.broadcast_shapes(*(np.shape(a) for a in (inc, sigma0_co, sigma0_cr, anc, None if np.isscalar(dsig_cr) else dsig_cr)
+                                      if a is not None))
+        inc = np.ascontiguousarray(np.broadcast_to(inc, shape))
         n = inc.size
         lines, samples = (int(np.prod(shape[:-1])), shape[-1]) if inc.ndim >= 1 and n else (0, 0)
         if inc.ndim == 0:

@@ -82,11 +82,20 @@ extern "C" int xsw_ctx_create(int device, xsw_ctx **out)
     if (device < 0 || device >= n) return fail(nullptr, XSW_EINVAL, "device %d out of range [0,%d)", device, n);
     xsw_ctx *c = new xsw_ctx;
     c->device = device;
-    HIPCHK(nullptr, hipSetDevice(device));
-    HIPCHK(nullptr, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    c->stream = c->own_stream;
-    HIPCHK(nullptr, hipMalloc((void **)&c->d_stats, 4 * sizeof(unsigned long long)));
-    HIPCHK(nullptr, hipMemset(c->d_stats, 0, 4 * sizeof(unsigned long long)));
+    const int rc = [&]() -> int {
+        HIPCHK(nullptr, hipSetDevice(device));
+        HIPCHK(nullptr, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+        c->stream = c->own_stream;
+        HIPCHK(nullptr, hipMalloc((void **)&c->d_stats, 4 * sizeof(unsigned long long)));
+        HIPCHK(nullptr, hipMemset(c->d_stats, 0, 4 * sizeof(unsigned long long)));
+        return XSW_OK;
+    }();
+    if (rc != XSW_OK) {  // nothing half-built is handed out or leaked
+        if (c->d_stats) (void)hipFree(c->d_stats);
+        if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+        delete c;
+        return rc;
+    }
     *out = c;
     return XSW_OK;
 }
@@ -164,13 +173,18 @@ static bool strictly_ascending(const double *a, int n)
         if (!(a[i] > a[i - 1])) return false;
     return true;
 }
+// "uniform" to the error budget the pruned kernels' screening assumes: they score with w_i = w0 + i*step (forward
+// differences) and re-score only candidates within 1e-9 (1 + |J_min| + m2) of the screening minimum with the real axis
+// values, so an axis point may be off its grid position by no more than ~1e-12 relative (dJ/dw is O(10..100)): np.linspace
+// axes are within a few ulps and pass; an axis stored in float32, or perturbed by 1e-7 of a step, takes the exact kernel.
 static bool uniform_axis(const double *a, int n)
 {
     if (n < 2) return false;
     const double step = (a[n - 1] - a[0]) / (n - 1);
     if (!(step > 0) || !std::isfinite(step)) return false;
+    const double tol = 1e-12 * std::max(std::max(std::fabs(a[0]), std::fabs(a[n - 1])), step);
     for (int i = 0; i < n; ++i)
-        if (std::fabs(a[i] - (a[0] + i * step)) > 1e-6 * step) return false;
+        if (!(std::fabs(a[i] - (a[0] + i * step)) <= tol)) return false;
     return true;
 }
 static bool all_finite(const double *a, size_t n)

@@ -21,6 +21,37 @@ def tile_bounds(lines, world, rank):
     return l0, l1
 
 
+def chunk_bounds(n_rows, n_chunks, k):
+    """[c0, c1) of chunk k when n_rows tile-local rows are cut into n_chunks nearly equal chunks."""
+    return n_rows * k // n_chunks, n_rows * (k + 1) // n_chunks
+
+
+def gather_chunk_async(tile, lines, k, n_chunks, dst=0, group=None, out=None):
+    """Start gathering chunk k (of n_chunks, `chunk_bounds` of each rank's OWN tile height) of every rank's tile into
+    `out` on `dst`; tiles may be uneven (`tile_bounds`: the last rank takes the remainder).  Returns the requests to
+    `wait()` on.  Lets a caller pipeline: invert chunk k, start its gather, invert chunk k+1 while chunk k travels
+    over xGMI (RCCL orders each transfer after the work already queued on the current stream)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    ops = []
+    if rank == dst:
+        for r in range(world):
+            t0, t1 = tile_bounds(lines, world, r)
+            c0, c1 = chunk_bounds(t1 - t0, n_chunks, k)
+            if c1 <= c0:
+                continue
+            if r == dst:
+                out[t0 + c0:t0 + c1].copy_(tile[c0:c1], non_blocking=True)
+            else:
+                ops.append(dist.P2POp(dist.irecv, out[t0 + c0:t0 + c1], r, group))
+    else:
+        t0, t1 = tile_bounds(lines, world, rank)
+        c0, c1 = chunk_bounds(t1 - t0, n_chunks, k)
+        if c1 > c0:
+            ops.append(dist.P2POp(dist.isend, tile[c0:c1], dst, group))
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
 def gather_rows_async(tile, lines, row0, row1, dst=0, group=None, out=None):
     """Start gathering rows [row0, row1) of every rank's tile (rows are tile-local, the same for all
     ranks: equal tiles) into `out` on `dst`; returns the list of requests to `wait()` on.  Lets a caller

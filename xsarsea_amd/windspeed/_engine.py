@@ -19,12 +19,34 @@ def host_tables(wspd, phi):
                 dual_dir=np.stack([unit.real, unit.imag], axis=-1))
 
 
+def _ascending(values, axes):
+    """The device wants strictly ascending axes (binary searches, uniform-grid windows); the reference takes any order
+    (`np.argmin(abs(dim - x))` and a flat argmin over the table).  A LUT whose coordinate runs the other way (or is
+    shuffled) is therefore re-ordered here, table permuted with it: the retrieved (wspd, phi) VALUES are those of the
+    reference.  (Only the resolution of exact ties -- equal cost at two grid points -- follows the sorted order instead
+    of the stored one.)  Repeated coordinates cannot be ordered and are refused."""
+    values = np.asarray(values, dtype=np.float64)
+    out_axes = []
+    for k, ax in enumerate(axes):
+        ax = np.asarray(ax, dtype=np.float64)
+        if ax.size > 1 and not np.all(np.diff(ax) > 0):
+            if np.isnan(ax).any() or np.unique(ax).size != ax.size:
+                raise ValueError(f"LUT axis {k} holds NaN or repeated coordinates: cannot be inverted on the device")
+            order = np.argsort(ax, kind="stable")
+            ax = ax[order]
+            values = np.take(values, order, axis=k)
+        out_axes.append(ax)
+    return np.ascontiguousarray(values), out_axes
+
+
 def _co_dict(lut):
-    return dict(db=lut.values, inc=lut.incidence, wspd=lut.wspd, phi=lut.phi, **host_tables(lut.wspd, lut.phi))
+    db, (inc, wspd, phi) = _ascending(lut.values, (lut.incidence, lut.wspd, lut.phi))
+    return dict(db=db, inc=inc, wspd=wspd, phi=phi, **host_tables(wspd, phi))
 
 
 def _cr_dict(lut):
-    return dict(db=lut.values, inc=lut.incidence, wspd=lut.wspd)
+    db, (inc, wspd) = _ascending(lut.values, (lut.incidence, lut.wspd))
+    return dict(db=db, inc=inc, wspd=wspd)
 
 
 def ensure_luts(ctx, lut_co, lut_cr):
@@ -118,8 +140,10 @@ def invert_numpy(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_c
     """
     ctx = _lib.default_context(options.device)
     inc = np.asarray(inc)
-    shape = inc.shape
     rasters = [a for a in (inc, sigma0_co, sigma0_cr, None if np.isscalar(dsig_cr) else dsig_cr) if a is not None]
+    # the gufunc "(n),(n),(n),(n),(n)->(n),(n)" broadcasts its loop dimensions over ALL inputs (windspeed.py:307-322):
+    # e.g. a 1-D incidence row with 2-D sigma0 gives (line, sample) outputs
+    shape = np.broadcast_shapes(*(np.shape(a) for a in rasters + ([] if anc is None else [anc])))
     all_f32 = all(np.asarray(a).dtype == np.float32 for a in rasters) and (
         anc is None or np.asarray(anc).dtype == np.complex64)
     on_dev = options.db_on_device

@@ -96,16 +96,19 @@ def axis_grid(rng, step):
     return np.linspace(rng[0], rng[1], num=int(np.round((rng[1] - rng[0]) / step) + 1))
 
 
-def lerp_axis(values, x_old, x_new, axis):
+def lerp_axis(values, x_old, x_new, axis, bounds_error=True):
     """Linear interpolation of `values` along `axis` from grid x_old to x_new.
 
     Same arithmetic as scipy.interpolate.interp1d(kind="linear"), which is what the reference's
-    `lut.interp(...)` (models.py:167) runs once per dimension: slope = (y_hi - y_lo)/(x_hi - x_lo),
-    y = slope*(x_new - x_lo) + y_lo, with bounds_error=True.
+    `lut.interp(...)` runs once per dimension: slope = (y_hi - y_lo)/(x_hi - x_lo),
+    y = slope*(x_new - x_lo) + y_lo.  bounds_error=True is `_normalize_lut`'s call (models.py:167: ValueError
+    outside the table); bounds_error=False is `LutModel.__call__`'s plain `lut.interp(...)` (models.py:330-346: NaN
+    outside the table, NaN abscissae give NaN).
     """
     x_old = np.asarray(x_old, dtype=np.float64)
     x_new = np.asarray(x_new, dtype=np.float64)
-    if x_new.min() < x_old[0] or x_new.max() > x_old[-1]:
+    outside = ~((x_new >= x_old[0]) & (x_new <= x_old[-1]))
+    if bounds_error and x_new.size and outside.any():
         raise ValueError("A value in x_new is outside the interpolation range.")
     hi = np.clip(np.searchsorted(x_old, x_new), 1, len(x_old) - 1)
     lo = hi - 1
@@ -114,4 +117,6 @@ def lerp_axis(values, x_old, x_new, axis):
     y_lo, y_hi = v[lo], v[hi]
     slope = (y_hi - y_lo) / (x_old[hi] - x_old[lo]).reshape(bshape)
     out = slope * (x_new - x_old[lo]).reshape(bshape) + y_lo
+    if not bounds_error and outside.any():
+        out[outside] = np.nan
     return np.moveaxis(out, 0, axis)

@@ -177,10 +177,11 @@ class LutModel(Model):
             raise NotImplementedError("Only scalar or 1D array are implemented for LutModel")
         kwargs.pop("broadcast", None)
         lut = self._lut(units=units, **kwargs)
-        out = lerp_axis(lut.values, lut.incidence, np.atleast_1d(np.asarray(inc, dtype=np.float64)), 0)
-        out = lerp_axis(out, lut.wspd, np.atleast_1d(np.asarray(wspd, dtype=np.float64)), 1)
+        # plain `lut.interp(...)` in the reference (models.py:330-346): points outside the table are NaN, not an error
+        out = lerp_axis(lut.values, lut.incidence, np.atleast_1d(np.asarray(inc, dtype=np.float64)), 0, bounds_error=False)
+        out = lerp_axis(out, lut.wspd, np.atleast_1d(np.asarray(wspd, dtype=np.float64)), 1, bounds_error=False)
         if lut.phi is not None:
-            out = lerp_axis(out, lut.phi, np.atleast_1d(np.asarray(phi, dtype=np.float64)), 2)
+            out = lerp_axis(out, lut.phi, np.atleast_1d(np.asarray(phi, dtype=np.float64)), 2, bounds_error=False)
         if all_scalar:
             return out.item()
         if xr is not None:

@@ -108,7 +108,10 @@ def invert_from_model(inc, sigma0, sigma0_dual=None, /, ancillary_wind=None, dsi
     template = next((v for v in (sigma0, inc, sigma0_dual, ancillary_wind) if _is_xr(v)), None)
     args = (inc, sigma0_co, sigma0_cr, dsig_cr, None if no_ancillary else ancillary_wind)
 
-    if any(_is_dask(v) for v in args if v is not None and not np.isscalar(v)):
+    # dask blocks only ever run behind an xarray container, as in the reference: there `xr.zeros_like` raises TypeError for
+    # anything that is not a DataArray (raw dask arrays included) and the whole call falls through to the numpy path,
+    # which materialises its inputs and returns numpy (windspeed.py:337-386)
+    if template is not None and any(_is_dask(v) for v in args if v is not None and not np.isscalar(v)):
         # dask in -> lazy dask out, one device call per row block (core dimension = last axis, :356-364)
         present = [i for i, v in enumerate(args) if v is not None and not np.isscalar(v)]
 
@@ -116,16 +119,17 @@ def invert_from_model(inc, sigma0, sigma0_dual=None, /, ancillary_wind=None, dsi
             full = list(args)
             for i, b in zip(present, blocks):
                 full[i] = b
-            for i, v in enumerate(full):
-                if i not in present and v is not None and not np.isscalar(v):
-                    full[i] = np.asarray(v)
             co_b, cr_b = _numpy(*full)
             nan_c = lambda: np.full(np.shape(full[0]), np.nan * 1j, dtype=np.complex128)
             return (co_b if co_b is not None else nan_c()), (cr_b if cr_b is not None else nan_c())
 
         ws_co, ws_cr = da.apply_gufunc(_block, ",".join(["(n)"] * len(present)) + "->(n),(n)",
-                                       *[getattr(args[i], "data", args[i]) for i in present],
+                                       *[args[i].data if _is_xr(args[i]) else args[i] for i in present],
                                        output_dtypes=(np.complex128, np.complex128))
+        if models[0] is None:
+            ws_co = None
+        if sigma0_cr is None:
+            ws_cr = None
     else:
         ws_co, ws_cr = _numpy(*[None if v is None else (v if np.isscalar(v) else np.asarray(v)) for v in args])
 
