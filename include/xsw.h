@@ -160,6 +160,15 @@ int xsw_gmf_eval(xsw_ctx *ctx, int32_t gmf_id, int64_t n, int32_t mem, const dou
 int xsw_detrend(xsw_ctx *ctx, int64_t lines, int64_t samples, int32_t dtype, int32_t out_dtype, int32_t mem,
                 const void *sigma0, const double *ratio_row, void *out);
 
+/* Replaces nesz_flattening (windspeed/utils.py:94-163), the full-raster pass in front of the dual-pol inversion:
+ * out[l][s] = 10 ** ((inc_row[s] * slope_l + icpt_l - 1) / 10), with inc_row = nanmean(inc, axis 0), and (slope_l, icpt_l)
+ * the degree-1 least-squares fit of 10*log10(noise[l], NaNs replaced by the column nan-mean) against inc_row over the
+ * finite samples of line l; a line without any finite sample is NaN.  noise/inc are `dtype` rasters (host or device per
+ * `mem`), out is float64 (the reference's result dtype).  Sums are float64 and the fit is closed-form: agrees with
+ * numpy's polyfit-based result to ~1e-13 relative for float64 rasters.  Returns after the work has completed. */
+int xsw_nesz_flatten(xsw_ctx *ctx, int64_t lines, int64_t samples, int32_t dtype, int32_t mem, const void *noise,
+                     const void *inc, double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,4 +21,7 @@ Parity pinning (see DESIGN.md "Oracle"):
     decomposition with scipy `interp1d`; xarray itself is absent from the
     image so bit-equality with the reference's `DataArray.interp` is
     UNPINNED (formula-pinned only).
+  * The cross-pol preprocessing (`oracle.crosspol`: get_dsig, get_dsig_wspd,
+    nesz_flattening) is pinned bit-for-bit against `crosspol_prep.npz`,
+    produced by executing the reference's `windspeed/utils.py`.
 """

@@ -23,6 +23,7 @@ explicit arrays stored inside the fixture.
 
 Usage:  python tests/golden/make_golden.py            (writes tests/golden/*.npz, ~2 min)
         python tests/golden/make_golden.py phi90_f64  (only the named kernel_small_* fixtures)
+        python tests/golden/make_golden.py crosspol_prep  (only crosspol_prep.npz: the reference's windspeed/utils.py)
 """
 import importlib.util
 import os
@@ -236,10 +237,58 @@ def run_reference(ws, models_mod, luts, inc, s_vv, s_vh, dsig_cr, anc):
     return out
 
 
+def crosspol_prep_golden():
+    """crosspol_prep.npz: inputs + outputs of the reference's windspeed/utils.py -- `get_dsig` (4 names), `get_dsig_wspd`
+    (3 names), `nesz_flattening` (float64 and float32 rasters with NaN columns, NaN rows, scattered NaNs, a zero)."""
+    import warnings
+    ru = sys.modules["xsarsea.windspeed.utils"]
+    rng = np.random.default_rng(20260320 + 30)
+    out = {}
+    # get_dsig
+    n = 96
+    inc = rng.uniform(17.0, 50.0, n)
+    nesz = 10 ** rng.uniform(-3.8, -3.0, n)
+    s_cr = nesz * 10 ** rng.uniform(-0.3, 2.0, n)
+    s_cr[0], s_cr[1], nesz[2], inc[3] = 0.0, np.nan, np.nan, np.nan
+    out.update(dsig_inc=inc, dsig_sigma0_cr=s_cr, dsig_nesz_cr=nesz)
+    with np.errstate(all="ignore"):
+        for name in ("gmf_s1_v2", "gmf_rs2_v2", "sarwing_lut_cmodms1ahw", "nc_lut_cmodms1ahw"):
+            out["dsig_" + name] = ru.get_dsig(name, inc, s_cr, nesz)
+            out["dsig32_" + name] = ru.get_dsig(name, inc.astype(np.float32), s_cr.astype(np.float32), nesz.astype(np.float32))
+        # get_dsig_wspd
+        U = np.concatenate([rng.uniform(0.0, 80.0, n - 4), [0.0, 30.0, 29.999, 80.0]])
+        snr = np.concatenate([rng.uniform(-3.0, 20.0, n - 2), [0.0, np.nan]])
+        out.update(dsigw_U=U, dsigw_SNR=snr)
+        for name in ("dsig_wspd_rs2_v3", "dsig_wspd_s1_ew_rec_v3", "dsig_wspd_rcm_v3"):
+            out[name] = ru.get_dsig_wspd(name, U, snr)
+    # nesz_flattening
+    L, S = 40, 96
+    inc2 = np.linspace(29.0, 46.0, S)[None, :] + 0.02 * np.sin(np.arange(L) / 7.0)[:, None]
+    noise = 10 ** ((-32.0 + 0.12 * (inc2 - 29.0) + 0.3 * rng.standard_normal((L, S))) / 10.0)
+    noise[:, 5] = np.nan            # a column with no valid sample: the column mean is NaN there too
+    noise[:, 50:53] = np.nan
+    noise[7, :] = np.nan            # a whole line: filled from the column means
+    noise[rng.random((L, S)) < 0.03] = np.nan
+    noise[11, 20] = 0.0             # log10(0) = -inf: dropped from that line's fit
+    noise[12, 21] = -1e-4           # log10(negative) = NaN: dropped
+    inc2[3, 40] = np.nan
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out.update(nesz_noise=noise, nesz_inc=inc2, nesz_flat=ru.nesz_flattening(noise, inc2),
+                   nesz_flat32=ru.nesz_flattening(noise.astype(np.float32), inc2.astype(np.float32)),
+                   nesz_flat_allnan=ru.nesz_flattening(np.full((3, 8), np.nan), inc2[:3, :8]))
+    np.savez_compressed(os.path.join(HERE, "crosspol_prep.npz"), **out)
+    print("crosspol_prep.npz")
+
+
 def main():
     models_mod, ws, gmfs = load_reference()
     from oracle import lut as olut
 
+    if "crosspol_prep" in sys.argv[1:]:
+        return crosspol_prep_golden()
+    if not sys.argv[1:]:
+        crosspol_prep_golden()
     only = set(sys.argv[1:])
     # ---- G1: scalar GMF lattice from the reference's own scalar functions
     inc_l = np.array([16.0, 20.3, 27.5, 35.0, 40.0, 47.7, 58.2, 66.0])

@@ -206,6 +206,53 @@ def test_sigma0_detrend_xarray(gpu_ctx, scene, xr_env):
     assert np.array_equal(np.asarray(out.values), ref, equal_nan=True)
 
 
+def test_nesz_flatten_device(gpu_ctx):
+    """xsw_nesz_flatten (windspeed/utils.py:94-163 on the device) against the REFERENCE's outputs (crosspol_prep.npz) and,
+    at a larger ragged size, against the oracle.  Tolerances: float64 rasters 1e-10 relative (numpy's polyfit solves by SVD,
+    the kernel by the normal equations about the mean abscissa, both in float64: observed ~1e-13); float32 rasters 1e-5
+    (numpy takes log10 and the column sums in float32, the kernel in float64)."""
+    import warnings
+    from conftest import golden
+    from oracle import crosspol as ocp
+    from xsarsea_amd import options, windspeed
+    d = golden("crosspol_prep.npz")
+    rel = lambda a, b: float(np.nanmax(np.abs(a - b) / np.abs(b)))
+    got = gpu_ctx.nesz_flatten_host(d["nesz_noise"], d["nesz_inc"])
+    assert got.dtype == np.float64 and np.isfinite(got).all() and rel(got, d["nesz_flat"]) <= 1e-10
+    got32 = gpu_ctx.nesz_flatten_host(d["nesz_noise"].astype(np.float32), d["nesz_inc"].astype(np.float32))
+    assert rel(got32, d["nesz_flat32"]) <= 1e-5
+    assert np.isnan(gpu_ctx.nesz_flatten_host(np.full((3, 8), np.nan), d["nesz_inc"][:3, :8])).all()
+    # larger, ragged (samples not a multiple of 4 or 256; more line blocks than one), NaN columns/lines, through the API
+    rng = np.random.default_rng(8)
+    L, S = 1537, 4101
+    inc = np.linspace(29.0, 46.0, S)[None, :] + 0.02 * np.sin(np.arange(L) / 90.0)[:, None]
+    noise = 10 ** ((-31.0 + 0.1 * (inc - 29.0) + 0.4 * rng.standard_normal((L, S))) / 10.0)
+    noise[rng.random((L, S)) < 0.02] = np.nan
+    noise[:, 77] = np.nan
+    noise[500, :] = np.nan
+    noise[3, 9] = 0.0
+    old = (options.nesz_on_device, options.nesz_device_min_size)
+    try:
+        options.nesz_on_device = "device"
+        dev = windspeed.nesz_flattening(noise, inc)
+        options.nesz_on_device, options.nesz_device_min_size = "auto", 1 << 20
+        assert np.array_equal(windspeed.nesz_flattening(noise, inc), dev)  # 6.3e6 px: "auto" takes the device too
+    finally:
+        options.nesz_on_device, options.nesz_device_min_size = old
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = ocp.nesz_flattening(noise, inc)
+    assert dev.shape == ref.shape and np.isfinite(dev).all() and rel(dev, ref) <= 1e-10, rel(dev, ref)
+    # one valid column only: every line fits a single point -> numpy's minimum-norm solution (slope = y/2x, icpt = y/2)
+    one = np.full((4, 6), np.nan)
+    one[:, 2] = [1e-3, 2e-3, 5e-4, 1e-3]
+    inc6 = np.broadcast_to(np.linspace(30.0, 35.0, 6), (4, 6)).copy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref1 = ocp.nesz_flattening(one, inc6)
+    assert rel(gpu_ctx.nesz_flatten_host(one, inc6), ref1) <= 1e-10
+
+
 def test_lut_interp_device_equals_host(gpu_ctx):
     """the low->high LUT interpolation on the device is bit-identical to the host numpy path
     (three sequential interp1d passes), co-pol 3-D and cross-pol 2-D, and rejects out-of-range targets."""

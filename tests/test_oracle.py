@@ -123,3 +123,36 @@ def test_detrend_formula():
     out = odet.sigma0_detrend(s, inc)
     g = gmf.gmf_cmod5n(inc[0], 10.0, 45.0)
     assert np.allclose(out, s * np.mean(g) / g[None, :], rtol=1e-14)
+
+
+def test_crosspol_prep_matches_the_reference_bitwise():
+    """oracle.crosspol AND the product's host helpers against the outputs of the reference's own windspeed/utils.py
+    (tests/golden/crosspol_prep.npz): bit-identical, float32 inputs included (dtype promotion as in the reference)."""
+    import warnings
+    from oracle import crosspol as ocp
+    from xsarsea_amd import options
+    from xsarsea_amd.windspeed import utils as putils
+    d = golden("crosspol_prep.npz")
+    same = lambda a, b: a.dtype == b.dtype and np.array_equal(a, b, equal_nan=True)
+    f4 = lambda a: a.astype(np.float32)
+    old = options.nesz_on_device
+    options.nesz_on_device = "host"
+    try:
+        with np.errstate(all="ignore"), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for mod in (ocp, putils):
+                for name in ("gmf_s1_v2", "gmf_rs2_v2", "sarwing_lut_cmodms1ahw", "nc_lut_cmodms1ahw"):
+                    assert same(mod.get_dsig(name, d["dsig_inc"], d["dsig_sigma0_cr"], d["dsig_nesz_cr"]), d["dsig_" + name]), name
+                    assert same(mod.get_dsig(name, f4(d["dsig_inc"]), f4(d["dsig_sigma0_cr"]), f4(d["dsig_nesz_cr"])),
+                                d["dsig32_" + name]), name
+                for name in ("dsig_wspd_rs2_v3", "dsig_wspd_s1_ew_rec_v3", "dsig_wspd_rcm_v3"):
+                    assert same(mod.get_dsig_wspd(name, d["dsigw_U"], d["dsigw_SNR"]), d[name]), name
+                assert same(mod.nesz_flattening(d["nesz_noise"], d["nesz_inc"]), d["nesz_flat"])
+                assert same(mod.nesz_flattening(f4(d["nesz_noise"]), f4(d["nesz_inc"])), d["nesz_flat32"])
+                assert same(mod.nesz_flattening(np.full((3, 8), np.nan), d["nesz_inc"][:3, :8]), d["nesz_flat_allnan"])
+                with pytest.raises(IndexError):
+                    mod.nesz_flattening(d["nesz_noise"][0], d["nesz_inc"][0])
+                with pytest.raises(ValueError):
+                    mod.get_dsig("nope", 1.0, 1.0, 1.0)
+    finally:
+        options.nesz_on_device = old

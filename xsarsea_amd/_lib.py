@@ -22,6 +22,7 @@ GMF_IDS = {"gmf_cmod5": 0, "gmf_cmod5n": 1, "gmf_cmod5n_pr_zhangA": 2, "gmf_cmod
 EXPORTS = (
     "xsw_version", "xsw_device_count", "xsw_ctx_create", "xsw_ctx_destroy", "xsw_last_error", "xsw_set_stream", "xsw_use_own_stream",
     "xsw_synchronize", "xsw_lut_upload", "xsw_invert", "xsw_stats_enable", "xsw_stats_read", "xsw_detrend", "xsw_lut_interp", "xsw_gmf_eval",
+    "xsw_nesz_flatten",
 )
 
 
@@ -106,6 +107,7 @@ def load():
         lib.xsw_lut_interp.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4 + [ctypes.c_int32] * 3 + \
             [ctypes.c_void_p] * 3 + [ctypes.c_int32] * 3 + [ctypes.c_void_p]
         lib.xsw_gmf_eval.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32] + [ctypes.c_void_p] * 4
+        lib.xsw_nesz_flatten.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 3
         _cdll = lib
     return _cdll
 
@@ -306,6 +308,27 @@ class Context:
                             _ptr(inc), _ptr(s_co), _ptr(s_cr), _ptr(dsig_arr), _ptr(anc_), _ptr(out_co), _ptr(out_cr),
                             _ptr(idx), dsig_co, dsig_scalar, sigma0_is_db, ALGOS.get(algo, algo), dual_select)
         return out_co, out_cr, idx
+
+    @_locked
+    def nesz_flatten_raw(self, lines, samples, dtype, mem, noise_ptr, inc_ptr, out_ptr):
+        """Thin call of xsw_nesz_flatten (pointers are ints: device or host addresses)."""
+        self._check(self._lib.xsw_nesz_flatten(self._h, int(lines), int(samples), dtype, mem, ctypes.c_void_p(noise_ptr),
+                                               ctypes.c_void_p(inc_ptr), ctypes.c_void_p(out_ptr)), "xsw_nesz_flatten")
+
+    @_locked
+    def nesz_flatten_host(self, noise, inc):
+        """xsw_nesz_flatten on host rasters of one dtype (float32 or float64) and one 2-D shape -> float64."""
+        noise = np.ascontiguousarray(noise)
+        if noise.dtype not in (np.float32, np.float64):
+            noise = noise.astype(np.float64)
+        inc = np.ascontiguousarray(inc, dtype=noise.dtype)
+        if noise.ndim != 2 or inc.shape != noise.shape:
+            raise ValueError("noise and inc must be 2-D rasters of one shape")
+        out = _host.empty_touched(noise.shape, np.float64)
+        if noise.size:
+            self.nesz_flatten_raw(noise.shape[0], noise.shape[1], XSW_F32 if noise.dtype == np.float32 else XSW_F64, MEM_HOST,
+                                  noise.ctypes.data, inc.ctypes.data, out.ctypes.data)
+        return out
 
     @_locked
     def detrend_raw(self, lines, samples, dtype, out_dtype, mem, sigma0_ptr, ratio_row, out_ptr):

@@ -16,6 +16,7 @@
 #include "xsw_device.hpp"
 #include "xsw_exhaustive.hpp"
 #include "xsw_gmf.hpp"
+#include "xsw_nesz.hpp"
 
 using namespace xsw;
 
@@ -833,5 +834,68 @@ extern "C" int xsw_detrend(xsw_ctx *c, int64_t lines, int64_t samples, int32_t d
     }
     for (hipError_t x : {de, s1, s2, s3}) if (e == hipSuccess) e = x;
     if (e != hipSuccess) return fail(c, XSW_EHIP, "detrend failed: %s", hipGetErrorString(e));
+    return XSW_OK;
+}
+
+// ---------------------------------------------------------------------------------------- cross-pol noise flattening
+template <typename T>
+static hipError_t launch_nesz(hipStream_t s, const void *noise, const void *inc, void *scratch, double *out, long long lines,
+                              long long samples, int nb, long long lpb)
+{
+    NeszPartial *part = (NeszPartial *)scratch;
+    double *col = (double *)((char *)scratch + (size_t)nb * samples * sizeof(NeszPartial));
+    double *x0 = col + 2 * samples;
+    const unsigned gx = (unsigned)((samples + 255) / 256);
+    hipLaunchKernelGGL((k_nesz_colsum<T>), dim3(gx, (unsigned)nb), dim3(256), 0, s, (const T *)noise, (const T *)inc, part, lines, samples, lpb);
+    hipLaunchKernelGGL(k_nesz_colmean, dim3(gx), dim3(256), 0, s, part, col, samples, nb);
+    hipLaunchKernelGGL(k_nesz_center, dim3(1), dim3(1024), 0, s, col, x0, samples);
+    hipLaunchKernelGGL((k_nesz_rows<T>), dim3((unsigned)lines), dim3(256), 0, s, (const T *)noise, col, x0, out, samples);
+    return hipGetLastError();
+}
+
+extern "C" int xsw_nesz_flatten(xsw_ctx *c, int64_t lines, int64_t samples, int32_t dtype, int32_t mem, const void *noise,
+                                const void *inc, double *out)
+{
+    if (!c) return XSW_EINVAL;
+    if (lines < 0 || samples < 0 || !noise || !inc || !out) return fail(c, XSW_EINVAL, "bad nesz_flatten argument");
+    if (dtype != XSW_F32 && dtype != XSW_F64) return fail(c, XSW_EINVAL, "dtype must be XSW_F32 or XSW_F64");
+    if (mem != XSW_MEM_HOST && mem != XSW_MEM_DEVICE) return fail(c, XSW_EINVAL, "bad mem kind");
+    if (lines > 0x7fffffffLL) return fail(c, XSW_EINVAL, "raster too large for one launch");
+    const long long n = (long long)lines * samples;
+    if (n == 0) return XSW_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t es = dtype == XSW_F32 ? 4 : 8;
+    // line blocks of the column pass: enough workgroups to fill the chip (~16 per CU), at least 8 lines each
+    const long long gx = (samples + 255) / 256;
+    long long nb = (256LL * 16 + gx - 1) / gx;
+    nb = std::max<long long>(1, std::min<long long>(std::min<long long>(nb, (lines + 7) / 8), 65535));
+    const long long lpb = (lines + nb - 1) / nb;
+    nb = (lines + lpb - 1) / lpb;
+    const size_t scratch_bytes = (size_t)nb * samples * sizeof(NeszPartial) + (2 * (size_t)samples + 8) * sizeof(double);
+    void *scratch = nullptr;
+    HIPCHK(c, hipMalloc(&scratch, scratch_bytes));
+    hipError_t e = hipSuccess;
+    const void *d_noise = noise, *d_inc = inc;
+    double *d_out = out;
+    void *stage = nullptr;
+    if (mem == XSW_MEM_HOST) {
+        const size_t in_b = ((size_t)n * es + 255) & ~(size_t)255;
+        e = hipMalloc(&stage, 2 * in_b + (size_t)n * 8);
+        if (e == hipSuccess) {
+            d_noise = stage; d_inc = (char *)stage + in_b; d_out = (double *)((char *)stage + 2 * in_b);
+            e = hipMemcpyAsync((void *)d_noise, noise, (size_t)n * es, hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync((void *)d_inc, inc, (size_t)n * es, hipMemcpyHostToDevice, c->stream);
+        }
+    }
+    if (e == hipSuccess)
+        e = dtype == XSW_F32 ? launch_nesz<float>(c->stream, d_noise, d_inc, scratch, d_out, lines, samples, (int)nb, lpb)
+                             : launch_nesz<double>(c->stream, d_noise, d_inc, scratch, d_out, lines, samples, (int)nb, lpb);
+    if (mem == XSW_MEM_HOST && e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream);
+    // the scratch (and the staging area) are call-local: wait for the stream before freeing them
+    hipError_t se = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = se;
+    (void)hipFree(scratch);
+    if (stage) (void)hipFree(stage);
+    if (e != hipSuccess) return fail(c, e == hipErrorOutOfMemory ? XSW_ENOMEM : XSW_EHIP, "nesz_flatten failed: %s", hipGetErrorString(e));
     return XSW_OK;
 }

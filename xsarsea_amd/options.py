@@ -23,3 +23,9 @@ lut_interp = "auto"
 #: evaluation to ~1e-14 relative, not bit for bit; LUT preparation always evaluates on the host), "host", "device".
 gmf_on_device = "auto"
 gmf_device_min_size = 1 << 18
+
+#: cross-pol noise flattening (`windspeed.nesz_flattening`): "auto" = device (`xsw_nesz_flatten`) for rasters of
+#: >= nesz_device_min_size pixels when a device is present -- float64 accumulation and closed-form least squares, within
+#: 1e-10 relative of the host route, which reproduces numpy's polyfit bit for bit -- "host", "device".
+nesz_on_device = "auto"
+nesz_device_min_size = 1 << 20

@@ -1,6 +1,12 @@
 """Cross-pol preprocessing helpers used right before `invert_from_model`
 (reference: src/xsarsea/windspeed/utils.py): `get_dsig` (:47-91), `get_dsig_wspd` (:18-44),
-`nesz_flattening` (:94-163).  Elementwise formulas / one degree-1 fit per row: host numpy."""
+`nesz_flattening` (:94-163).
+
+`get_dsig*` are elementwise formulas (host numpy, bit-identical to the reference incl. its dtype promotion:
+tests/golden/crosspol_prep.npz).  `nesz_flattening` is a full-raster pass -- column nan-mean, then one degree-1
+least-squares fit per line in dB -- and runs on the device for large rasters (`xsw_nesz_flatten`, include/xsw.h;
+`options.nesz_on_device`); the host route below reproduces the reference bit for bit.
+"""
 import warnings
 
 import numpy as np
@@ -10,50 +16,73 @@ _DSIG_WSPD = {
     "dsig_wspd_s1_ew_rec_v3": (-0.5858970325653666, 16.50039320910609, 1.1032031322520397, 7.434663633997121),
     "dsig_wspd_rcm_v3": (-0.7920301376936547, 15.8288289109038, 0.24040294696606557, 0.2538177092195224),
 }
+# logistic exponent c(inc) of the S1 v2 rule: rate, centre, floor, span.  numpy float64 scalars on purpose: like the
+# reference's coefficient array they promote a float32 incidence raster to float64.
+_S1_V2_EXPONENT = np.array([1.57952257, 25.61843791, 1.46852088, 1.4058646])
 
 
 def get_dsig_wspd(name, U_crosspol, SNR_cr):
     """Weight alpha(U, SNR) in [0, 1]: logistic in (U - c0 + gamma*SNR) times a roll-off above Umax = 30."""
     b, c0_base, gamma, k = _DSIG_WSPD[name]
-    core = 1 / (1 + np.exp(-b * (U_crosspol - (c0_base - gamma * SNR_cr))))
+    centre = c0_base - gamma * SNR_cr
+    core = 1 / (1 + np.exp(-b * (U_crosspol - centre)))
     drop = 1 / (1 + np.exp((U_crosspol - 30) * k))
     return np.clip(core * drop, 0, 1)
 
 
 def get_dsig(name, inc, sigma0_cr, nesz_cr):
     """`dsig_cr` for `invert_from_model` from the cross-pol signal-to-noise ratio."""
-    snr = sigma0_cr / nesz_cr
     if name == "gmf_s1_v2":
-        c = 1.46852088 + 1.4058646 / (1 + np.exp(-1.57952257 * (inc - 25.61843791)))
-        return 1 / np.sqrt(1 * snr ** c)
+        rate, centre, floor, span = _S1_V2_EXPONENT
+        c = floor + span / (1 + np.exp(-rate * (inc - centre)))
+        return 1 / np.sqrt(1 * (sigma0_cr / nesz_cr) ** c)
     if name == "gmf_rs2_v2":
-        return 1 / np.sqrt(1 * snr ** 8)
+        return 1 / np.sqrt(1 * (sigma0_cr / nesz_cr) ** 8)
     if name in ("sarwing_lut_cmodms1ahw", "nc_lut_cmodms1ahw"):
-        return (1.25 / snr) ** 4.0
+        return (1.25 / (sigma0_cr / nesz_cr)) ** 4.0
     raise ValueError("dsig names different than 'gmf_s1_v2' or 'gmf_rs2_v2' or 'sarwing_lut_cmodms1ahw' or "
                      "'nc_lut_cmodms1ahw' are not handled. You can compute your own dsig_cr.")
 
 
-def nesz_flattening(noise, inc):
-    """Flatten a (line, sample) noise-equivalent sigma0 by a per-line degree-1 fit of its dB value
-    against incidence; NaNs are first replaced by the column mean.  Returns 10**((fit - 1)/10)."""
-    if noise.ndim != 2:
-        raise IndexError("Only 2D noise allowed")
-    values = np.asarray(noise, dtype=np.float64)
+def _nesz_flattening_host(values, inc):
+    """The reference's arithmetic, line by line (utils.py:119-163), dtypes left as they come."""
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", RuntimeWarning)
         col_mean = np.nanmean(values, axis=0)
-        inc_row = np.nanmean(np.asarray(inc, dtype=np.float64), axis=0)
-    out = np.empty_like(values)
+        inc_row = np.nanmean(inc, axis=0)  # "incidence is almost constant along line dim"
+    out = np.empty(values.shape, dtype=np.float64)
     for i, row in enumerate(values):
-        filled = np.where(np.isnan(row), col_mean, row)
+        filled = row.copy()
+        gap = np.isnan(filled)
+        filled[gap] = col_mean[gap]
         with np.errstate(all="ignore"):
             db = 10.0 * np.log10(filled)
         ok = np.isfinite(db)
         try:
-            slope, icpt = np.polyfit(inc_row[ok], db[ok], 1)
-        except TypeError:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                slope, icpt = np.polyfit(inc_row[ok], db[ok], 1)
+        except TypeError:  # nothing to fit on this line
             out[i] = np.nan
             continue
         out[i] = 10.0 ** ((inc_row * slope + icpt - 1.0) / 10.0)
     return out
+
+
+def nesz_flattening(noise, inc):
+    """Flatten a (line, sample) noise-equivalent sigma0 by a per-line degree-1 fit of its dB value
+    against incidence; NaNs are first replaced by the column mean.  Returns 10**((fit - 1)/10), float64.
+
+    >>> nesz_flat = nesz_flattening(nesz_cr, inc)
+    >>> dsig_cr = (1.25 / (sigma0_cr / nesz_flat)) ** 4.0
+    """
+    if noise.ndim != 2:
+        raise IndexError("Only 2D noise allowed")
+    from .. import _lib, options
+    values, inc_v = np.asarray(noise), np.asarray(inc)
+    mode = options.nesz_on_device
+    on_dev = mode == "device" or (mode == "auto" and values.size >= options.nesz_device_min_size
+                                  and _lib.device_count_safe() > 0)
+    if on_dev and values.dtype in (np.float32, np.float64) and inc_v.shape == values.shape and values.size:
+        return _lib.default_context(options.device).nesz_flatten_host(values, inc_v)
+    return _nesz_flattening_host(values, inc_v)
