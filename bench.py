@@ -402,10 +402,21 @@ def main():
     stream = torch.cuda.Stream(device=device)  # the kernels, the events and RCCL all use this stream
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
+    if cfg["lut"] == "cmod5n":
+        # time to a searchable LUT, device route (options.lut_build="device": grid fill + interpolation + dB + layout on the
+        # GPU, xsw_lut_build); the timed steps below then run on the host-built table (bit parity with the CPU baseline)
+        from xsarsea_amd.windspeed import _engine, get_model
+        plan = get_model("gmf_cmod5n").device_lut_plan(**({} if args.resolution == "high" else {"resolution": args.resolution}))
+        t0 = time.perf_counter()
+        _engine.DeviceLut("gmf_cmod5n", plan[0], plan[1], plan[2], key=None).build(ctx)
+        ctx.synchronize()
+        timings["lut_device_build_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
     t0 = time.perf_counter()
     ctx.upload_luts(co=co_dict)
     ctx.synchronize()
     timings["lut_upload_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+    timings["note"] = ("host route = lut_build_ms (Model.to_lut: numpy GMF fill, device interpolation, numpy log10) + lut_upload_ms; "
+                       "device route = lut_device_build_ms (xsw_lut_build, table never on the host)")
 
     l0, l1 = multi_gpu.tile_bounds(total_lines, world, rank)  # this rank's row tile (windspeed.py:356-364: row blocks)
     lines = l1 - l0

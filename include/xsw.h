@@ -141,6 +141,22 @@ int xsw_lut_interp(xsw_ctx *ctx, const double *raw, const double *inc_raw, const
                    const double *inc, const double *wspd, const double *phi, int32_t n_inc, int32_t n_wspd,
                    int32_t n_phi, double *out);
 
+/* Device-side LUT preparation for the built-in GMFs (gmf_id: XSW_GMF_* below): evaluates the model on its RAW grid
+ * (GmfModel._raw_lut, windspeed/gmfs.py:350-395), brings it to the TARGET grid with the three sequential linear
+ * interpolations of Model._normalize_lut (windspeed/models.py:142-168; skipped when the two grids are equal, e.g.
+ * resolution="low"), converts to dB (models.py:210-216) and installs the result as the context's co-pol (phi axes given)
+ * or cross-pol (n_phi_raw == 0, target->n_phi == 0) LUT, exactly as xsw_lut_upload would -- without the table visiting
+ * the host.  `target` carries the target axes and the optional host tables of xsw_lut; target->db is ignored.
+ * Values agree with the host-built LUT to ~1e-13 dB (device libm), not bit for bit: use xsw_lut_upload with a
+ * host-built table when bit parity with a CPU run is wanted. */
+int xsw_lut_build(xsw_ctx *ctx, int32_t gmf_id, const double *inc_raw, int32_t n_inc_raw, const double *wspd_raw,
+                  int32_t n_wspd_raw, const double *phi_raw, int32_t n_phi_raw, const xsw_lut *target);
+
+/* Copies the context's current co-pol (cross == 0: out_db[n_inc][n_wspd][n_phi]) or cross-pol (cross != 0:
+ * out_db[n_inc][n_wspd]) dB table back to the host, unpadded -- what Model.to_lut(units="dB") would hold
+ * (windspeed/models.py:186-230) for a LUT that was built on the device.  Synchronous. */
+int xsw_lut_read(xsw_ctx *ctx, int32_t cross, double *out_db);
+
 /* Built-in analytic GMFs on the device: out[i] = gmf(inc[i], wspd[i], phi[i]) over n already-broadcast float64
  * elements (phi may be NULL for cross-pol models).  Replaces the numba-vectorised forward GMF of
  * GmfModel.__call__(..., broadcast=True) (windspeed/gmfs.py:202-214, :293-316) for the models of gmfs_impl.py.

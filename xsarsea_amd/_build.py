@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "xsw.hip")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("xsw.hip", "xsw_device.hpp", "xsw_exhaustive.hpp", "xsw_gmf.hpp", "xsw_nesz.hpp")] + [
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("xsw.hip", "xsw_device.hpp", "xsw_exhaustive.hpp", "xsw_gmf.hpp", "xsw_nesz.hpp", "xsw_lutbuild.hpp")] + [
     os.path.join(REPO, "include", "xsw.h")]
 LIB = os.environ.get("XSW_LIB") or os.path.join(HERE, "libxsw.so")  # XSW_LIB: experiment builds only
 ARCH = "gfx950"

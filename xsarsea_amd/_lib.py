@@ -22,7 +22,7 @@ GMF_IDS = {"gmf_cmod5": 0, "gmf_cmod5n": 1, "gmf_cmod5n_pr_zhangA": 2, "gmf_cmod
 EXPORTS = (
     "xsw_version", "xsw_device_count", "xsw_ctx_create", "xsw_ctx_destroy", "xsw_last_error", "xsw_set_stream", "xsw_use_own_stream",
     "xsw_synchronize", "xsw_lut_upload", "xsw_invert", "xsw_stats_enable", "xsw_stats_read", "xsw_detrend", "xsw_lut_interp", "xsw_gmf_eval",
-    "xsw_nesz_flatten",
+    "xsw_nesz_flatten", "xsw_lut_build", "xsw_lut_read",
 )
 
 
@@ -108,6 +108,9 @@ def load():
             [ctypes.c_void_p] * 3 + [ctypes.c_int32] * 3 + [ctypes.c_void_p]
         lib.xsw_gmf_eval.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32] + [ctypes.c_void_p] * 4
         lib.xsw_nesz_flatten.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 3
+        lib.xsw_lut_build.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                      ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(LutStruct)]
+        lib.xsw_lut_read.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
         _cdll = lib
     return _cdll
 
@@ -191,12 +194,12 @@ class Context:
 
     @staticmethod
     def _lut_struct(db, inc, wspd, phi=None, cos_phi=None, sin_phi=None, out_dir=None, abs_co=None, dual_dir=None):
-        keep = [_f64(db), _f64(inc), _f64(wspd)] + [None if v is None else _f64(v) for v in
-                                                    (phi, cos_phi, sin_phi, out_dir, abs_co, dual_dir)]
+        keep = [None if db is None else _f64(db), _f64(inc), _f64(wspd)] + [None if v is None else _f64(v) for v in
+                                                                            (phi, cos_phi, sin_phi, out_dir, abs_co, dual_dir)]
         n_phi = 0 if phi is None else len(keep[3])
         n_w = len(keep[2])
         expect = (len(keep[1]), n_w) + ((n_phi,) if phi is not None else ())
-        if keep[0].shape != expect:
+        if keep[0] is not None and keep[0].shape != expect:
             raise ValueError(f"LUT shape {keep[0].shape} does not match axes {expect}")
         for a, shp, nm in ((keep[4], (n_phi,), "cos_phi"), (keep[5], (n_phi,), "sin_phi"),
                            (keep[6], (2, n_phi, 2), "out_dir"), (keep[7], (n_w, n_phi), "abs_co"),
@@ -219,6 +222,24 @@ class Context:
             keep.append(k)
         self._check(self._lib.xsw_lut_upload(self._h, ctypes.byref(sco) if sco else None,
                                              ctypes.byref(scr) if scr else None), "xsw_lut_upload")
+
+    @_locked
+    def build_lut(self, gmf_id, raw_axes, target):
+        """xsw_lut_build: raw_axes = (inc, wspd, phi or None) of the model's own grid; target = dict(inc, wspd[, phi, cos_phi,
+        sin_phi, out_dir, abs_co, dual_dir]) of the grid to search on.  The table is built and kept on the device."""
+        inc_r, wspd_r = _f64(raw_axes[0]), _f64(raw_axes[1])
+        phi_r = None if raw_axes[2] is None else _f64(raw_axes[2])
+        st, keep = self._lut_struct(None, **target)
+        self._check(self._lib.xsw_lut_build(self._h, int(gmf_id), _ptr(inc_r), len(inc_r), _ptr(wspd_r), len(wspd_r), _ptr(phi_r),
+                                            0 if phi_r is None else len(phi_r), ctypes.byref(st)), "xsw_lut_build")
+        del keep
+
+    @_locked
+    def read_lut(self, shape, cross=False):
+        """xsw_lut_read: the context's current dB table as a host array of `shape` (the caller knows the axes)."""
+        out = np.empty(shape, dtype=np.float64)
+        self._check(self._lib.xsw_lut_read(self._h, int(bool(cross)), _ptr(out)), "xsw_lut_read")
+        return out
 
     @_locked
     def lut_interp(self, raw, inc_raw, wspd_raw, phi_raw, inc, wspd, phi):

@@ -17,6 +17,7 @@
 #include "xsw_exhaustive.hpp"
 #include "xsw_gmf.hpp"
 #include "xsw_nesz.hpp"
+#include "xsw_lutbuild.hpp"
 
 using namespace xsw;
 
@@ -207,9 +208,12 @@ static int upload(xsw_ctx *c, std::vector<void *> &owner, const V *host, size_t 
     return XSW_OK;
 }
 
-static int upload_co(xsw_ctx *c, const xsw_lut *l)
+// Installs a co-pol LUT.  The dense dB table [n_inc][n_wspd][n_phi] comes from the host (l->db) or is already on the
+// device (d_dense, built by xsw_lut_build); the padded float64 copy, the float32 copy, the finiteness flag and max |dB|
+// are produced on the device either way (k_pad_co).
+static int install_co(xsw_ctx *c, const xsw_lut *l, const double *d_dense)
 {
-    if (!l->db || !l->inc || !l->wspd || !l->phi || l->n_inc < 1 || l->n_wspd < 1 || l->n_phi < 1)
+    if ((!l->db && !d_dense) || !l->inc || !l->wspd || !l->phi || l->n_inc < 1 || l->n_wspd < 1 || l->n_phi < 1)
         return fail(c, XSW_EINVAL, "co-pol LUT: null pointer or empty axis");
     if (!strictly_ascending(l->inc, l->n_inc) || !strictly_ascending(l->wspd, l->n_wspd) ||
         !strictly_ascending(l->phi, l->n_phi))
@@ -220,23 +224,44 @@ static int upload_co(xsw_ctx *c, const xsw_lut *l)
     DevTables &T = c->T;
     const int nI = l->n_inc, nW = l->n_wspd, nP = l->n_phi;
     const int ppad = (nP + 3) & ~3, wpad = (nW + 3) & ~3;
-    // padded incidence-major copy
-    std::vector<double> pad((size_t)nI * nW * ppad + (size_t)260 * ppad, 0.0);  // + slack rows: kernels read 4 row groups ahead unmasked
-    for (size_t r = 0; r < (size_t)nI * nW; ++r) memcpy(&pad[r * ppad], l->db + r * nP, nP * sizeof(double));
     int rc;
-    if ((rc = upload(c, c->co_allocs, pad.data(), pad.size(), &T.co))) return rc;
-    {
-        std::vector<float> pad32(pad.size());
-        double amax = 0.0;
-        for (size_t k = 0; k < pad.size(); ++k) {
-            pad32[k] = (float)pad[k];
-            const double v = std::fabs(pad[k]);
-            if (v > amax && std::isfinite(v)) amax = v;
-        }
-        T.co_absmax = amax;
-        if ((rc = upload(c, c->co_allocs, pad32.data(), pad32.size(), &T.co32))) return rc;
+    const size_t n_dense = (size_t)nI * nW * nP;
+    const size_t n_pad = (size_t)nI * nW * ppad + (size_t)260 * ppad;  // + slack rows: kernels read 4 row groups ahead unmasked
+    void *tmp_dense = nullptr;
+    if (!d_dense) {
+        HIPCHK(c, hipMalloc(&tmp_dense, n_dense * sizeof(double)));
+        hipError_t e = hipMemcpyAsync(tmp_dense, l->db, n_dense * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { (void)hipFree(tmp_dense); return fail(c, XSW_EHIP, "LUT upload failed: %s", hipGetErrorString(e)); }
+        d_dense = (const double *)tmp_dense;
     }
-    std::vector<double>().swap(pad);
+    bool lut_finite = false;
+    {
+        double *d_co = nullptr;
+        float *d_co32 = nullptr;
+        unsigned long long *d_flags = nullptr, h_flags[2] = {0, 0};
+        hipError_t e = hipMalloc((void **)&d_co, n_pad * sizeof(double) + 64);
+        if (e == hipSuccess) { c->co_allocs.push_back(d_co); e = hipMalloc((void **)&d_co32, n_pad * sizeof(float) + 64); }
+        if (e == hipSuccess) { c->co_allocs.push_back(d_co32); e = hipMalloc((void **)&d_flags, 2 * sizeof(unsigned long long)); }
+        if (e == hipSuccess) e = hipMemsetAsync(d_flags, 0, 2 * sizeof(unsigned long long), c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_co + (size_t)nI * nW * ppad, 0, (size_t)260 * ppad * sizeof(double), c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_co32 + (size_t)nI * nW * ppad, 0, (size_t)260 * ppad * sizeof(float), c->stream);
+        if (e == hipSuccess) {
+            const long long rows = (long long)nI * nW;
+            hipLaunchKernelGGL(k_pad_co, dim3((unsigned)std::min<long long>((rows + 3) / 4, 256 * 32)), dim3(256), 0, c->stream, d_dense, d_co,
+                               d_co32, nP, ppad, rows, d_flags);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(h_flags, d_flags, sizeof h_flags, hipMemcpyDeviceToHost, c->stream);
+        hipError_t se = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = se;
+        if (d_flags) (void)hipFree(d_flags);
+        if (tmp_dense) (void)hipFree(tmp_dense);
+        if (e != hipSuccess) return fail(c, e == hipErrorOutOfMemory ? XSW_ENOMEM : XSW_EHIP, "LUT install failed: %s", hipGetErrorString(e));
+        T.co = d_co;
+        T.co32 = d_co32;
+        lut_finite = h_flags[0] == 0;
+        memcpy(&T.co_absmax, &h_flags[1], sizeof(double));
+    }
     std::vector<double> wh(nW), cp(nP), sp(nP);
     for (int i = 0; i < nW; ++i) wh[i] = 0.5 * l->wspd[i];
     bool trig_ok = true;
@@ -290,7 +315,7 @@ static int upload_co(xsw_ctx *c, const xsw_lut *l)
     T.inv_wstep = nW > 1 ? (nW - 1) / (l->wspd[nW - 1] - l->wspd[0]) : 0.0;
     T.inv_dphi = nP > 1 ? (nP - 1) / (l->phi[nP - 1] - l->phi[0]) : 0.0;
     T.prunable = (nW >= 2 && nP >= 2 && nW < 32768 && nP < 65536 && (int64_t)nW * ppad < ((int64_t)1 << 30) && uniform_axis(l->wspd, nW) && uniform_axis(l->phi, nP) && trig_ok &&
-                  (l->phi[nP - 1] - l->phi[0]) <= 360.0 + 1e-9 && all_finite(l->db, (size_t)nI * nW * nP))
+                  (l->phi[nP - 1] - l->phi[0]) <= 360.0 + 1e-9 && lut_finite)
                      ? 1 : 0;
     T.co_off32 = ((uint64_t)nI * nW + 260) * (uint64_t)ppad * 8u < ((uint64_t)1 << 32) ? 1 : 0;
     // transposed slices for the ray scan
@@ -343,8 +368,24 @@ extern "C" int xsw_lut_upload(xsw_ctx *c, const xsw_lut *co, const xsw_lut *cr)
     if (!c) return XSW_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
-    if (co && (rc = upload_co(c, co))) return rc;
+    if (co && (rc = install_co(c, co, nullptr))) return rc;
     if (cr && (rc = upload_cr(c, cr))) return rc;
+    return XSW_OK;
+}
+
+extern "C" int xsw_lut_read(xsw_ctx *c, int32_t cross, double *out_db)
+{
+    if (!c || !out_db) return XSW_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    const DevTables &T = c->T;
+    if (cross ? !c->have_cr : !c->have_co) return fail(c, XSW_ENOLUT, "lut_read: no such LUT on this context");
+    if (cross)
+        HIPCHK(c, hipMemcpy2DAsync(out_db, (size_t)T.n_wcr * 8, T.cr, (size_t)T.wcr_pad * 8, (size_t)T.n_wcr * 8, (size_t)T.n_inc_cr,
+                                   hipMemcpyDeviceToHost, c->stream));
+    else
+        HIPCHK(c, hipMemcpy2DAsync(out_db, (size_t)T.n_phi * 8, T.co, (size_t)T.phi_pad * 8, (size_t)T.n_phi * 8,
+                                   (size_t)T.n_inc * T.n_w, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return XSW_OK;
 }
 
@@ -576,13 +617,13 @@ static bool left_neighbours(const double *x_old, int n_old, const double *x_new,
     return true;
 }
 
-extern "C" int xsw_lut_interp(xsw_ctx *c, const double *raw, const double *inc_raw, const double *wspd_raw,
-                              const double *phi_raw, int32_t n_inc_raw, int32_t n_wspd_raw, int32_t n_phi_raw,
-                              const double *inc, const double *wspd, const double *phi, int32_t n_inc, int32_t n_wspd,
-                              int32_t n_phi, double *out)
+// Interpolation with device-resident raw table and output (d_raw -> d_out); axes are host arrays.  Asynchronous on the
+// context's stream except for the small uploads; temporaries are appended to `tmp` (freed by the caller after a sync).
+static int interp_device(xsw_ctx *c, const double *d_raw, const double *inc_raw, const double *wspd_raw, const double *phi_raw,
+                         int32_t n_inc_raw, int32_t n_wspd_raw, int32_t n_phi_raw, const double *inc, const double *wspd,
+                         const double *phi, int32_t n_inc, int32_t n_wspd, int32_t n_phi, double *d_out, std::vector<void *> &tmp)
 {
-    if (!c) return XSW_EINVAL;
-    if (!raw || !inc_raw || !wspd_raw || !inc || !wspd || !out || n_inc_raw < 2 || n_wspd_raw < 2 || n_inc < 1 || n_wspd < 1)
+    if (!inc_raw || !wspd_raw || !inc || !wspd || n_inc_raw < 2 || n_wspd_raw < 2 || n_inc < 1 || n_wspd < 1)
         return fail(c, XSW_EINVAL, "lut_interp: null pointer or axis shorter than 2");
     const bool has_phi = n_phi_raw > 0;
     if (has_phi && (!phi_raw || !phi || n_phi_raw < 2 || n_phi < 1)) return fail(c, XSW_EINVAL, "lut_interp: bad phi axis");
@@ -593,8 +634,6 @@ extern "C" int xsw_lut_interp(xsw_ctx *c, const double *raw, const double *inc_r
     if (!left_neighbours(inc_raw, n_inc_raw, inc, n_inc, loi) || !left_neighbours(wspd_raw, n_wspd_raw, wspd, n_wspd, low) ||
         (has_phi && !left_neighbours(phi_raw, n_phi_raw, phi, n_phi, lop)))
         return fail(c, XSW_EINVAL, "A value in x_new is outside the interpolation range.");
-    HIPCHK(c, hipSetDevice(c->device));
-    std::vector<void *> tmp;
     InterpArgs a{};
     int rc = XSW_OK;
     auto up = [&](const void *h, size_t bytes, const void **d) {
@@ -602,12 +641,10 @@ extern "C" int xsw_lut_interp(xsw_ctx *c, const double *raw, const double *inc_r
         if (rc) return;
         if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) { rc = fail(c, XSW_ENOMEM, "lut_interp: hipMalloc failed"); return; }
         tmp.push_back(p);
-        if (bytes && hipMemcpyAsync(p, h, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(c, XSW_EHIP, "lut_interp: H2D failed");
+        if (bytes && hipMemcpy(p, h, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = fail(c, XSW_EHIP, "lut_interp: H2D failed");
         *d = p;
     };
-    const size_t n_raw = (size_t)n_inc_raw * n_wspd_raw * (has_phi ? n_phi_raw : 1);
-    const size_t n_out = (size_t)n_inc * n_wspd * (has_phi ? n_phi : 1);
-    up(raw, n_raw * 8, (const void **)&a.raw);
+    a.raw = d_raw;
     up(inc_raw, (size_t)n_inc_raw * 8, (const void **)&a.xi_raw);
     up(wspd_raw, (size_t)n_wspd_raw * 8, (const void **)&a.xw_raw);
     up(inc, (size_t)n_inc * 8, (const void **)&a.xi);
@@ -619,23 +656,116 @@ extern "C" int xsw_lut_interp(xsw_ctx *c, const double *raw, const double *inc_r
         up(phi, (size_t)n_phi * 8, (const void **)&a.xp);
         up(lop.data(), lop.size() * 4, (const void **)&a.lop);
     }
-    if (!rc) {
-        void *p = nullptr;
-        if (hipMalloc(&p, n_out * 8) != hipSuccess) rc = fail(c, XSW_ENOMEM, "lut_interp: hipMalloc(out) failed");
-        else { tmp.push_back(p); a.out = (double *)p; }
-    }
+    a.out = d_out;
     a.ni_raw = n_inc_raw; a.nw_raw = n_wspd_raw; a.np_raw = has_phi ? n_phi_raw : 0;
     a.ni = n_inc; a.nw = n_wspd; a.np = has_phi ? n_phi : 0;
     if (!rc) {
+        const size_t n_out = (size_t)n_inc * n_wspd * (has_phi ? n_phi : 1);
         long long blocks = (long long)((n_out + 255) / 256);
         if (blocks > 256 * 16) blocks = 256 * 16;
         hipLaunchKernelGGL(k_lut_interp, dim3((unsigned)blocks), dim3(256), 0, c->stream, a);
         if (hipGetLastError() != hipSuccess) rc = fail(c, XSW_EHIP, "lut_interp: launch failed");
     }
-    if (!rc && hipMemcpyAsync(out, a.out, n_out * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+    return rc;
+}
+
+extern "C" int xsw_lut_interp(xsw_ctx *c, const double *raw, const double *inc_raw, const double *wspd_raw,
+                              const double *phi_raw, int32_t n_inc_raw, int32_t n_wspd_raw, int32_t n_phi_raw,
+                              const double *inc, const double *wspd, const double *phi, int32_t n_inc, int32_t n_wspd,
+                              int32_t n_phi, double *out)
+{
+    if (!c) return XSW_EINVAL;
+    if (!raw || !out) return fail(c, XSW_EINVAL, "lut_interp: null pointer or axis shorter than 2");
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool has_phi = n_phi_raw > 0;
+    std::vector<void *> tmp;
+    const size_t n_raw = (size_t)std::max(n_inc_raw, 0) * std::max(n_wspd_raw, 0) * (has_phi ? n_phi_raw : 1);
+    const size_t n_out = (size_t)std::max(n_inc, 0) * std::max(n_wspd, 0) * (has_phi ? std::max(n_phi, 0) : 1);
+    void *d_raw = nullptr, *d_out = nullptr;
+    int rc = XSW_OK;
+    if (hipMalloc(&d_raw, n_raw * 8 + 8) != hipSuccess || hipMalloc(&d_out, n_out * 8 + 8) != hipSuccess)
+        rc = fail(c, XSW_ENOMEM, "lut_interp: hipMalloc failed");
+    if (d_raw) tmp.push_back(d_raw);
+    if (d_out) tmp.push_back(d_out);
+    if (!rc && hipMemcpyAsync(d_raw, raw, n_raw * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(c, XSW_EHIP, "lut_interp: H2D failed");
+    if (!rc) rc = interp_device(c, (const double *)d_raw, inc_raw, wspd_raw, phi_raw, n_inc_raw, n_wspd_raw, n_phi_raw, inc, wspd, phi,
+                                n_inc, n_wspd, n_phi, (double *)d_out, tmp);
+    if (!rc && hipMemcpyAsync(out, d_out, n_out * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
         rc = fail(c, XSW_EHIP, "lut_interp: D2H failed");
     hipError_t se = hipStreamSynchronize(c->stream);
     if (!rc && se != hipSuccess) rc = fail(c, XSW_EHIP, "lut_interp: %s", hipGetErrorString(se));
+    for (void *p : tmp) (void)hipFree(p);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------- device-side LUT build
+static bool same_axis(const double *a, int na, const double *b, int nb)
+{
+    if (na != nb) return false;
+    for (int i = 0; i < na; ++i)
+        if (a[i] != b[i]) return false;
+    return true;
+}
+
+extern "C" int xsw_lut_build(xsw_ctx *c, int32_t gmf_id, const double *inc_raw, int32_t n_inc_raw, const double *wspd_raw,
+                             int32_t n_wspd_raw, const double *phi_raw, int32_t n_phi_raw, const xsw_lut *target)
+{
+    if (!c) return XSW_EINVAL;
+    if (gmf_id < 0 || gmf_id >= GMF_COUNT) return fail(c, XSW_EINVAL, "unknown gmf_id %d", gmf_id);
+    if (!target || !inc_raw || !wspd_raw || !target->inc || !target->wspd || n_inc_raw < 1 || n_wspd_raw < 1 ||
+        target->n_inc < 1 || target->n_wspd < 1)
+        return fail(c, XSW_EINVAL, "lut_build: null pointer or empty axis");
+    const bool copol = gmf_id <= GMF_CMODIFR2;
+    if (copol != (n_phi_raw > 0) || copol != (target->n_phi > 0) || (copol && (!phi_raw || !target->phi)))
+        return fail(c, XSW_EINVAL, "lut_build: a co-pol GMF needs phi axes, a cross-pol GMF must not have them");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int npr = copol ? n_phi_raw : 1, npt = copol ? target->n_phi : 1;
+    const size_t n_raw = (size_t)n_inc_raw * n_wspd_raw * npr, n_out = (size_t)target->n_inc * target->n_wspd * npt;
+    std::vector<void *> tmp;
+    int rc = XSW_OK;
+    auto dev = [&](const void *h, size_t bytes) -> void * {
+        void *p = nullptr;
+        if (rc) return nullptr;
+        if (hipMalloc(&p, bytes + 8) != hipSuccess) { rc = fail(c, XSW_ENOMEM, "lut_build: hipMalloc(%zu) failed", bytes); return nullptr; }
+        tmp.push_back(p);
+        if (h && hipMemcpy(p, h, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = fail(c, XSW_EHIP, "lut_build: H2D failed");
+        return p;
+    };
+    const double *d_i = (const double *)dev(inc_raw, (size_t)n_inc_raw * 8), *d_w = (const double *)dev(wspd_raw, (size_t)n_wspd_raw * 8);
+    const double *d_p = copol ? (const double *)dev(phi_raw, (size_t)n_phi_raw * 8) : nullptr;
+    double *d_raw = (double *)dev(nullptr, n_raw * 8);
+    if (!rc) {
+        hipLaunchKernelGGL(k_gmf_grid, dim3((unsigned)std::min<size_t>((n_raw + 255) / 256, 256 * 16)), dim3(256), 0, c->stream, (int)gmf_id,
+                           d_i, d_w, d_p, n_inc_raw, n_wspd_raw, copol ? n_phi_raw : 0, d_raw);
+        if (hipGetLastError() != hipSuccess) rc = fail(c, XSW_EHIP, "lut_build: launch failed");
+    }
+    // resolution change only when the grids differ (Model._normalize_lut returns the raw LUT as is otherwise)
+    const bool same = same_axis(inc_raw, n_inc_raw, target->inc, target->n_inc) && same_axis(wspd_raw, n_wspd_raw, target->wspd, target->n_wspd) &&
+                      (!copol || same_axis(phi_raw, n_phi_raw, target->phi, target->n_phi));
+    double *d_dense = d_raw;
+    if (!rc && !same) {
+        d_dense = (double *)dev(nullptr, n_out * 8);
+        if (!rc) rc = interp_device(c, d_raw, inc_raw, wspd_raw, phi_raw, n_inc_raw, n_wspd_raw, copol ? n_phi_raw : 0, target->inc,
+                                    target->wspd, target->phi, target->n_inc, target->n_wspd, copol ? target->n_phi : 0, d_dense, tmp);
+    }
+    if (!rc) {
+        hipLaunchKernelGGL(k_to_db, dim3((unsigned)std::min<size_t>((n_out + 255) / 256, 256 * 16)), dim3(256), 0, c->stream, d_dense, (long long)n_out);
+        if (hipGetLastError() != hipSuccess) rc = fail(c, XSW_EHIP, "lut_build: launch failed");
+    }
+    if (!rc && copol) rc = install_co(c, target, d_dense);
+    if (!rc && !copol) {  // cross-pol tables are small (a few MB): the host-side checks of upload_cr are reused
+        std::vector<double> h(n_out);
+        hipError_t e = hipMemcpyAsync(h.data(), d_dense, n_out * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(c, XSW_EHIP, "lut_build: D2H failed: %s", hipGetErrorString(e));
+        if (!rc) {
+            xsw_lut t = *target;
+            t.db = h.data();
+            rc = upload_cr(c, &t);
+        }
+    }
+    hipError_t se = hipStreamSynchronize(c->stream);
+    if (!rc && se != hipSuccess) rc = fail(c, XSW_EHIP, "lut_build: %s", hipGetErrorString(se));
     for (void *p : tmp) (void)hipFree(p);
     return rc;
 }

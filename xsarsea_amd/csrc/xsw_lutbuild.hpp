@@ -1,0 +1,65 @@
+// Device side of the LUT preparation (reference: GmfModel._raw_lut, gmfs.py:350-395; Model._normalize_lut,
+// models.py:142-168; the dB conversion of Model.to_lut, models.py:210-216; the closure arrays of
+// _invert_from_model_numpy, windspeed.py:144-181).  With these kernels a built-in GMF goes from its name to a searchable
+// table without the 362 MB float64 block ever visiting the host:
+//   k_gmf_grid   raw[i][j][k] = gmf(inc[i], wspd[j], phi[k])          (the fill of the raw grid, linear units)
+//   k_lut_interp low -> high resolution (xsw_device.hpp)
+//   k_to_db      10 log10(x + 1e-15) in place
+//   k_pad_co     dense [n_inc][n_wspd][n_phi] -> phi-padded float64 + float32 copies, finiteness flag, max |dB|
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "xsw_gmf.hpp"
+
+namespace xsw {
+
+__global__ __launch_bounds__(256) void k_gmf_grid(int id, const double *__restrict__ inc, const double *__restrict__ wspd,
+                                                  const double *__restrict__ phi, int ni, int nw, int np, double *__restrict__ out)
+{
+    const int npp = np > 0 ? np : 1;
+    const long long n = (long long)ni * nw * npp;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(t % npp), j = (int)((t / npp) % nw), i = (int)(t / ((long long)npp * nw));
+        out[t] = gmf_eval(id, inc[i], wspd[j], np > 0 ? phi[k] : 0.0);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_to_db(double *__restrict__ x, long long n)
+{
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x)
+        x[t] = 10.0 * log10(x[t] + 1e-15);
+}
+
+// One wave per LUT row (n_phi values -> phi_pad slots, the pad zero-filled); flags[0] |= 1 when a value is not finite,
+// flags[1] = bits of max |finite value| (non-negative doubles order like their bit patterns).
+__global__ __launch_bounds__(256) void k_pad_co(const double *__restrict__ dense, double *__restrict__ co,
+                                                float *__restrict__ co32, int n_phi, int phi_pad, long long rows,
+                                                unsigned long long *__restrict__ flags)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+    double amax = 0.0;
+    bool bad = false;
+    for (long long r = wave0; r < rows; r += nwaves) {
+        const double *src = dense + r * n_phi;
+        double *dst = co + r * phi_pad;
+        float *dst32 = co32 + r * phi_pad;
+        for (int k = lane; k < phi_pad; k += 64) {
+            const double v = k < n_phi ? src[k] : 0.0;
+            dst[k] = v;
+            dst32[k] = (float)v;
+            const double a = fabs(v);
+            if (a <= 1.79769313486231570815e308) amax = fmax(amax, a); else bad = true;  // NaN and inf fail the test
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off));
+    const unsigned long long any_bad = __ballot(bad);
+    if (lane == 0) {
+        if (any_bad) atomicOr(&flags[0], 1ULL);
+        atomicMax(&flags[1], (unsigned long long)__double_as_longlong(amax));
+    }
+}
+
+}  // namespace xsw

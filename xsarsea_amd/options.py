@@ -29,3 +29,10 @@ gmf_device_min_size = 1 << 18
 #: 1e-10 relative of the host route, which reproduces numpy's polyfit bit for bit -- "host", "device".
 nesz_on_device = "auto"
 nesz_device_min_size = 1 << 20
+
+#: where the dB LUT of a built-in GMF is prepared for `invert_from_model`:
+#:   "host"   : `Model.to_lut` on the host (numpy GMF fill + interpolation (see lut_interp) + numpy log10), then uploaded --
+#:              the table is bit-identical to what a CPU run of the reference on this host searches (the default);
+#:   "device" : `xsw_lut_build` -- grid fill, interpolation, dB conversion and search layout all on the device, the
+#:              362 MB table never exists on the host (values within ~1e-13 dB of the host-built table: device libm).
+lut_build = "host"

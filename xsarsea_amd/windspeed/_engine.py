@@ -49,13 +49,53 @@ def _cr_dict(lut):
     return dict(db=db, inc=inc, wspd=wspd)
 
 
+class DeviceLut:
+    """A LUT that is BUILT on the device (`xsw_lut_build`: GMF grid fill -> interpolation -> dB -> search layout) instead of
+    being prepared on the host and uploaded; stands where a host `Lut` stands in `invert_numpy`.  Carries the axes only."""
+
+    def __init__(self, model_name, gmf_id, raw_axes, target_axes, key):
+        self.model_name, self.gmf_id, self.raw_axes, self.key = model_name, gmf_id, raw_axes, key
+        self.incidence, self.wspd, self.phi = target_axes
+        self.shape = tuple(len(a) for a in target_axes if a is not None)
+
+    def build(self, ctx):
+        target = dict(inc=self.incidence, wspd=self.wspd)
+        if self.phi is not None:
+            target.update(phi=self.phi, **host_tables(self.wspd, self.phi))
+        ctx.build_lut(self.gmf_id, self.raw_axes, target)
+
+
+_device_luts = {}
+
+
+def lut_source(model, kwargs):
+    """The dB LUT `invert_from_model` searches for `model`: the host-prepared `Lut` (`Model._lut`, memoised; the default:
+    bit parity with a CPU run of the reference on this host), or -- `options.lut_build = "device"`, built-in GMFs only -- a
+    `DeviceLut` whose table never exists on the host."""
+    if options.lut_build == "device" and hasattr(model, "device_lut_plan"):
+        plan = model.device_lut_plan(**kwargs)
+        if plan is not None:
+            key = (model.name,) + tuple(sorted(kwargs.items()))
+            hit = _device_luts.get(key)
+            if hit is None:
+                hit = _device_luts[key] = DeviceLut(model.name, plan[0], plan[1], plan[2], key)
+            return hit
+    return model._lut(units="dB", **kwargs)
+
+
 def ensure_luts(ctx, lut_co, lut_cr):
-    """Upload the dB LUT objects unless this context already holds exactly them."""
+    """Upload (or build in place) the dB LUT objects unless this context already holds exactly them."""
     key_co, key_cr = ctx.lut_key
     up_co = lut_co is not None and key_co is not lut_co
     up_cr = lut_cr is not None and key_cr is not lut_cr
+    for lut, up in ((lut_co, up_co), (lut_cr, up_cr)):
+        if up and isinstance(lut, DeviceLut):
+            lut.build(ctx)
+    host_co = up_co and not isinstance(lut_co, DeviceLut)
+    host_cr = up_cr and not isinstance(lut_cr, DeviceLut)
+    if host_co or host_cr:
+        ctx.upload_luts(co=_co_dict(lut_co) if host_co else None, cr=_cr_dict(lut_cr) if host_cr else None)
     if up_co or up_cr:
-        ctx.upload_luts(co=_co_dict(lut_co) if up_co else None, cr=_cr_dict(lut_cr) if up_cr else None)
         ctx.lut_key = (lut_co if up_co else key_co, lut_cr if up_cr else key_cr)
 
 

@@ -148,7 +148,8 @@ class GmfModel(Model):
         return np.ascontiguousarray(
             _array_eval(self._gmf_pyfunc_scalar, inc[:, None, None], wspd[None, :, None], phi[None, None, :]))
 
-    def _raw_lut(self, **kwargs):
+    def _raw_axes(self, **kwargs):
+        """Grid the raw LUT is generated on (gmfs.py:350-384): (inc, wspd, phi, resolution, generated steps)."""
         resolution = kwargs.get("resolution", "low")  # generated at low resolution by default (:353)
         if resolution not in ("low", "high", None):
             raise ValueError('kwargs resolution must be "low" or "high" or None, or not provided')
@@ -161,5 +162,22 @@ class GmfModel(Model):
         steps = {n: kwargs.get(f"{n}_step{sfx}", getattr(self, f"{n}_step{sfx}")) for n in ("inc", "wspd", "phi")}
         inc, wspd, phi = (axis_grid(r, steps[n]) for r, n in
                           zip((self.inc_range, self.wspd_range, self.phi_range), ("inc", "wspd", "phi")))
+        return inc, wspd, phi, resolution, steps
+
+    def _raw_lut(self, **kwargs):
+        inc, wspd, phi, resolution, steps = self._raw_axes(**kwargs)
         return Lut(self._grid(inc, wspd, phi), inc, wspd, phi, units=self.units, resolution=resolution,
                    generated_steps=steps)
+
+    def device_lut_plan(self, **kwargs):
+        """(gmf_id, raw axes, target axes) for `xsw_lut_build`, or None when this model / these kwargs cannot be built on the
+        device (not a built-in GMF, not in linear units).  Same grid policy as `_raw_lut` + `Model._normalize_lut`."""
+        from .. import _lib
+        gid = _lib.GMF_IDS.get(self.name) if getattr(self, "_builtin", False) else None
+        if gid is None or self.units != "linear":
+            return None
+        inc, wspd, phi, have, steps = self._raw_axes(**kwargs)
+        target = self._normalized_axes(have, steps, phi is not None, **kwargs)
+        if target is None:
+            target = (inc, wspd, phi)
+        return gid, (inc, wspd, phi), target

@@ -91,21 +91,30 @@ class Model:
         steps = [kwargs.get(f"{n}_step{sfx}", getattr(self, f"{n}_step{sfx}")) for n in ("inc", "wspd", "phi")]
         return [axis_grid(r, st) for r, st in zip((self.inc_range, self.wspd_range, self.phi_range), steps)]
 
+    def _normalized_axes(self, have, generated_steps, has_phi, **kwargs):
+        """Resolution policy of `_normalize_lut` (models.py:107-173) on axes alone: the target (inc, wspd, phi) axes when a
+        LUT generated at resolution `have` (with `generated_steps`, or None) must be interpolated, None when it is used as is."""
+        resolution = kwargs.get("resolution") or "high"
+        do_interp = False
+        if resolution == have:
+            sfx = "" if resolution == "high" else "_lr"
+            names = ["inc", "wspd"] + (["phi"] if self.iscopol else [])
+            own = generated_steps or {n: getattr(self, f"{n}_step{sfx}") for n in names}
+            do_interp = any(own[n] != kwargs.get(f"{n}_step{sfx}", own[n]) for n in names)
+        if resolution == have and not do_interp:
+            return None
+        inc, wspd, phi = self._target_axes(resolution, kwargs)
+        return inc, wspd, (phi if has_phi else None)
+
     def _normalize_lut(self, lut, **kwargs):
         """Bring `lut` to the requested resolution (default "high") by separable linear interpolation,
         in the LUT's own units, exactly when the reference does (models.py:107-173)."""
         lut = Lut.from_any(lut)
         resolution = kwargs.get("resolution") or "high"
-        have = lut.attrs["resolution"]
-        do_interp = False
-        if resolution == have:
-            sfx = "" if resolution == "high" else "_lr"
-            names = ["inc", "wspd"] + (["phi"] if self.iscopol else [])
-            own = lut.attrs.get("generated_steps") or {n: getattr(self, f"{n}_step{sfx}") for n in names}
-            do_interp = any(own[n] != kwargs.get(f"{n}_step{sfx}", own[n]) for n in names)
-        if resolution == have and not do_interp:
+        target = self._normalized_axes(lut.attrs["resolution"], lut.attrs.get("generated_steps"), lut.phi is not None, **kwargs)
+        if target is None:
             return lut
-        inc, wspd, phi = self._target_axes(resolution, kwargs)
+        inc, wspd, phi = target
         if lut.phi is None or phi is None:
             phi = lut.phi
         vals = _interp(lut, inc, wspd, phi)

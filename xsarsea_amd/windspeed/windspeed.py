@@ -96,8 +96,8 @@ def invert_from_model(inc, sigma0, sigma0_dual=None, /, ancillary_wind=None, dsi
     else:
         sigma0_co, sigma0_cr = sigma0, sigma0_dual
 
-    lut_co = models[0]._lut(units="dB", **kwargs) if models[0] is not None else None
-    lut_cr = models[1]._lut(units="dB", **kwargs) if (models[1] is not None and sigma0_cr is not None) else None
+    lut_co = _engine.lut_source(models[0], kwargs) if models[0] is not None else None
+    lut_cr = _engine.lut_source(models[1], kwargs) if (models[1] is not None and sigma0_cr is not None) else None
     if sigma0_cr is not None and lut_cr is None:
         raise ValueError("a cross-pol sigma0 was given but `model` names no cross-pol model")
 
