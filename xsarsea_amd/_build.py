@@ -40,5 +40,44 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def kernel_resources(lib=None):
+    """Per-kernel register / LDS / scratch figures read from the gfx950 code object inside libxsw.so (the
+    `amdhsa.kernels` metadata note: .vgpr_count, .agpr_count, .sgpr_count, .group_segment_fixed_size,
+    .private_segment_fixed_size), plus the waves per SIMD the VGPR count allows (512 VGPRs per SIMD lane, allocation
+    granule 8, at most 8 waves).  Returns a list of dicts sorted by kernel name."""
+    import re
+    import tempfile
+    lib = lib or LIB
+    llvm = "/opt/rocm/lib/llvm/bin"
+    with tempfile.TemporaryDirectory() as td:
+        fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "dev.co")
+        subprocess.check_call([f"{llvm}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", lib, os.path.join(td, "unused.so")])
+        subprocess.check_call([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o",
+                               f"--targets=hipv4-amdgcn-amd-amdhsa--{ARCH}", f"--input={fat}", f"--output={co}"])
+        notes = subprocess.check_output([f"{llvm}/llvm-readelf", "--notes", co], text=True)
+        try:
+            names = subprocess.check_output([f"{llvm}/llvm-cxxfilt"] + re.findall(r"\.name:\s+(\S+)", notes), text=True).splitlines()
+        except (OSError, subprocess.CalledProcessError):
+            names = re.findall(r"\.name:\s+(\S+)", notes)
+    out = []
+    for blk, name in zip(re.split(r"\n\s+- (?=\.agpr_count)", notes)[1:], names):
+        g = lambda key: int(re.search(rf"\.{key}:\s+(\d+)", blk).group(1))
+        vg, ag = g("vgpr_count"), g("agpr_count")
+        alloc = -(-max(vg + ag, 1) // 8) * 8
+        out.append(dict(kernel=name, vgpr=vg, agpr=ag, sgpr=g("sgpr_count"), lds_bytes=g("group_segment_fixed_size"),
+                        scratch_bytes=g("private_segment_fixed_size"), waves_per_simd_by_vgpr=min(8, 512 // alloc)))
+    return sorted(out, key=lambda d: d["kernel"])
+
+
+def write_kernel_resources(path):
+    rows = kernel_resources()
+    with open(path, "w") as f:
+        f.write("# per-kernel resources of libxsw.so's gfx950 code object (xsarsea_amd/_build.py: kernel_resources)\n")
+        f.write("vgpr\tagpr\tsgpr\tlds_B\tscratch_B\twaves/SIMD(vgpr)\tkernel\n")
+        for r in rows:
+            f.write(f"{r['vgpr']}\t{r['agpr']}\t{r['sgpr']}\t{r['lds_bytes']}\t{r['scratch_bytes']}\t{r['waves_per_simd_by_vgpr']}\t{r['kernel']}\n")
+    return rows
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
