@@ -116,3 +116,96 @@ def pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig):
             best = key
     flat = best[1]
     return flat // n_phi, flat % n_phi, js.size + nray
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Band pruning (round 2): the sigma0 term alone is also >= 0, so a candidate with ((L - s)/dsig)^2 > J_ub cannot be the
+# argmin either: |L - s| <= d = |dsig| sqrt(J_ub) is necessary.  Where every LUT column is non-decreasing in the wind
+# speed over the rows of the window, that set is ONE row interval per direction, [lower_bound(s - d), upper_bound(s + d)),
+# found by bisection inside the window: a handful of candidates per direction instead of the whole window column.
+def mono_rows(slice_wp):
+    """Largest R such that every column of the (n_w, n_phi) slice is non-decreasing over rows [0, R)."""
+    dec = np.diff(slice_wp, axis=0) < 0  # also False for NaN (a NaN LUT is not prunable at all)
+    if not dec.any():
+        return slice_wp.shape[0]
+    first = np.where(dec.any(axis=0), dec.argmax(axis=0), slice_wp.shape[0])
+    return int(first.min()) + 1
+
+
+def band_radius(j_ub, dsig):
+    """d such that every candidate with ((L - s)/dsig)^2 <= j_ub has |L - s| <= d (inflated: rounding never excludes one)."""
+    return abs(dsig) * np.sqrt(j_ub) * (1.0 + 1e-9) + 1e-12
+
+
+def band_pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig, max_len=16):
+    """Like pruned_argmin, with the band rule on top of the disc window.  Returns (i_wspd, i_phi, n_evaluated, used_band);
+    falls back to pruned_argmin when the window leaves the monotone rows, a band is longer than max_len, or the screening
+    cannot decide (the device then re-does the pixel with the window sweep)."""
+    n_w, n_phi = slice_wp.shape
+    if phi_180:
+        b = abs(b)
+    if not (np.isfinite(s) and np.isfinite(a) and np.isfinite(b)):
+        return None
+    w0, inv_wstep = wspd[0], (n_w - 1) / (wspd[-1] - wspd[0])
+    phi0, inv_dphi = phi[0], (n_phi - 1) / (phi[-1] - phi[0])
+    inv = 1.0 / dsig
+    sn = -s * inv
+    ah, bh = 0.5 * a, 0.5 * b
+    m2 = ah * ah + bh * bh
+    mag = np.sqrt(a * a + b * b)
+    theta = np.degrees(np.arctan2(b, a))
+    if theta < phi0:
+        theta += 360.0
+    ipr = int(np.clip(np.rint((theta - phi0) * inv_dphi), 0, n_phi - 1))
+    wh = 0.5 * wspd
+    ur = 2.0 * (ah * cphi[ipr] + bh * sphi[ipr])
+    npairs = (n_w + 1) >> 1
+    lo, hi, rbest, nray = 0, npairs, np.inf, 0
+    col = slice_wp[:, ipr]
+    for _ in range(int(npairs).bit_length()):
+        mid = min((lo + hi) >> 1, npairs - 1)
+        ja = wh[2 * mid] * (wh[2 * mid] - ur) + (col[2 * mid] * inv + sn) ** 2
+        jb = wh[2 * mid + 1] * (wh[2 * mid + 1] - ur) + (col[2 * mid + 1] * inv + sn) ** 2 if 2 * mid + 1 < n_w else np.inf
+        rbest = min(rbest, ja, jb)
+        nray += 2
+        if lo < hi:
+            if jb < ja:
+                lo = mid + 1
+            else:
+                hi = mid
+    j_ub = (rbest + m2) * (1.0 + 1e-9) + 1e-9
+    w_lo, w_hi, ip_lo, ip_hi = search_window(mag, theta, rbest + m2, w0, inv_wstep, n_w, phi0, phi[-1], inv_dphi, n_phi)
+
+    def fallback():
+        r = pruned_argmin(slice_wp, wspd, phi, cphi, sphi, False, s, a, b, dsig)
+        return r[0], r[1], r[2], False
+
+    if w_hi >= mono_rows(slice_wp) or ip_hi - ip_lo + 1 > 64:
+        return fallback()
+    d = band_radius(j_ub, dsig)
+    cand = []
+    for ip in range(ip_lo, ip_hi + 1):
+        c = slice_wp[:, ip]
+        lo_r, hi_r = w_lo, w_hi + 1
+        while lo_r < hi_r:  # lower_bound(s - d) inside the window
+            mid = (lo_r + hi_r) >> 1
+            if c[mid] < s - d:
+                lo_r = mid + 1
+            else:
+                hi_r = mid
+        r = lo_r
+        n = 0
+        while r <= w_hi and c[r] <= s + d:
+            n += 1
+            if n > max_len:
+                return fallback()
+            u = 2.0 * (ah * cphi[ip] + bh * sphi[ip])
+            cand.append((wh[r] * (wh[r] - u) + (c[r] * inv + sn) ** 2, r, ip))
+            r += 1
+    assert cand, "the ray's best candidate always lies in the band"
+    js = np.array([c[0] for c in cand])
+    gmin = js.min()
+    keep = [c for c in cand if c[0] <= gmin + screening_eps(gmin, m2)]
+    if len(keep) != 1:
+        return fallback()  # the device settles near-ties in the window sweep
+    return keep[0][1], keep[0][2], len(cand) + nray, True

@@ -66,3 +66,43 @@ def test_search_window_contains_disc(seed):
         if iw.size:
             assert w_lo <= iw.min() and iw.max() <= w_hi, (case, mag, R, theta, w_lo, w_hi, iw.min(), iw.max())
             assert ip_lo <= ip.min() and ip.max() <= ip_hi, (case, mag, R, theta, ip_lo, ip_hi, ip.min(), ip.max())
+
+
+@pytest.mark.parametrize("kind", ["smooth", "plateaus", "rolloff", "noisy"])
+def test_band_rule_never_excludes_the_argmin(kind):
+    """Round-2 band pruning (|L - s| <= dsig sqrt(J_ub), one row interval per direction on monotone columns): same argmin
+    as the oracle on a smooth LUT, a LUT quantised to 0.05 dB (long exact plateaus), a LUT that rolls off at high wind
+    (the window must stay inside the monotone rows or fall back) and a noisy LUT (never eligible: always falls back)."""
+    rng = np.random.default_rng({"smooth": 1, "plateaus": 2, "rolloff": 3, "noisy": 4}[kind])
+    inc_ax, w_ax, phi_ax = np.linspace(20, 44, 7), np.linspace(0.5, 39.5, 196), np.linspace(0, 180, 91)
+    co = 10 * np.log10(gmf.gmf_cmod5n(inc_ax[:, None, None], w_ax[None, :, None], phi_ax[None, None, :]) + 1e-15)
+    if kind == "plateaus":
+        co = np.round(co / 0.05) * 0.05
+    elif kind == "rolloff":
+        co = co - 0.02 * np.maximum(w_ax[None, :, None] - 24.0, 0.0) ** 2
+    elif kind == "noisy":
+        co = co + 0.05 * rng.standard_normal(co.shape)
+    lco = olut.Lut(co, inc_ax, w_ax, phi_ax, "dB", "x", "co", "VV")
+    p = oinv.Prepared(lco, None)
+    n = 1200
+    inc, wt, pt = rng.uniform(18, 46, n), rng.uniform(0.5, 35, n), rng.uniform(-180, 180, n)
+    s = oinv.to_db(gmf.gmf_cmod5n(inc, wt, pt) * rng.gamma(100, 1 / 100, n))
+    anc = wt * np.exp(1j * np.deg2rad(pt)) + rng.normal(0, 1.5, n) + 1j * rng.normal(0, 1.5, n)
+    anc[:150] = rng.uniform(0, 40, 150) * np.exp(1j * rng.uniform(-np.pi, np.pi, 150))
+    nan = np.full(n, np.nan)
+    idx = cport.invert_numpy(p, inc, s, nan, nan, anc, return_idx=True, reference_layout=False)[2]
+    cphi, sphi = np.cos(np.radians(phi_ax)), np.sin(np.radians(phi_ax))
+    used, evaluated = 0, []
+    for i in range(n):
+        ii = np.argmin(np.abs(inc_ax - inc[i]))
+        r = pm.band_pruned_argmin(co[ii], w_ax, phi_ax, cphi, sphi, p.phi_180, s[i], anc[i].real, anc[i].imag, 0.1)
+        assert (r[0], r[1]) == (idx[i, 0], idx[i, 1]), (kind, i, r, idx[i])
+        used += r[3]
+        if r[3]:
+            evaluated.append(r[2])
+    if kind == "noisy":
+        assert used == 0
+    else:
+        assert used > 0.5 * n and np.mean(evaluated) < 120, (used, np.mean(evaluated))
+    # CMOD5.N itself saturates and decreases at high wind / low incidence: the monotone prefix is a per-slice property
+    assert pm.mono_rows(co[0]) < len(w_ax) and (kind == "noisy" or pm.mono_rows(co[-1]) == len(w_ax))

@@ -251,6 +251,18 @@ static int install_co(xsw_ctx *c, const xsw_lut *l, const double *d_dense)
                                d_co32, nP, ppad, rows, d_flags);
             e = hipGetLastError();
         }
+        int *d_mono = nullptr;
+        if (e == hipSuccess) e = hipMalloc((void **)&d_mono, (size_t)nI * sizeof(int) + 64);
+        if (e == hipSuccess) {
+            c->co_allocs.push_back(d_mono);
+            std::vector<int> init((size_t)nI, nW);
+            e = hipMemcpy(d_mono, init.data(), (size_t)nI * sizeof(int), hipMemcpyHostToDevice);
+        }
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_mono_rows, dim3((unsigned)(((long long)nI * nP + 255) / 256)), dim3(256), 0, c->stream, d_dense, nI, nW, nP, d_mono);
+            e = hipGetLastError();
+        }
+        T.mono_rows = d_mono;
         if (e == hipSuccess) e = hipMemcpyAsync(h_flags, d_flags, sizeof h_flags, hipMemcpyDeviceToHost, c->stream);
         hipError_t se = hipStreamSynchronize(c->stream);
         if (e == hipSuccess) e = se;

@@ -62,4 +62,24 @@ __global__ __launch_bounds__(256) void k_pad_co(const double *__restrict__ dense
     }
 }
 
+// out[i] = min over the directions of slice i of (index of the first row that is LOWER than its predecessor), n_w when
+// none: every column of slice i is non-decreasing in wind speed over rows [0, out[i]) -- the precondition of the band
+// pruning of co_band_pass (CMOD5.N itself saturates and decreases beyond 24..40 m/s at incidences below 41 deg).
+// out[] preset to n_w by the host.
+__global__ __launch_bounds__(256) void k_mono_rows(const double *__restrict__ dense, int n_inc, int n_w, int n_phi, int *__restrict__ out)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n_inc * n_phi) return;
+    const int i = (int)(t / n_phi), p = (int)(t % n_phi);
+    const double *col = dense + (size_t)i * n_w * n_phi + p;
+    int first = n_w;
+    double prev = col[0];
+    for (int r = 1; r < n_w; ++r) {
+        const double v = col[(size_t)r * n_phi];
+        if (v < prev) { first = r; break; }
+        prev = v;
+    }
+    if (first < n_w) atomicMin(&out[i], first);
+}
+
 }  // namespace xsw
