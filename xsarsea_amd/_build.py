@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "xsw.hip")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("xsw.hip", "xsw_device.hpp", "xsw_exhaustive.hpp", "xsw_gmf.hpp", "xsw_nesz.hpp", "xsw_lutbuild.hpp")] + [
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("xsw.hip", "xsw_device.hpp", "xsw_exhaustive.hpp", "xsw_gmf.hpp", "xsw_nesz.hpp", "xsw_lutbuild.hpp", "xsw_band.hpp")] + [
     os.path.join(REPO, "include", "xsw.h")]
 LIB = os.environ.get("XSW_LIB") or os.path.join(HERE, "libxsw.so")  # XSW_LIB: experiment builds only
 ARCH = "gfx950"
@@ -33,7 +33,7 @@ def build(force=False, verbose=False):
         return LIB
     cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
            "-I" + os.path.join(REPO, "include"), "-I" + os.path.join(HERE, "csrc"),
-           "-o", LIB, SRC, "-Wl,-rpath,/opt/rocm/lib"]
+           "-o", LIB, SRC, "-Wl,-rpath,/opt/rocm/lib"] + os.environ.get("XSW_EXTRA_FLAGS", "").split()  # experiment builds only
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

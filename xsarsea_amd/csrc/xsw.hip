@@ -14,6 +14,7 @@
 
 #include "xsw.h"
 #include "xsw_device.hpp"
+#include "xsw_band.hpp"
 #include "xsw_exhaustive.hpp"
 #include "xsw_gmf.hpp"
 #include "xsw_nesz.hpp"
@@ -33,6 +34,8 @@ struct xsw_ctx {
     bool have_co = false, have_cr = false;
     unsigned long long *d_stats = nullptr;
     bool stats_on = false;
+    unsigned *d_list = nullptr;  // hand-over k_invert_band -> k_invert_list: [0] = count, [16..] = pixel indices
+    size_t list_cap = 0;         // (context-owned, grown on demand)
     double *d_ratio = nullptr;  // detrend ratio row (context-owned, grown on demand)
     size_t ratio_cap = 0;
     hipStream_t s_in = nullptr, s_out = nullptr;  // upload / download streams of the host-memory path (lazily created)
@@ -117,6 +120,7 @@ extern "C" int xsw_ctx_destroy(xsw_ctx *c)
     free_all(c->cr_allocs);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_ratio) (void)hipFree(c->d_ratio);
+    if (c->d_list) (void)hipFree(c->d_list);
     if (c->arena) (void)hipFree(c->arena);
     if (c->s_in) (void)hipStreamDestroy(c->s_in);
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
@@ -412,6 +416,34 @@ static int launch_invert(xsw_ctx *c, const KArgs &A, int algo)
     if (algo == XSW_ALGO_EXHAUSTIVE || algo == XSW_ALGO_EXHAUSTIVE_F64)
         return launch_exhaustive<T, TO>(c->T, A, c->stream, algo == XSW_ALGO_EXHAUSTIVE) == hipSuccess
                                                 ? XSW_OK : fail(c, XSW_EHIP, "exhaustive launch failed: %s", hipGetErrorString(hipGetLastError()));
+    // Two-kernel fast path: k_invert_band finishes every pixel the band rule decides (monotone LUT rows, finite inputs,
+    // unique minimum; cross-pol by the interval rule) and appends the rest to a work list; k_invert_list inverts those.
+    static const bool band_off = getenv("XSW_NO_BAND") != nullptr;  // experiments / A-B measurements only
+    if (algo == XSW_ALGO_PRUNED && !band_off && A.s_co && c->T.prunable && c->T.mono_rows && c->T.co_off32 &&
+        (!A.s_cr || c->T.cr_monotone) && A.n < (1LL << 32)) {
+        if ((size_t)A.n > c->list_cap) {
+            if (c->d_list) (void)hipFree(c->d_list);
+            c->d_list = nullptr;
+            c->list_cap = 0;
+            if (hipMalloc((void **)&c->d_list, ((size_t)A.n + 16) * sizeof(unsigned)) != hipSuccess)
+                return fail(c, XSW_ENOMEM, "hipMalloc(work list, %lld) failed", A.n);
+            c->list_cap = (size_t)A.n;
+        }
+        KArgs B = A;
+        B.list_count = c->d_list;
+        B.list = c->d_list + 16;
+        HIPCHK(c, hipMemsetAsync(c->d_list, 0, sizeof(unsigned), c->stream));
+        const unsigned list_blocks = (unsigned)std::min<long long>(nblocks, 256 * 8);
+        if (!A.s_cr && !A.out_cr) {
+            hipLaunchKernelGGL((k_invert_band<T, TO, false>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, B);
+            hipLaunchKernelGGL((k_invert_list<T, TO, false>), dim3(list_blocks), dim3(256), 0, c->stream, c->T, B);
+        } else {
+            hipLaunchKernelGGL((k_invert_band<T, TO, true>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, B);
+            hipLaunchKernelGGL((k_invert_list<T, TO, true>), dim3(list_blocks), dim3(256), 0, c->stream, c->T, B);
+        }
+        HIPCHK(c, hipGetLastError());
+        return XSW_OK;
+    }
     if (algo == XSW_ALGO_PRUNED && !A.s_cr && !A.out_cr)
         hipLaunchKernelGGL((k_invert<T, TO, 1, false>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, A);
     else if (algo == XSW_ALGO_PRUNED)

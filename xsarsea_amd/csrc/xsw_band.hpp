@@ -1,0 +1,303 @@
+// Fast path of the branch-and-bound inversion: `k_invert_band` (round 2).  tests/prune_model.py: band_pruned_argmin is its
+// executable specification.
+//
+// Besides the disc |c - m| <= 2 sqrt(J_ub) of the window (xsw_device.hpp), the sigma0 term bounds the candidates on its
+// own: both cost terms are >= 0, so ((LUT - s)/dsig)^2 <= J_ub, i.e. |LUT - s| <= d = |dsig| sqrt(J_ub), is necessary for
+// the argmin.  Where the LUT columns are non-decreasing in wind speed over the rows of the window (L.mono_rows, checked at
+// upload; CMOD5.N itself turns over beyond 24..40 m/s below 41 deg of incidence), that is ONE row interval per direction
+// -- 1..4 candidates instead of the 7..40 rows of the window column: 31 instead of 638 candidates per pixel on the
+// benchmark scene.
+//
+// Two kernels share a launch (xsw.hip: launch_invert): this one finishes every pixel the band rule decides and writes a
+// status byte per pixel; `k_invert` (the general kernel: window sweep, exact scan, any LUT) then handles the pixels left
+// over (status 1: window outside the monotone rows, non-finite inputs, near-ties, cross-pol sweeps the interval rule
+// cannot do) and returns at once on strips that have none.  Keeping the rare, register-hungry paths out of this kernel is
+// what lets it run at a higher occupancy than the one-kernel form did.
+//
+// Work decomposition: a workgroup = 4 waves = a tile of 4 lines x 64 samples (as k_invert); lane i loads pixel i, finds its
+// incidence bin, the upper bound along the a-priori direction and the window (co_window_lanes), and parks the pixel's search
+// parameters in an LDS slot.  Then the wave takes 64/S pixels per pass, one per S-lane segment; a lane owns K adjacent
+// directions of one pixel (classes S*K = 4, 8, ..., 128 directions; wider windows loop over chunks in the S = 64 class):
+//   * the lane bisects its first column inside the window for the first row with LUT >= s - d (wave-uniform trip count);
+//     the next column starts from its neighbour's row and walks (the contour moves by 0..2 rows per degree);
+//   * it then scores upwards while LUT <= s + d (a few trips; scores are formed directly, no forward differences);
+//   * segment argmin by DPP; the unique candidate within eps of the minimum is the reference's argmin (same settle rule as
+//     co_box_search); the winner lane posts it to the owner lane through LDS.  Near-ties, several survivors, bands longer
+//     than XSW_BAND_MAX -> left to k_invert.
+// The cross-pol search (dual-pol) runs one pixel per lane with the interval rule of search_cr_interval.
+#pragma once
+#include "xsw_device.hpp"
+
+namespace xsw {
+
+#ifndef XSW_BAND_MAX
+#define XSW_BAND_MAX 64
+#endif
+#ifndef XSW_BAND_WALK_MAX
+#define XSW_BAND_WALK_MAX 16
+#endif
+#ifndef XSW_BAND_K
+#define XSW_BAND_K 2
+#endif
+#ifndef XSW_BAND_WAVES
+#define XSW_BAND_WAVES 1
+#endif
+
+struct BandSlot {  // 64 bytes per pixel, read by every lane of its segment (same address: LDS broadcast)
+    double sn, thr_lo, thr_hi, ah, bh, m2;
+    int i_inc, rows /* w_lo | w_hi << 16 */, ip_lo, ncols;
+};
+
+__device__ __forceinline__ double ld_co(const char *__restrict__ base, unsigned off0, int row, unsigned rowB)
+{
+    return *(const double *)(base + (off0 + __umul24((unsigned)row, rowB)));
+}
+
+template <int S, int K, bool COUNT>
+__device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig, int nsteps, int lane,
+                                             const BandSlot *slots /* this wave's [64], by pixel lane */, int *map /* [32] */,
+                                             int *res /* [32] */, unsigned long long &pend, int &my_flat, unsigned &cand)
+{
+    constexpr int NP = 64 / S;
+    const double inf = __builtin_inf();
+    // the first NP pending pixels, in lane order: pixel of rank r -> segment r
+    const bool is_p = ((pend >> lane) & 1ULL) != 0;
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pend >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pend, 0u));
+    const bool take = is_p && rank < NP;
+    if (take) map[rank] = lane;
+    const unsigned long long taken = __ballot(take);
+    const int nvalid = __popcll(taken);
+    pend &= ~taken;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int q = lane / S, sl = lane & (S - 1);
+    const bool valid = q < nvalid;
+    const int owner = valid ? map[q] : lane;
+    BandSlot B = slots[owner];
+    if (!valid) { B.i_inc = 0; B.rows = 0; B.ip_lo = 0; B.ncols = 0; }  // idle segment: harmless addresses, nothing scored
+    const int w_lo = B.rows & 0xffff, w_hi = B.rows >> 16;
+    const double thr_lo = B.thr_lo, thr_hi = B.thr_hi, sn = B.sn;
+    const double wh0 = 0.5 * L.w0, whs = 0.5 / L.inv_wstep;
+    const char *__restrict__ base = (const char *)L.co;
+    const unsigned rowB = (unsigned)L.phi_pad * 8u;
+    const unsigned slice0 = (unsigned)(B.i_inc * L.n_w) * rowB;
+    double best = inf, second = inf;
+    int bflat = 0;
+    unsigned ncand = 0;
+    bool overflow = false;
+    const int nchunks = S == 64 ? (__builtin_amdgcn_readfirstlane(B.ncols) + 64 * K - 1) / (64 * K) : 1;  // S == 64: one pixel, wave-uniform
+#pragma unroll 1
+    for (int ch = 0; ch < nchunks; ++ch) {
+        bool act[K], more[K];
+        int ip[K], r[K];
+        unsigned off0[K];
+        double U[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int col = K * sl + j + S * K * ch;
+            act[j] = valid && col < B.ncols;
+            ip[j] = B.ip_lo + (act[j] ? col : 0);
+            const unsigned ipB = (unsigned)ip[j] * 8u;
+            U[j] = 2.0 * (B.ah * *(const double *)((const char *)L.cphi + ipB) + B.bh * *(const double *)((const char *)L.sphi + ipB));
+            off0[j] = slice0 + ipB;
+        }
+        // first column: lower_bound(s - d) over the window rows
+        int lo = w_lo, hi = w_hi + 1;
+#pragma unroll 1
+        for (int it = 0; it < nsteps; ++it) {
+            const int mid = (lo + hi) >> 1;
+            const double v = ld_co(base, off0[0], min(mid, w_hi), rowB);
+            const bool open = lo < hi, below = v < thr_lo;
+            lo = (open && below) ? mid + 1 : lo;
+            hi = (open && !below) ? mid : hi;
+        }
+        r[0] = lo;
+        // next columns: from the neighbour's row, walk until  LUT[r - 1] < s - d <= LUT[r]  (window ends count as -inf / +inf)
+#pragma unroll
+        for (int j = 1; j < K; ++j) {
+            int rr = r[j - 1];
+#pragma unroll 1
+            for (int it = 0;; ++it) {
+                const double a = ld_co(base, off0[j], max(rr - 1, w_lo), rowB), b = ld_co(base, off0[j], min(rr, w_hi), rowB);
+                const bool down = act[j] && rr > w_lo && a >= thr_lo;
+                const bool up = act[j] && !down && rr <= w_hi && b < thr_lo;
+                rr += (up ? 1 : 0) - (down ? 1 : 0);
+                if (__ballot(up || down) == 0ULL) break;
+                if (it >= XSW_BAND_WALK_MAX) { overflow = overflow || up || down; break; }
+            }
+            r[j] = rr;
+        }
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < K; ++j) { more[j] = act[j] && r[j] <= w_hi; any = any || more[j]; }
+#pragma unroll 1
+        for (int t = 0; __ballot(any) != 0ULL; ++t) {
+            if (t >= XSW_BAND_MAX) { overflow = overflow || any; break; }
+            any = false;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int rc = min(r[j], w_hi);
+                const double v = ld_co(base, off0[j], rc, rowB);
+                const bool inb = more[j] && v <= thr_hi;
+                const double wh = fma((double)rc, whs, wh0);
+                const double dd = fma(v, inv_dsig, sn);
+                double J = fma(dd, dd, wh * (wh - U[j]));
+                J = inb ? J : inf;
+                second = vmin(second, vmax(J, best));
+                bflat = J < best ? (int)__umul24((unsigned)rc, (unsigned)L.n_phi) + ip[j] : bflat;
+                best = vmin(best, J);
+                if (COUNT) ncand += inb ? 1u : 0u;
+                r[j] += 1;
+                more[j] = inb && r[j] <= w_hi;
+                any = any || more[j];
+            }
+        }
+    }
+    const double gmin = S == 64 ? wave_min_d(best) : seg_min_d<S>(best);
+    const double T = gmin + 1e-9 * (1.0 + fabs(gmin) + slots[owner].m2);  // re-read: not kept live through the sweep
+    const unsigned long long amb = __ballot(valid && (second <= T || overflow)), surv = __ballot(valid && best <= T);
+    const unsigned long long segmask = S == 64 ? ~0ULL : (((1ULL << (S & 63)) - 1ULL) << ((q * S) & 63));
+    const bool bad = (amb & segmask) != 0ULL || __popcll(surv & segmask) != 1 || !(gmin < 1e300);
+    if (valid && ((!bad && best <= T) || (bad && sl == 0))) res[q] = bad ? -1 : bflat;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (take) my_flat = res[rank];  // -1: undecided here, left to k_invert
+    if (COUNT) {
+        unsigned c = ncand;
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+        cand += c;
+    }
+}
+
+template <typename T, typename TO, bool CR>
+__global__ __launch_bounds__(256, XSW_BAND_WAVES) void k_invert_band(DevTables L, KArgs A)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ BandSlot slots[4][64];  // search parameters of the wave's 64 pixels
+    __shared__ int map_[4][32];        // pass: segment -> owner lane
+    __shared__ int res_[4][32];        // pass: segment -> winning flat index (or -1)
+    // same tile walk as k_invert (XCD x owns a contiguous range of tile columns, line groups fastest)
+    const long long strips_per_line = (A.samples + 63) >> 6, line_groups = (A.lines + 3) >> 2;
+    const long long cols_per_xcd = (strips_per_line + 7) >> 3;
+    const long long xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const long long col = xcd * cols_per_xcd + jb / line_groups;
+    const long long line = (jb % line_groups) * 4 + wv;
+    if (jb / line_groups >= cols_per_xcd || col >= strips_per_line || line >= A.lines) return;  // wave-uniform
+    const long long smp = col * 64 + lane;
+    const bool in = smp < A.samples;
+    const long long i = line * A.samples + (in ? smp : A.samples - 1);
+    const double nan = __builtin_nan("");
+
+    int flags, my_flat = -1, my_icr = -1;
+    unsigned cand = 0;
+    unsigned long long cls[6], seen_all = 0;
+    int ns[6];
+    {
+        // ---- stage 1, one pixel per lane: classify, incidence bin, upper bound along the a-priori direction, window
+        Pixel P;
+        load_pixel<T, false>(L, A, i, in, P);
+        flags = P.flags;
+        const unsigned long long todo = __ballot((P.flags & F_NEED_CO) != 0);
+        bool eligb = false;
+        int ncols_p = 0, bits = 0;
+        if (todo) {
+            bool loose = false;
+            const CoWindow W = co_window_lanes(L, P, A.inv_dsig_co, loose);
+            const int nrows_p = W.w_hi - W.w_lo + 1;
+            ncols_p = W.ip_hi - W.ip_lo + 1;
+            const bool need = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0 && !loose && ncols_p >= 1 && nrows_p >= 1;
+            eligb = need && W.w_hi < L.mono_rows[need ? P.i_inc : 0];  // the window stays inside the monotone rows
+            bits = eligb ? 32 - __clz(nrows_p) : 0;                    // bisection steps this window needs
+            if (eligb) {
+                BandSlot b;
+                const double ah = 0.5 * P.a_re, bh = 0.5 * P.b_eff;
+                b.sn = -P.s_co * A.inv_dsig_co; b.thr_lo = P.s_co - W.band_d; b.thr_hi = P.s_co + W.band_d;
+                b.ah = ah; b.bh = bh; b.m2 = ah * ah + bh * bh;
+                b.i_inc = P.i_inc; b.rows = W.w_lo | (W.w_hi << 16); b.ip_lo = W.ip_lo; b.ncols = ncols_p;
+                slots[wv][lane] = b;
+            }
+            if (A.stats) cand += (unsigned)__popcll(__ballot(eligb)) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)));
+        }
+        constexpr int BK = XSW_BAND_K;
+        unsigned long long seen = 0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            cls[c] = (c < 5 ? __ballot(eligb && ncols_p <= (2 << c) * BK) : __ballot(eligb)) & ~seen;
+            seen |= cls[c];
+            ns[c] = cls[c] ? wave_max_i(((cls[c] >> lane) & 1ULL) ? bits : 0) : 0;
+        }
+        seen_all = seen;
+    }
+    // ---- stage 2: band passes, narrowest windows first (most pixels per pass)
+    {
+        constexpr int BK = XSW_BAND_K;
+        auto run = [&](auto seg, unsigned long long m, int nsteps) {
+            constexpr int S = decltype(seg)::value;
+            if (A.stats) while (m) co_band_pass<S, BK, true>(L, A.inv_dsig_co, nsteps, lane, slots[wv], map_[wv], res_[wv], m, my_flat, cand);
+            else while (m) co_band_pass<S, BK, false>(L, A.inv_dsig_co, nsteps, lane, slots[wv], map_[wv], res_[wv], m, my_flat, cand);
+        };
+        run(std::integral_constant<int, 2>{}, cls[0], ns[0]);
+        run(std::integral_constant<int, 4>{}, cls[1], ns[1]);
+        run(std::integral_constant<int, 8>{}, cls[2], ns[2]);
+        run(std::integral_constant<int, 16>{}, cls[3], ns[3]);
+        run(std::integral_constant<int, 32>{}, cls[4], ns[4]);
+        run(std::integral_constant<int, 64>{}, cls[5], ns[5]);
+    }
+    const bool need_co = (flags & F_NEED_CO) != 0;
+    bool unresolved = in && need_co && my_flat < 0;  // not eligible, or undecided by its pass
+
+    // ---- cross-pol search (windspeed.py:252-269), one pixel per lane, interval rule only (host: L.cr_monotone)
+    bool need_cr = false;
+    if (CR && A.s_cr) {
+        const double inc = ld<T>(A.inc, i);
+        const T x = ((const T *)A.s_cr)[i];
+        const double s_cr = to_db(x, A.is_db);
+        const double dsig = A.dsig_cr ? (double)((const T *)A.dsig_cr)[i] : (double)(T)(x * (T)0 + (T)A.dsig_cr_scalar);
+        need_cr = in && !(flags & F_EARLY_NAN) && s_cr == s_cr && dsig == dsig;
+        const bool here = need_cr && !unresolved;
+        const int i_inc_cr = here ? nearest_index(L.inc_cr, L.n_inc_cr, inc) : 0;
+        const double aco = (here && need_co) ? L.abs_co[my_flat] : nan;  // np.abs(wind_co), table [n_w][n_phi]
+        bool undecided = here;
+        const bool done = search_cr_interval(L, here, i_inc_cr, s_cr, dsig, need_co, aco, my_icr, undecided);
+        unresolved = unresolved || (need_cr && (undecided || !done));
+        if (need_cr) flags |= F_NEED_CR;
+    }
+    if (A.stats) {
+        const unsigned long long done_co = __ballot(in && need_co && my_flat >= 0), done_cr = __ballot(need_cr && !unresolved);
+#ifdef XSW_DEBUG_REASONS  // pixels_exact := not-eligible count | undecided-by-pass count << 32 (experiments only)
+        const unsigned long long noel = __ballot(in && need_co && !((seen_all >> lane) & 1ULL)), und = __ballot(in && need_co && ((seen_all >> lane) & 1ULL) && my_flat < 0);
+        if (lane == 0) atomicAdd(&A.stats[2], (unsigned long long)__popcll(noel) | ((unsigned long long)__popcll(und) << 32));
+#endif
+        if (lane == 0) {
+            atomicAdd(&A.stats[0], (unsigned long long)__popcll(done_co));
+            atomicAdd(&A.stats[1], (unsigned long long)cand);
+            atomicAdd(&A.stats[3], (unsigned long long)__popcll(done_cr));
+        }
+    }
+    {   // hand the undecided pixels over to k_invert_list: one atomic per wave, then a compact append
+        const unsigned long long um = __ballot(unresolved);
+        if (um) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(A.list_count, (unsigned)__popcll(um));
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if (unresolved) A.list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u))] = (unsigned)i;
+        }
+    }
+    if (in) {
+        if (!unresolved) {
+            Pixel Q;  // what store_pixel reads: flags and the ancillary wind (reloaded: not kept live through the passes)
+            Q.flags = flags;
+            Q.a_re = nan; Q.a_im = nan;
+            if (A.anc) {
+                typename Cx<T>::type z = ((const typename Cx<T>::type *)A.anc)[i];
+                Q.a_re = (double)z.x;
+                Q.a_im = (double)z.y;
+            }
+            store_pixel<TO, CR>(L, A, i, Q, my_flat, my_icr);
+        }
+    }
+}
+
+}  // namespace xsw

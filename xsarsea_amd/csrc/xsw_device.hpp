@@ -55,6 +55,8 @@ struct KArgs {
     void *out_co, *out_cr;
     int *out_idx;
     unsigned long long *stats;  // [4]: pixels_co, cand_co, pixels_exact, pixels_cr (nullable)
+    unsigned *list;             // two-kernel path (nullable): k_invert_band appends the flat index of every pixel it leaves
+    unsigned *list_count;       // undecided; k_invert_list then inverts exactly those, 64 per wave
     long long n, lines, samples;
     double dsig_co, inv_dsig_co, dsig_cr_scalar;
     int is_db, dual_select;
@@ -512,7 +514,7 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
 template <int S> __device__ __forceinline__ double seg_min_d(double v)
 {
     v = vmin(v, dpp_d<0xB1, 0xF>(v));   // lane ^ 1
-    v = vmin(v, dpp_d<0x4E, 0xF>(v));   // lane ^ 2
+    if (S >= 4) v = vmin(v, dpp_d<0x4E, 0xF>(v));   // lane ^ 2
     if (S >= 8) v = vmin(v, dpp_d<0x141, 0xF>(v));  // 8-lane halves mirrored: every lane of an 8-lane group holds its minimum
     if (S >= 16) v = vmin(v, dpp_d<0x140, 0xF>(v));  // 16-lane rows mirrored
     if (S == 32) v = vmin(v, __shfl_xor(v, 16));
@@ -601,121 +603,6 @@ __device__ __forceinline__ void co_seg_pass(const DevTables &L, const Pixel &P, 
             const int flat = rd_lane_i(row, wl) * L.n_phi + rd_lane_i(ip, wl);
             if (lane == o[k]) my_flat = flat;
         }
-    }
-}
-
-// Stage 2 with BAND PRUNING, `co_band_pass<S>` (round 2; tests/prune_model.py: band_pruned_argmin is its specification).
-// Besides the disc |c - m| <= 2 sqrt(J_ub), the sigma0 term bounds the candidates: |LUT - s| <= d = |dsig| sqrt(J_ub).  Where
-// the LUT columns are non-decreasing in wind speed over the rows of the window (L.mono_rows, checked at upload), that is ONE
-// row interval per direction -- 1..4 candidates instead of the 7..40 rows of the window column (31 instead of 638 per pixel
-// on the benchmark scene).  The wave takes 64/S pixels per pass, one per S-lane segment; lane = one direction of one pixel:
-//   * the pixel parameters travel owner lane -> LDS slot -> segment lanes (three 16-byte broadcast reads);
-//   * each lane bisects its column inside the window for the first row with LUT >= s - d (wave-uniform trip count),
-//     then scores upwards while LUT <= s + d (a few trips; scores are formed directly, no forward differences);
-//   * segment argmin by DPP; the unique candidate within eps of the minimum is the reference's argmin; the winner lane
-//     posts it to the owner through LDS.  Near-ties, several survivors, bands longer than XSW_BAND_MAX -> `redo`
-//     (settled by co_box_search in the window).
-// Windows wider than 64 directions run in the S = 64 class, 64 directions per chunk.
-#ifndef XSW_BAND_MAX
-#define XSW_BAND_MAX 12
-#endif
-#ifndef XSW_BAND
-#define XSW_BAND 1
-#endif
-struct BandSlot {  // 48 bytes, read by every lane of a segment (same address: LDS broadcast)
-    double s, a, b, d;
-    int i_inc, rows /* w_lo | w_hi << 16 */, ip_lo, ncols;
-};
-template <int S>
-__device__ __forceinline__ void co_band_pass(const DevTables &L, const Pixel &P, const CoWindow &W, double inv_dsig, int nsteps,
-                                             int lane, BandSlot *slots /* this wave's [64 / S] */, int *res /* this wave's [64 / S] */,
-                                             unsigned long long &pend, int &my_flat, unsigned long long &redo, unsigned &cand,
-                                             bool count)
-{
-    constexpr int NP = 64 / S;
-    const double inf = __builtin_inf();
-    // the first NP pending pixels, in lane order: pixel of rank r -> segment r
-    const bool is_p = ((pend >> lane) & 1ULL) != 0;
-    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pend >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pend, 0u));
-    const bool take = is_p && rank < NP;
-    if (take) {
-        BandSlot b;
-        b.s = P.s_co; b.a = P.a_re; b.b = P.b_eff; b.d = W.band_d;
-        b.i_inc = P.i_inc; b.rows = W.w_lo | (W.w_hi << 16); b.ip_lo = W.ip_lo; b.ncols = W.ip_hi - W.ip_lo + 1;
-        slots[rank] = b;
-    }
-    const unsigned long long taken = __ballot(take);
-    const int nvalid = __popcll(taken);
-    pend &= ~taken;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int q = lane / S, sl = lane & (S - 1);
-    const bool valid = q < nvalid;
-    const BandSlot B = slots[valid ? q : 0];
-    const int w_lo = B.rows & 0xffff, w_hi = B.rows >> 16;
-    const double ah = 0.5 * B.a, bh = 0.5 * B.b, m2 = ah * ah + bh * bh, sn = -B.s * inv_dsig;
-    const double thr_lo = B.s - B.d, thr_hi = B.s + B.d;
-    const double wh0 = 0.5 * L.w0, whs = 0.5 / L.inv_wstep;
-    const char *__restrict__ base = (const char *)L.co;
-    const unsigned rowB = (unsigned)L.phi_pad * 8u;
-    const unsigned slice0 = (unsigned)(B.i_inc * L.n_w) * rowB;
-    double best = inf, second = inf;
-    int bflat = 0;
-    unsigned ncand = 0;
-    bool overflow = false;
-    const int nchunks = S == 64 ? (__builtin_amdgcn_readfirstlane(B.ncols) + 63) >> 6 : 1;  // S == 64: one pixel, wave-uniform
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int col = sl + 64 * ch;
-        const bool act = valid && col < B.ncols;
-        const int ip = B.ip_lo + (act ? col : 0);
-        const unsigned ipB = (unsigned)ip * 8u;
-        const double U = 2.0 * (ah * *(const double *)((const char *)L.cphi + ipB) + bh * *(const double *)((const char *)L.sphi + ipB));
-        const unsigned off0 = slice0 + ipB;
-        // lower_bound(s - d) over the window rows of this column
-        int lo = w_lo, hi = w_hi + 1;
-        for (int it = 0; it < nsteps; ++it) {
-            const int mid = (lo + hi) >> 1;
-            const double v = *(const double *)(base + (off0 + (unsigned)min(mid, w_hi) * rowB));
-            const bool open = lo < hi, below = v < thr_lo;
-            lo = (open && below) ? mid + 1 : lo;
-            hi = (open && !below) ? mid : hi;
-        }
-        int r = lo;
-        bool more = act && r <= w_hi;
-        for (int t = 0; __ballot(more) != 0ULL; ++t) {
-            if (t >= XSW_BAND_MAX) { overflow = overflow || more; break; }
-            const int rc = min(r, w_hi);
-            const double v = *(const double *)(base + (off0 + (unsigned)rc * rowB));
-            const bool inb = more && v <= thr_hi;
-            const double wh = fma((double)rc, whs, wh0);
-            const double dd = fma(v, inv_dsig, sn);
-            double J = fma(dd, dd, wh * (wh - U));
-            J = inb ? J : inf;
-            second = vmin(second, vmax(J, best));
-            bflat = J < best ? rc * L.n_phi + ip : bflat;
-            best = vmin(best, J);
-            ncand += inb ? 1u : 0u;
-            r += 1;
-            more = inb && r <= w_hi;
-        }
-    }
-    const double gmin = S == 64 ? wave_min_d(best) : seg_min_d<S>(best);
-    const double T = gmin + 1e-9 * (1.0 + fabs(gmin) + m2);
-    const unsigned long long amb = __ballot(valid && (second <= T || overflow)), surv = __ballot(valid && best <= T);
-    const unsigned long long segmask = S == 64 ? ~0ULL : (((1ULL << (S & 63)) - 1ULL) << ((q * S) & 63));
-    const bool bad = (amb & segmask) != 0ULL || __popcll(surv & segmask) != 1 || !(gmin < 1e300);
-    if (valid && ((!bad && best <= T) || (bad && sl == 0))) res[q] = bad ? -1 : bflat;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int got = take ? res[rank] : 0;
-    if (take && got >= 0) my_flat = got;
-    redo |= __ballot(take && got < 0);
-    if (count) {
-        unsigned c = ncand;
-        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-        cand += c;
     }
 }
 
@@ -1010,26 +897,10 @@ __device__ __forceinline__ void store_pixel(const DevTables &L, const KArgs &A, 
 #endif
 // CR = false: mono co-pol instantiation (no cross-pol raster, no second output): the cross-pol pixel state is not kept
 // alive through the co-pol search.
-template <typename T, typename TO, int ALGO, bool CR = true>
-__global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTables L, KArgs A)
+// Inverts the (up to) 64 pixels of one wave: lane l owns pixel i (in = the lane has one).  Body of k_invert / k_invert_list.
+template <typename T, typename TO, int ALGO, bool CR>
+__device__ __forceinline__ void invert_strip(const DevTables &L, const KArgs &A, long long i, bool in, int lane)
 {
-    const int lane = threadIdx.x & 63;
-    __shared__ BandSlot band_slots[4][16];  // co_band_pass: pixel parameters owner lane -> segment lanes, per wave
-    __shared__ int band_res[4][16];         //               winner lane -> owner lane
-    // Raster tile of this workgroup: 4 lines x 64 samples (one strip per wave).  Incidence varies along
-    // `sample` only, so a column of tiles shares one or two LUT slices.  Workgroups are dealt round-robin
-    // over the 8 XCDs (b % 8 shares an XCD; placement is a speed heuristic, never a correctness
-    // assumption): XCD x walks its own contiguous range of tile columns, line groups fastest, so that the
-    // waves resident on one XCD at any time work in the same few slices and its L2 keeps them.
-    const long long strips_per_line = (A.samples + 63) >> 6, line_groups = (A.lines + 3) >> 2;
-    const long long cols_per_xcd = (strips_per_line + 7) >> 3;
-    const long long xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const long long col = xcd * cols_per_xcd + j / line_groups;
-    const long long line = (j % line_groups) * 4 + (threadIdx.x >> 6);
-    if (j / line_groups >= cols_per_xcd || col >= strips_per_line || line >= A.lines) return;  // wave-uniform
-    const long long smp = col * 64 + lane;
-    const bool in = smp < A.samples;
-    const long long i = line * A.samples + (in ? smp : A.samples - 1);
     const double nan = __builtin_nan("");
 
     Pixel P;
@@ -1050,35 +921,9 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTa
         if (loose) P.flags &= ~F_CO_FINITE;  // -> exact_scan_co
         const unsigned long long fin_m = __ballot((P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0);
         cand += (unsigned)__popcll(fin_m) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)));
-        unsigned long long banded = 0;  // pixels taken by the band passes
-        if (XSW_BAND && L.co_off32 && L.mono_rows) {
-            const int ncols_p = W.ip_hi - W.ip_lo + 1, nrows_p = W.w_hi - W.w_lo + 1;
-            const bool need = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0 && ncols_p >= 1 && nrows_p >= 1;
-            const bool eligb = need && W.w_hi < L.mono_rows[need ? P.i_inc : 0];  // the window stays inside the monotone rows
-            const int bits = eligb ? 32 - __clz(nrows_p) : 0;  // bisection steps this window needs
-            unsigned long long cls[5];
-            cls[0] = __ballot(eligb && ncols_p <= 4);
-            cls[1] = __ballot(eligb && ncols_p <= 8) & ~cls[0];
-            cls[2] = __ballot(eligb && ncols_p <= 16) & ~(cls[0] | cls[1]);
-            cls[3] = __ballot(eligb && ncols_p <= 32) & ~(cls[0] | cls[1] | cls[2]);
-            cls[4] = __ballot(eligb) & ~(cls[0] | cls[1] | cls[2] | cls[3]);
-            banded = cls[0] | cls[1] | cls[2] | cls[3] | cls[4];
-            unsigned long long redo = 0;
-            const int wv = threadIdx.x >> 6;
-            const bool cnt = A.stats != nullptr;
-            auto steps_of = [&](unsigned long long m) { return wave_max_i(((m >> lane) & 1ULL) ? bits : 0); };
-            if (cls[0]) { const int ns = steps_of(cls[0]); while (cls[0]) co_band_pass<4>(L, P, W, A.inv_dsig_co, ns, lane, band_slots[wv], band_res[wv], cls[0], my_flat, redo, cand, cnt); }
-            if (cls[1]) { const int ns = steps_of(cls[1]); while (cls[1]) co_band_pass<8>(L, P, W, A.inv_dsig_co, ns, lane, band_slots[wv], band_res[wv], cls[1], my_flat, redo, cand, cnt); }
-            if (cls[2]) { const int ns = steps_of(cls[2]); while (cls[2]) co_band_pass<16>(L, P, W, A.inv_dsig_co, ns, lane, band_slots[wv], band_res[wv], cls[2], my_flat, redo, cand, cnt); }
-            if (cls[3]) { const int ns = steps_of(cls[3]); while (cls[3]) co_band_pass<32>(L, P, W, A.inv_dsig_co, ns, lane, band_slots[wv], band_res[wv], cls[3], my_flat, redo, cand, cnt); }
-            if (cls[4]) { const int ns = steps_of(cls[4]); while (cls[4]) co_band_pass<64>(L, P, W, A.inv_dsig_co, ns, lane, band_slots[wv], band_res[wv], cls[4], my_flat, redo, cand, cnt); }
-            n_co += (unsigned)__popcll(banded & ~redo);
-            relay |= redo;  // laid out for a segment: co_box_search lays them out again
-            todo = (todo & ~banded) | redo;
-        }
         if (L.co_off32) {
             const int ncols_p = W.ip_hi - W.ip_lo + 1;
-            const bool elig = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0 && ((banded >> lane) & 1ULL) == 0;
+            const bool elig = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0;
             unsigned long long m4 = __ballot(XSW_SEG4 && elig && ncols_p <= 4);
             unsigned long long m8 = __ballot(XSW_SEG8 && elig && ncols_p <= 8) & ~m4;
             unsigned long long m16 = __ballot(elig && ncols_p <= 16) & ~(m8 | m4), m32 = __ballot(XSW_SEG32 && elig && ncols_p > 16 && ncols_p <= 32);
@@ -1148,6 +993,47 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTa
         atomicAdd(&A.stats[3], (unsigned long long)n_cr);
     }
     if (in) store_pixel<TO, CR>(L, A, i, P, my_flat, my_icr);
+}
+
+// Production kernel (general path).  ALGO: 1 = branch-and-bound, 3 = exact full sweep for every pixel.
+// CR = false: mono co-pol instantiation (no cross-pol raster, no second output): the cross-pol pixel state is not kept
+// alive through the co-pol search.
+template <typename T, typename TO, int ALGO, bool CR = true>
+__global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTables L, KArgs A)
+{
+    const int lane = threadIdx.x & 63;
+    // Raster tile of this workgroup: 4 lines x 64 samples (one strip per wave).  Incidence varies along
+    // `sample` only, so a column of tiles shares one or two LUT slices.  Workgroups are dealt round-robin
+    // over the 8 XCDs (b % 8 shares an XCD; placement is a speed heuristic, never a correctness
+    // assumption): XCD x walks its own contiguous range of tile columns, line groups fastest, so that the
+    // waves resident on one XCD at any time work in the same few slices and its L2 keeps them.
+    const long long strips_per_line = (A.samples + 63) >> 6, line_groups = (A.lines + 3) >> 2;
+    const long long cols_per_xcd = (strips_per_line + 7) >> 3;
+    const long long xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const long long col = xcd * cols_per_xcd + j / line_groups;
+    const long long line = (j % line_groups) * 4 + (threadIdx.x >> 6);
+    if (j / line_groups >= cols_per_xcd || col >= strips_per_line || line >= A.lines) return;  // wave-uniform
+    const long long smp = col * 64 + lane;
+    const bool in = smp < A.samples;
+    const long long i = line * A.samples + (in ? smp : A.samples - 1);
+    invert_strip<T, TO, ALGO, CR>(L, A, i, in, lane);
+}
+
+// Second kernel of the two-kernel path: inverts the pixels k_invert_band left undecided (A.list, A.list_count), 64 per wave,
+// with the general algorithm.  The pixels are scattered, so their rasters are gathered; they are few (0.2 % on the
+// benchmark scene).  Fixed grid; every wave strides over the list.
+template <typename T, typename TO, bool CR>
+__global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert_list(DevTables L, KArgs A)
+{
+    const int lane = threadIdx.x & 63;
+    const long long count = (long long)*A.list_count;
+    const long long nwaves = (long long)gridDim.x * 4;
+    for (long long c = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); c * 64 < count; c += nwaves) {  // wave-uniform
+        const long long k = c * 64 + lane;
+        const bool in = k < count;
+        const long long i = (long long)A.list[in ? k : count - 1];
+        invert_strip<T, TO, 1, CR>(L, A, i, in, lane);
+    }
 }
 
 // [n_inc][n_w][phi_pad] -> [n_inc][n_phi][w_pad], 32x32 LDS tiles
