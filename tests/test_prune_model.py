@@ -103,6 +103,6 @@ def test_band_rule_never_excludes_the_argmin(kind):
     if kind == "noisy":
         assert used == 0
     else:
-        assert used > 0.5 * n and np.mean(evaluated) < 120, (used, np.mean(evaluated))
+        assert used > 0.3 * n and np.mean(evaluated) < 120, (used, np.mean(evaluated))
     # CMOD5.N itself saturates and decreases at high wind / low incidence: the monotone prefix is a per-slice property
-    assert pm.mono_rows(co[0]) < len(w_ax) and (kind == "noisy" or pm.mono_rows(co[-1]) == len(w_ax))
+    assert pm.mono_rows(co[0]) < len(w_ax) and (kind in ("noisy", "rolloff") or pm.mono_rows(co[-1]) == len(w_ax))
