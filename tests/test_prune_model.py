@@ -72,7 +72,7 @@ def test_search_window_contains_disc(seed):
 def test_band_rule_never_excludes_the_argmin(kind):
     """Round-2 band pruning (|L - s| <= dsig sqrt(J_ub), one row interval per direction on monotone columns): same argmin
     as the oracle on a smooth LUT, a LUT quantised to 0.05 dB (long exact plateaus), a LUT that rolls off at high wind
-    (the window must stay inside the monotone rows or fall back) and a noisy LUT (never eligible: always falls back)."""
+    (the window must stay inside the monotone rows or fall back) and a noisy LUT (eligible only on its steep low-wind rows: nearly always falls back)."""
     rng = np.random.default_rng({"smooth": 1, "plateaus": 2, "rolloff": 3, "noisy": 4}[kind])
     inc_ax, w_ax, phi_ax = np.linspace(20, 44, 7), np.linspace(0.5, 39.5, 196), np.linspace(0, 180, 91)
     co = 10 * np.log10(gmf.gmf_cmod5n(inc_ax[:, None, None], w_ax[None, :, None], phi_ax[None, None, :]) + 1e-15)
@@ -101,7 +101,7 @@ def test_band_rule_never_excludes_the_argmin(kind):
         if r[3]:
             evaluated.append(r[2])
     if kind == "noisy":
-        assert used == 0
+        assert used < 0.1 * n  # only the steep low-wind rows of a noisy LUT are monotone
     else:
         assert used > 0.3 * n and np.mean(evaluated) < 120, (used, np.mean(evaluated))
     # CMOD5.N itself saturates and decreases at high wind / low incidence: the monotone prefix is a per-slice property
