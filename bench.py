@@ -487,6 +487,7 @@ def main():
         gather()
     fence()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ctx.timing_enable(True)  # HIP events of the library around each of the two kernels of an inversion (launch stream)
     t0 = time.perf_counter()
     for a, b in ev:
         a.record(stream)
@@ -495,7 +496,14 @@ def main():
         gather()
     fence()
     dt = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # the step's kernels on this rank (HIP events, launch stream)
+    step_kernels_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # all kernels of a step on this rank
+    tm = ctx.timing()
+    ctx.timing_enable(False)
+    if tm["launches"]:  # two-kernel path: the dominant kernel is k_invert_band; per STEP = summed over the step's row chunks
+        kernel_ms = tm["first_kernel_ms"] / args.steps
+        second_ms = tm["second_kernel_ms"] / args.steps
+    else:
+        kernel_ms, second_ms = step_kernels_ms, None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -564,16 +572,20 @@ def main():
                 "achieved": float(f"{lane_ops:.4g}"), "frac": round(lane_ops / LANE_OPS_PEAK, 5),
                 "note": "useful work only: 6 lane-ops x candidates actually scored / kernel time / (256 CU x 128 lanes x 2.4 GHz); "
                         "the grid has candidates_per_pixel_full_grid points, all but the evaluated ones are excluded by an exact bound"}
-        sq = _profile_json(f"{PROFILE_ROUND}_pmc_sq_summary.json") or _profile_json("r01_f_pmc_sq_summary.json")
+        sq = (_profile_json(f"{PROFILE_ROUND}_pmc_counters_summary.json") or {}).get("k_invert_band")
         if sq and is_metric_shape:
             try:
                 pp = sq["per_pixel"]
-                valu["issue"] = {"valu_insts_per_pixel": round(pp["SQ_INSTS_VALU"], 1), "salu_insts_per_pixel": round(pp["SQ_INSTS_SALU"], 1),
+                cyc = sq["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+                valu["issue"] = {"kernel": "k_invert_band",
+                                 "valu_insts_per_pixel": round(pp["SQ_INSTS_VALU"], 1), "salu_insts_per_pixel": round(pp["SQ_INSTS_SALU"], 1),
                                  "vmem_rd_insts_per_pixel": round(pp["SQ_INSTS_VMEM_RD"], 1),
-                                 "valu_issue_frac_of_simd_cycles": round(sq["SQ_INSTS_VALU"] * 4.0 / (1024.0 * sq["GRBM_GUI_ACTIVE"] / 8.0), 3)
-                                 if sq.get("GRBM_GUI_ACTIVE") else None,
-                                 "source": f"profiles/{PROFILE_ROUND if _profile_json(f'{PROFILE_ROUND}_pmc_sq_summary.json') else 'r01_f'}_pmc_sq_summary.json "
-                                           "(rocprofv3 --pmc SQ_INSTS_*, same workload; 4 issue cycles per wave64 VALU instruction, 1024 SIMDs, cycles = GRBM_GUI_ACTIVE / 8 XCDs)"}
+                                 "l1_line_accesses_per_pixel": round(pp["TCP_TOTAL_CACHE_ACCESSES_sum"], 1),
+                                 "valu_issue_frac_of_simd_cycles": round(sq["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cyc), 3),
+                                 "texture_addresser_busy_frac": round(sq["TA_TA_BUSY_sum"] / (256.0 * cyc), 3),
+                                 "wave_time_waiting_frac": round(sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"], 3),
+                                 "source": f"profiles/{PROFILE_ROUND}_pmc_counters_summary.json (rocprofv3 --pmc passes of profiles/collect_counters.sh, "
+                                           "same workload; 4 issue cycles per wave64 VALU instruction, 1024 SIMDs, 256 TAs, cycles = GRBM_GUI_ACTIVE / 8 XCDs)"}
             except Exception:
                 pass
         mode_txt = "mono-VV" if mode == "mono" else "dual-pol (VV + S1 VH GMF)"
@@ -593,10 +605,15 @@ def main():
                        "lines_rank0": lines, "lut": [int(x) for x in lut.shape], "parallelism": par},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel": {"exhaustive": "k_invert_exhaustive32", "exhaustive_f64": "k_invert_exhaustive"}.get(args.algo, "k_invert"),
+                         "kernel": {"exhaustive": "k_invert_exhaustive32", "exhaustive_f64": "k_invert_exhaustive"}.get(
+                             args.algo, "k_invert_band" if second_ms is not None else "k_invert"),
                          "kernel_ms": round(kernel_ms, 3), "bytes_per_pixel": bytes_px,
+                         "second_kernel": None if second_ms is None else {"kernel": "k_invert_list", "kernel_ms": round(second_ms, 3),
+                                                                           "pixels_last_launch": tm.get("last_list_pixels")},
+                         "step_kernels_ms": round(step_kernels_ms, 3),
                          "note": f"algorithmic raster bytes ({bytes_px} B read+written per pixel x rank 0's {lines * samples} px) / mean "
-                                 "kernel time of a step (HIP events on the launch stream); the search itself is VALU-issue bound: see valu",
+                                 "duration of the dominant kernel per step (HIP events on the launch stream, recorded by the library around each kernel); "
+                                 "the search itself is bound by VALU issue and the texture-address path, not by HBM: see valu",
                          "valu": valu},
             "lut": timings,
         }

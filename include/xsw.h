@@ -129,6 +129,18 @@ int xsw_invert(xsw_ctx *ctx, const xsw_invert_args *args);
 int xsw_stats_enable(xsw_ctx *ctx, int on);
 int xsw_stats_read(xsw_ctx *ctx, xsw_stats *out);
 
+/* Measurement aid (no reference counterpart): while enabled, every XSW_ALGO_PRUNED inversion of DEVICE rasters that takes the
+ * two-kernel path (k_invert_band, then k_invert_list on the pixels it left undecided) is bracketed by HIP events on the launch
+ * stream.  xsw_timing_read synchronises, returns the summed durations since the last read and forgets them. */
+typedef struct {
+    int64_t launches;        /* inversions measured                                                   */
+    double first_kernel_ms;  /* k_invert_band, summed over the launches                               */
+    double second_kernel_ms; /* k_invert_list, summed over the launches                               */
+    int64_t last_list_pixels;/* pixels the most recent launch left to k_invert_list                   */
+} xsw_timing;
+int xsw_timing_enable(xsw_ctx *ctx, int on);
+int xsw_timing_read(xsw_ctx *ctx, xsw_timing *out);
+
 /* Replaces the low->high resolution interpolation of Model._normalize_lut (windspeed/models.py:142-168:
  * `lut.interp(incidence=, wspd=, phi=)`, i.e. three sequential linear 1-D interpolations in the order
  * incidence -> wspd -> phi) on the device, with the arithmetic of scipy.interp1d

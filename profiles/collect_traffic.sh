@@ -17,7 +17,7 @@ for c in ("FETCH_SIZE","WRITE_SIZE"):
     for f in glob.glob(f"{R}/gpurun_out/traffic/{c}/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             k=r["Kernel_Name"]
-            name="k_detrend" if "k_detrend" in k else ("k_invert" if "k_invert" in k else None)
+            name="k_detrend" if "k_detrend" in k else ("k_invert" if "k_invert" in k else None)  # k_invert_band + k_invert_list of one inversion are summed
             if name and r["Counter_Name"]==c:
                 vals[name][c]=vals[name].get(c,0.0)+float(r["Counter_Value"])
 n=20000*20000
@@ -32,3 +32,4 @@ out={"raw_KiB":vals,"calibration":{"read_true_over_reported":cal_read,"write_tru
 json.dump(out,open(f"{R}/gpurun_out/traffic/summary.json","w"),indent=1)
 print(json.dumps(out,indent=1))
 PY
+rm -rf $R/gpurun_out/traffic/FETCH_SIZE $R/gpurun_out/traffic/WRITE_SIZE   # raw per-dispatch CSVs: large; the summary stays

@@ -22,7 +22,7 @@ GMF_IDS = {"gmf_cmod5": 0, "gmf_cmod5n": 1, "gmf_cmod5n_pr_zhangA": 2, "gmf_cmod
 EXPORTS = (
     "xsw_version", "xsw_device_count", "xsw_ctx_create", "xsw_ctx_destroy", "xsw_last_error", "xsw_set_stream", "xsw_use_own_stream",
     "xsw_synchronize", "xsw_lut_upload", "xsw_invert", "xsw_stats_enable", "xsw_stats_read", "xsw_detrend", "xsw_lut_interp", "xsw_gmf_eval",
-    "xsw_nesz_flatten", "xsw_lut_build", "xsw_lut_read",
+    "xsw_nesz_flatten", "xsw_lut_build", "xsw_lut_read", "xsw_timing_enable", "xsw_timing_read",
 )
 
 
@@ -50,6 +50,11 @@ class InvertArgs(ctypes.Structure):
 class Stats(ctypes.Structure):
     _fields_ = [("pixels_co", ctypes.c_uint64), ("cand_co", ctypes.c_uint64), ("pixels_exact", ctypes.c_uint64),
                 ("pixels_cr", ctypes.c_uint64)]
+
+
+class Timing(ctypes.Structure):
+    _fields_ = [("launches", ctypes.c_int64), ("first_kernel_ms", ctypes.c_double), ("second_kernel_ms", ctypes.c_double),
+                ("last_list_pixels", ctypes.c_int64)]
 
 
 _cdll = None
@@ -111,6 +116,8 @@ def load():
         lib.xsw_lut_build.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                       ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(LutStruct)]
         lib.xsw_lut_read.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+        lib.xsw_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.xsw_timing_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(Timing)]
         _cdll = lib
     return _cdll
 
@@ -267,6 +274,17 @@ class Context:
         self._check(self._lib.xsw_gmf_eval(self._h, int(gmf_id), inc.size, MEM_HOST, _ptr(inc), _ptr(wspd), _ptr(phi),
                                            _ptr(out)), "xsw_gmf_eval")
         return out
+
+    @_locked
+    def timing_enable(self, on=True):
+        self._check(self._lib.xsw_timing_enable(self._h, int(bool(on))), "xsw_timing_enable")
+
+    @_locked
+    def timing(self):
+        """xsw_timing_read: dict(launches, first_kernel_ms, second_kernel_ms) summed since the last read."""
+        t = Timing()
+        self._check(self._lib.xsw_timing_read(self._h, ctypes.byref(t)), "xsw_timing_read")
+        return {k: getattr(t, k) for k, _ in Timing._fields_}
 
     @_locked
     def stats_enable(self, on=True):

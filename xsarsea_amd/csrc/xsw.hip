@@ -34,6 +34,8 @@ struct xsw_ctx {
     bool have_co = false, have_cr = false;
     unsigned long long *d_stats = nullptr;
     bool stats_on = false;
+    bool timing_on = false;                 // xsw_timing_enable: HIP events around the kernels of every device-memory inversion
+    std::vector<hipEvent_t> timing_events;  // triples (start, after the first kernel, end) on the launch stream
     unsigned *d_list = nullptr;  // hand-over k_invert_band -> k_invert_list: [0] = count, [16..] = pixel indices
     size_t list_cap = 0;         // (context-owned, grown on demand)
     double *d_ratio = nullptr;  // detrend ratio row (context-owned, grown on demand)
@@ -121,6 +123,7 @@ extern "C" int xsw_ctx_destroy(xsw_ctx *c)
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_ratio) (void)hipFree(c->d_ratio);
     if (c->d_list) (void)hipFree(c->d_list);
+    for (hipEvent_t e : c->timing_events) (void)hipEventDestroy(e);
     if (c->arena) (void)hipFree(c->arena);
     if (c->s_in) (void)hipStreamDestroy(c->s_in);
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
@@ -156,6 +159,49 @@ extern "C" int xsw_stats_enable(xsw_ctx *c, int on)
     if (!c) return XSW_EINVAL;
     c->stats_on = on != 0;
     return XSW_OK;
+}
+
+extern "C" int xsw_timing_enable(xsw_ctx *c, int on)
+{
+    if (!c) return XSW_EINVAL;
+    for (hipEvent_t e : c->timing_events) (void)hipEventDestroy(e);
+    c->timing_events.clear();
+    c->timing_on = on != 0;
+    return XSW_OK;
+}
+
+extern "C" int xsw_timing_read(xsw_ctx *c, xsw_timing *out)
+{
+    if (!c || !out) return XSW_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    out->launches = 0;
+    out->first_kernel_ms = out->second_kernel_ms = 0.0;
+    out->last_list_pixels = 0;
+    if (c->d_list) {
+        unsigned cnt = 0;
+        HIPCHK(c, hipMemcpy(&cnt, c->d_list, sizeof cnt, hipMemcpyDeviceToHost));
+        out->last_list_pixels = (int64_t)cnt;
+    }
+    for (size_t k = 0; k + 3 <= c->timing_events.size(); k += 3) {
+        float a = 0.f, b = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&a, c->timing_events[k], c->timing_events[k + 1]));
+        HIPCHK(c, hipEventElapsedTime(&b, c->timing_events[k + 1], c->timing_events[k + 2]));
+        out->first_kernel_ms += a;
+        out->second_kernel_ms += b;
+        out->launches += 1;
+    }
+    for (hipEvent_t e : c->timing_events) (void)hipEventDestroy(e);
+    c->timing_events.clear();
+    return XSW_OK;
+}
+
+static void timing_mark(xsw_ctx *c)
+{
+    if (!c->timing_on) return;
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) == hipSuccess && hipEventRecord(e, c->stream) == hipSuccess) c->timing_events.push_back(e);
+    else c->timing_on = false;  // never half a triple
 }
 
 extern "C" int xsw_stats_read(xsw_ctx *c, xsw_stats *out)
@@ -423,6 +469,7 @@ static int launch_invert(xsw_ctx *c, const KArgs &A, int algo)
         (!A.s_cr || c->T.cr_monotone) && A.n < (1LL << 32)) {
         if ((size_t)A.n > c->list_cap) {
             if (c->d_list) (void)hipFree(c->d_list);
+    for (hipEvent_t e : c->timing_events) (void)hipEventDestroy(e);
             c->d_list = nullptr;
             c->list_cap = 0;
             if (hipMalloc((void **)&c->d_list, ((size_t)A.n + 16) * sizeof(unsigned)) != hipSuccess)
@@ -434,13 +481,17 @@ static int launch_invert(xsw_ctx *c, const KArgs &A, int algo)
         B.list = c->d_list + 16;
         HIPCHK(c, hipMemsetAsync(c->d_list, 0, sizeof(unsigned), c->stream));
         const unsigned list_blocks = (unsigned)std::min<long long>(nblocks, 256 * 8);
+        timing_mark(c);
         if (!A.s_cr && !A.out_cr) {
             hipLaunchKernelGGL((k_invert_band<T, TO, false>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, B);
+            timing_mark(c);
             hipLaunchKernelGGL((k_invert_list<T, TO, false>), dim3(list_blocks), dim3(256), 0, c->stream, c->T, B);
         } else {
             hipLaunchKernelGGL((k_invert_band<T, TO, true>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, B);
+            timing_mark(c);
             hipLaunchKernelGGL((k_invert_list<T, TO, true>), dim3(list_blocks), dim3(256), 0, c->stream, c->T, B);
         }
+        timing_mark(c);
         HIPCHK(c, hipGetLastError());
         return XSW_OK;
     }
