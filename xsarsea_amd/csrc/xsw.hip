@@ -480,7 +480,7 @@ static int launch_invert(xsw_ctx *c, const KArgs &A, int algo)
         B.list_count = c->d_list;
         B.list = c->d_list + 16;
         HIPCHK(c, hipMemsetAsync(c->d_list, 0, sizeof(unsigned), c->stream));
-        const unsigned list_blocks = (unsigned)std::min<long long>(nblocks, 256 * 8);
+        const unsigned list_blocks = (unsigned)std::min<long long>(nblocks, 256 * 8);  // 8 waves per SIMD
         timing_mark(c);
         if (!A.s_cr && !A.out_cr) {
             hipLaunchKernelGGL((k_invert_band<T, TO, false>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, B);

@@ -36,11 +36,15 @@ namespace xsw {
 #ifndef XSW_BAND_WALK_MAX
 #define XSW_BAND_WALK_MAX 16
 #endif
+// K directions per lane and the occupancy the kernel is compiled for.  Measured at 20000 x 20000 (band kernel alone):
+// K = 1 at 8 waves/SIMD (63 VGPRs, no scratch) 94.7 ms; K = 2 at 6 waves (80 VGPRs) 101.0 ms, forced to 7 / 8 waves
+// 101.5 / 101.9 ms (spills at 8); K = 1 at 7 waves 116 ms per step: with one direction per lane the pass is short enough
+// for the eighth wave to pay, and the walk that seeds the second direction costs what the wider lane saves.
 #ifndef XSW_BAND_K
-#define XSW_BAND_K 2
+#define XSW_BAND_K 1
 #endif
 #ifndef XSW_BAND_WAVES
-#define XSW_BAND_WAVES 1
+#define XSW_BAND_WAVES 8
 #endif
 
 struct BandSlot {  // 64 bytes per pixel, read by every lane of its segment (same address: LDS broadcast)

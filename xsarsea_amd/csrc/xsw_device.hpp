@@ -1028,9 +1028,14 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert_list(
     const int lane = threadIdx.x & 63;
     const long long count = (long long)*A.list_count;
     const long long nwaves = (long long)gridDim.x * 4;
-    for (long long c = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); c * 64 < count; c += nwaves) {  // wave-uniform
-        const long long k = c * 64 + lane;
-        const bool in = k < count;
+    // XSW_LIST_PX pixels per wave and pass: the cooperative stage takes the pixels one after the other, so fewer pixels per
+    // wave spread a short list over more SIMDs (the per-lane stage runs with idle lanes, which costs nothing here)
+#ifndef XSW_LIST_PX
+#define XSW_LIST_PX 16
+#endif
+    for (long long c = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); c * XSW_LIST_PX < count; c += nwaves) {  // wave-uniform
+        const long long k = c * XSW_LIST_PX + lane;
+        const bool in = lane < XSW_LIST_PX && k < count;
         const long long i = (long long)A.list[in ? k : count - 1];
         invert_strip<T, TO, 1, CR>(L, A, i, in, lane);
     }
