@@ -482,12 +482,18 @@ static int launch_invert(xsw_ctx *c, const KArgs &A, int algo)
         HIPCHK(c, hipMemsetAsync(c->d_list, 0, sizeof(unsigned), c->stream));
         const unsigned list_blocks = (unsigned)std::min<long long>(nblocks, 256 * 8);  // 8 waves per SIMD
         timing_mark(c);
-        if (!A.s_cr && !A.out_cr) {
-            hipLaunchKernelGGL((k_invert_band<T, TO, false>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, B);
+        if (A.stats) {  // statistics instantiation (counts the scored candidates)
+            if (!A.s_cr && !A.out_cr) hipLaunchKernelGGL((k_invert_band<T, TO, false, true>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, B);
+            else hipLaunchKernelGGL((k_invert_band<T, TO, true, true>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, B);
+            timing_mark(c);
+            if (!A.s_cr && !A.out_cr) hipLaunchKernelGGL((k_invert_list<T, TO, false>), dim3(list_blocks), dim3(256), 0, c->stream, c->T, B);
+            else hipLaunchKernelGGL((k_invert_list<T, TO, true>), dim3(list_blocks), dim3(256), 0, c->stream, c->T, B);
+        } else if (!A.s_cr && !A.out_cr) {
+            hipLaunchKernelGGL((k_invert_band<T, TO, false, false>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, B);
             timing_mark(c);
             hipLaunchKernelGGL((k_invert_list<T, TO, false>), dim3(list_blocks), dim3(256), 0, c->stream, c->T, B);
         } else {
-            hipLaunchKernelGGL((k_invert_band<T, TO, true>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, B);
+            hipLaunchKernelGGL((k_invert_band<T, TO, true, false>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, B);
             timing_mark(c);
             hipLaunchKernelGGL((k_invert_list<T, TO, true>), dim3(list_blocks), dim3(256), 0, c->stream, c->T, B);
         }

@@ -175,7 +175,9 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
     }
 }
 
-template <typename T, typename TO, bool CR>
+// COUNT = true: the statistics instantiation (xsw_stats_enable): candidates are counted per pass; its own kernel so that the
+// production kernel carries one copy of each pass (half the code).
+template <typename T, typename TO, bool CR, bool COUNT>
 __global__ __launch_bounds__(256, XSW_BAND_WAVES) void k_invert_band(DevTables L, KArgs A)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256, XSW_BAND_WAVES) void k_invert_band(DevTables L
                 b.i_inc = P.i_inc; b.rows = W.w_lo | (W.w_hi << 16); b.ip_lo = W.ip_lo; b.ncols = ncols_p;
                 slots[wv][lane] = b;
             }
-            if (A.stats) cand += (unsigned)__popcll(__ballot(eligb)) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)));
+            if (COUNT) cand += (unsigned)__popcll(__ballot(eligb)) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)));
         }
         constexpr int BK = XSW_BAND_K;
         unsigned long long seen = 0;
@@ -239,8 +241,7 @@ __global__ __launch_bounds__(256, XSW_BAND_WAVES) void k_invert_band(DevTables L
         constexpr int BK = XSW_BAND_K;
         auto run = [&](auto seg, unsigned long long m, int nsteps) {
             constexpr int S = decltype(seg)::value;
-            if (A.stats) while (m) co_band_pass<S, BK, true>(L, A.inv_dsig_co, nsteps, lane, slots[wv], map_[wv], res_[wv], m, my_flat, cand);
-            else while (m) co_band_pass<S, BK, false>(L, A.inv_dsig_co, nsteps, lane, slots[wv], map_[wv], res_[wv], m, my_flat, cand);
+            while (m) co_band_pass<S, BK, COUNT>(L, A.inv_dsig_co, nsteps, lane, slots[wv], map_[wv], res_[wv], m, my_flat, cand);
         };
         run(std::integral_constant<int, 2>{}, cls[0], ns[0]);
         run(std::integral_constant<int, 4>{}, cls[1], ns[1]);
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(256, XSW_BAND_WAVES) void k_invert_band(DevTables L
         unresolved = unresolved || (need_cr && (undecided || !done));
         if (need_cr) flags |= F_NEED_CR;
     }
-    if (A.stats) {
+    if (COUNT && A.stats) {
         const unsigned long long done_co = __ballot(in && need_co && my_flat >= 0), done_cr = __ballot(need_cr && !unresolved);
 #ifdef XSW_DEBUG_REASONS  // pixels_exact := not-eligible count | undecided-by-pass count << 32 (experiments only)
         const unsigned long long noel = __ballot(in && need_co && !((seen_all >> lane) & 1ULL)), und = __ballot(in && need_co && ((seen_all >> lane) & 1ULL) && my_flat < 0);
