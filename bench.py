@@ -287,6 +287,32 @@ def detrend_figures(args, ctx, stream, s_vv, lines, samples):
                          "traffic": traffic}}
 
 
+def nesz_figures(args, ctx, stream, noise, inc, lines, samples):
+    """`nesz_flattening` (windspeed/utils.py:94-163) on resident float32 rasters -> float64: the raster pass in front of the
+    dual-pol inversion.  Algorithmic bytes: noise read twice (column means, then the per-line fit) + incidence once + float64
+    out = 20 B per pixel.  (The sigma0 raster stands in for a noise raster: same NaN holes, positive values.)"""
+    from xsarsea_amd import _lib
+    out = torch.empty((lines, samples), dtype=torch.float64, device=noise.device)
+
+    def step():
+        ctx.nesz_flatten_raw(lines, samples, _lib.XSW_F32, _lib.MEM_DEVICE, noise.data_ptr(), inc.data_ptr(), out.data_ptr())
+
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()  # returns after the work has completed (call-local scratch)
+    dt = (time.perf_counter() - t0) / args.steps
+    del out
+    px = lines * samples
+    achieved = 20.0 * px / dt / 1e9
+    return {"workload": f"nesz_flattening, {lines}x{samples} float32 noise + incidence -> float64 (k_nesz_colsum + k_nesz_colmean + k_nesz_center + k_nesz_rows)",
+            "value": round(px / dt / 1e6, 1), "unit": "Mpixels/s", "ms_per_call": round(dt * 1e3, 3), "bytes_per_pixel": 20,
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "note": "wall time of the synchronous call (three launches, a scratch hipMalloc/hipFree and a stream sync included)"}}
+
+
 # ------------------------------------------------------------------------------------------ rank launcher
 def _free_port():
     with socket.socket() as s:
@@ -648,6 +674,7 @@ def main():
                                  "valu_frac": round(xops / LANE_OPS_PEAK, 4)}
         if extras:
             res["detrend"] = detrend_figures(args, ctx, stream, s_vv, lines, samples)
+            res["nesz_flatten"] = nesz_figures(args, ctx, stream, s_vv, inc, lines, samples)
         if n_gpus == 1 and not args.no_cpu_baseline and mode == "mono":
             cpu, parity = cpu_baseline_and_parity(ctx, inc, s_vv, anc, args.algo)
             res["cpu_baseline"] = cpu

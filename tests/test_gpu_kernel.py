@@ -178,6 +178,66 @@ def test_u10_v10_tolerance(gpu_ctx, default_luts):
     assert_complex_close(got[0], o[0], rtol=1e-4, what="u10/v10")
 
 
+def test_two_kernel_path_bookkeeping(gpu_ctx, default_luts):
+    """The pruned algorithm on a monotone LUT runs as k_invert_band + k_invert_list: the timing facility sees both kernels,
+    the work list is short, the candidate counters of the two kernels add up, and XSW_NO_BAND-style results (the general
+    kernel alone: XSW_ALGO_EXACT) are identical."""
+    lco, _ = default_luts
+    co, _ = lut_dicts(lco, None)
+    gpu_ctx.upload_luts(co=co)
+    inc, s_vv, _, _, anc = synthetic_scene(96, 700, np.float32, 5)
+    n = inc.size
+    gpu_ctx.timing_enable(True)
+    gpu_ctx.stats_enable(True)
+    try:
+        import torch
+        dev = torch.device("cuda", 0)
+        t_inc, t_s, t_anc = (torch.from_numpy(a).to(dev) for a in (inc, s_vv, anc))
+        out = torch.empty(inc.shape, dtype=torch.complex64, device=dev)
+        torch.cuda.synchronize()
+        from xsarsea_amd import _lib
+        gpu_ctx.invert_raw(inc.shape[0], inc.shape[1], _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, t_inc.data_ptr(), t_s.data_ptr(), None, None,
+                           t_anc.data_ptr(), out.data_ptr(), None, algo=_lib.ALGO_PRUNED)
+        tm, st = gpu_ctx.timing(), gpu_ctx.stats()
+    finally:
+        gpu_ctx.timing_enable(False)
+        gpu_ctx.stats_enable(False)
+    assert tm["launches"] == 1 and tm["first_kernel_ms"] > 0 and tm["second_kernel_ms"] >= 0
+    valid = int(np.sum(~np.isnan(inc) & ~np.isnan(s_vv)))
+    assert st["pixels_co"] == valid, (st, valid)
+    assert 0 <= tm["last_list_pixels"] < 0.05 * n, tm
+    assert 16 < st["cand_co"] / valid < 400  # a few dozen candidates per pixel, not the 90 319 of the grid
+    ex = gpu_ctx.invert_host(inc, sigma0_co=s_vv, anc=anc, algo="exact", out_dtype=np.complex64)
+    assert np.array_equal(out.cpu().numpy().view(np.int32), ex[0].view(np.int32))
+
+
+def test_axis_off_the_uniform_grid_takes_the_exact_kernel(gpu_ctx):
+    """A wind-speed axis perturbed by 5e-7 of a step is NOT uniform to the budget the pruned kernels' screening assumes
+    (csrc/xsw.hip: uniform_axis): it must take the exact kernel -- and give the oracle's indices."""
+    from oracle import gmf, lut as olut
+    rng = np.random.default_rng(3)
+    inc_ax, w_ax, phi_ax = np.linspace(20, 44, 9), np.linspace(0.5, 39.5, 196), np.linspace(0, 180, 91)
+    step = w_ax[1] - w_ax[0]
+    w_ax = w_ax + 5e-7 * step * rng.uniform(-1, 1, w_ax.size)
+    co_db = 10 * np.log10(gmf.gmf_cmod5n(inc_ax[:, None, None], w_ax[None, :, None], phi_ax[None, None, :]) + 1e-15)
+    lco = olut.Lut(co_db, inc_ax, w_ax, phi_ax, "dB", "x", "co", "VV")
+    co, _ = lut_dicts(lco, None)
+    gpu_ctx.upload_luts(co=co)
+    inc, s_vv, _, _, anc = synthetic_scene(20, 150, np.float64, 9)
+    inc = np.clip(inc, 20.5, 43.5)
+    o = oracle_full(inc, s_vv, None, None, anc, lco, None)
+    gpu_ctx.stats_enable(True)
+    try:
+        got = gpu_ctx.invert_host(inc, sigma0_co=s_vv, anc=anc, algo="auto", want_idx=True)
+        st = gpu_ctx.stats()
+    finally:
+        gpu_ctx.stats_enable(False)
+    assert np.array_equal(got[2][..., :2], o[2][..., :2])
+    assert st["cand_co"] == st["pixels_co"] * len(w_ax) * len(phi_ax), "every candidate scored: the exact kernel ran"
+    with pytest.raises(Exception, match="uniform finite LUT"):
+        gpu_ctx.invert_host(inc, sigma0_co=s_vv, anc=anc, algo="exhaustive")
+
+
 def test_stats_and_exact_fallback(gpu_ctx, default_luts):
     lco, lcr = default_luts
     co, cr = lut_dicts(lco, lcr)
