@@ -508,6 +508,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:  # connect every peer to rank 0 once (RCCL builds its point-to-point channels lazily), whatever --warmup is
+        hello = torch.zeros((world, samples), dtype=torch.complex64, device=device)
+        for q in multi_gpu.gather_chunk_async(hello[rank:rank + 1] if rank else hello[:1], world, 0, 1, dst=0, out=hello):
+            q.wait()
+        del hello
     for _ in range(args.warmup):
         step()
         gather()
