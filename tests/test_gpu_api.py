@@ -316,6 +316,13 @@ def test_lut_interp_device_equals_host(gpu_ctx):
         dev = gpu_ctx.lut_interp(raw.values, raw.incidence, raw.wspd, raw.phi, inc, wspd, phi)
         t2 = time.perf_counter()
         assert dev.shape == host.shape and np.array_equal(dev, host), name
+        # and against the ORACLE's restatement of xarray's interp (scipy interp1d per dimension: oracle/lut.py), not
+        # only the product's own host path: same raw table in, same bits out
+        from oracle import lut as olut
+        o_raw = olut.raw_lut(name)
+        assert np.array_equal(o_raw.values, raw.values), name
+        o_hi = olut.normalize_lut(o_raw, resolution="high")
+        assert np.array_equal(dev, o_hi.values), name
         print(f"{name}: host lerp {t1 - t0:.2f} s, device {t2 - t1:.3f} s")
     with pytest.raises(_lib.XswError, match="outside the interpolation range"):
         gpu_ctx.lut_interp(raw.values, raw.incidence, raw.wspd, None, inc + 1.0, wspd, None)

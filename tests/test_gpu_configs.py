@@ -164,6 +164,37 @@ def _run_bench(extra_args, tmp_path):
     return json.loads(lines[0])
 
 
+def test_bench_line_contract(tmp_path):
+    """The default bench command (at a reduced raster so that it runs in seconds) prints ONE JSON line carrying the driver's
+    contract: metric/value/unit/n_gpus/..., `roofline` (hbm, dominant kernel, its own HIP-event time, the valu view),
+    `cpu_baseline` (oracle C port on a bounded crop) and the parity block; the two-kernel path reports both kernels."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, bench, "--lines", "768", "--samples", "2048", "--steps", "2", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["unit"] == "Mpixels/s" and j["vs_baseline"] is None and j["value"] > 0
+    rf = j["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-5
+    assert rf["kernel"] == "k_invert_band" and rf["kernel_ms"] > 0 and rf["second_kernel"]["kernel"] == "k_invert_list"
+    assert rf["kernel_ms"] + rf["second_kernel"]["kernel_ms"] <= rf["step_kernels_ms"] * 1.05 + 0.05
+    v = rf["valu"]
+    assert v["candidates_per_pixel_full_grid"] == 499 * 181 and 16 < v["evaluated_candidates_per_pixel"] < 1000 and 0 < v["frac"] < 1
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "crop" in cb["sample"]
+    p = j["parity"]
+    assert p["nan_mask_equal"] is True and p["index_match_host_db"] == 1.0 and p["index_match_device_db"] > 0.999
+    assert j["detrend"]["roofline"]["bound"] == "hbm" and j["nesz_flatten"]["roofline"]["bound"] == "hbm" and j["lut"]["lut_device_build_ms"] > 0
+
+
 @pytest.mark.parametrize("cfg,shape", [("4", (2503, 1700)), ("3", (1001, 1030))])
 def test_two_rank_rehearsal_gathers_the_single_launch_raster(cfg, shape, tmp_path):
     """`python bench.py --gpus 2` starts its own two ranks (here both on this GPU, gloo instead of RCCL): strong scaling,
