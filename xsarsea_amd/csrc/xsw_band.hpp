@@ -43,6 +43,12 @@ namespace xsw {
 #ifndef XSW_BAND_K
 #define XSW_BAND_K 1
 #endif
+#ifndef XSW_BAND_RAY_D
+#define XSW_BAND_RAY_D 2
+#endif
+#ifndef XSW_BAND_RAYS
+#define XSW_BAND_RAYS 3   // rays of the upper bound (co_window_lanes)
+#endif
 #ifndef XSW_BAND_WAVES
 #define XSW_BAND_WAVES 8
 #endif
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(256, XSW_BAND_WAVES) void k_invert_band(DevTables L
         int ncols_p = 0, bits = 0;
         if (todo) {
             bool loose = false;
-            const CoWindow W = co_window_lanes(L, P, A.inv_dsig_co, loose);
+            const CoWindow W = co_window_lanes<XSW_BAND_RAYS, XSW_BAND_RAY_D>(L, P, A.inv_dsig_co, loose);
             const int nrows_p = W.w_hi - W.w_lo + 1;
             ncols_p = W.ip_hi - W.ip_lo + 1;
             const bool need = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0 && !loose && ncols_p >= 1 && nrows_p >= 1;
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(256, XSW_BAND_WAVES) void k_invert_band(DevTables L
                 b.i_inc = P.i_inc; b.rows = W.w_lo | (W.w_hi << 16); b.ip_lo = W.ip_lo; b.ncols = ncols_p;
                 slots[wv][lane] = b;
             }
-            if (COUNT) cand += (unsigned)__popcll(__ballot(eligb)) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)));
+            if (COUNT) cand += (unsigned)__popcll(__ballot(eligb)) * (unsigned)(XSW_BAND_RAYS * 2 * (32 - __clz((L.n_w + 1) >> 1)));
         }
         constexpr int BK = XSW_BAND_K;
         unsigned long long seen = 0;
