@@ -161,11 +161,13 @@ def band_pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig, 
     npairs = (n_w + 1) >> 1
     rbest, nray = np.inf, 0
     # three rays (k_invert_band: co_window_lanes<3, 2>): the direction nearest to m and the ones two grid steps to either side
-    for ipq in (ipr, max(ipr - 2, 0), min(ipr + 2, n_phi - 1)):
+    seed = 0
+    for q, ipq in enumerate((ipr, max(ipr - 2, 0), min(ipr + 2, n_phi - 1))):
         ur = 2.0 * (ah * cphi[ipq] + bh * sphi[ipq])
-        lo, hi = 0, npairs
+        # the side rays bisect 3 steps in a bracket of +-4 row pairs around the first ray's result (any score seen is a bound)
+        lo, hi = (0, npairs) if q == 0 else (max(seed - 4, 0), min(seed + 4, npairs))
         col = slice_wp[:, ipq]
-        for _ in range(int(npairs).bit_length()):
+        for _ in range(int(npairs).bit_length() if q == 0 else 3):
             mid = min((lo + hi) >> 1, npairs - 1)
             ja = wh[2 * mid] * (wh[2 * mid] - ur) + (col[2 * mid] * inv + sn) ** 2
             jb = wh[2 * mid + 1] * (wh[2 * mid + 1] - ur) + (col[2 * mid + 1] * inv + sn) ** 2 if 2 * mid + 1 < n_w else np.inf
@@ -176,6 +178,8 @@ def band_pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig, 
                     lo = mid + 1
                 else:
                     hi = mid
+        if q == 0:
+            seed = lo
     j_ub = (rbest + m2) * (1.0 + 1e-9) + 1e-9
     w_lo, w_hi, ip_lo, ip_hi = search_window(mag, theta, rbest + m2, w0, inv_wstep, n_w, phi0, phi[-1], inv_dphi, n_phi)
 

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, XSW_BAND_WAVES) void k_invert_band(DevTables L
                 b.i_inc = P.i_inc; b.rows = W.w_lo | (W.w_hi << 16); b.ip_lo = W.ip_lo; b.ncols = ncols_p;
                 slots[wv][lane] = b;
             }
-            if (COUNT) cand += (unsigned)__popcll(__ballot(eligb)) * (unsigned)(XSW_BAND_RAYS * 2 * (32 - __clz((L.n_w + 1) >> 1)));
+            if (COUNT) cand += (unsigned)__popcll(__ballot(eligb)) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)) + (XSW_BAND_RAYS - 1) * 2 * XSW_RAY_SIDE_STEPS);
         }
         constexpr int BK = XSW_BAND_K;
         unsigned long long seen = 0;

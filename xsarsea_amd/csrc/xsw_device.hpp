@@ -351,7 +351,11 @@ __device__ __forceinline__ CoWindow box_from_jub(const DevTables &L, double mag,
 // a pixel (sigma0 wildly at odds with the ancillary wind, or a pathological LUT) takes the exact full scan.
 // NRAYS = 3: the bound is the smallest score seen on three rays, the direction nearest to the ancillary wind and the ones RAY_D
 // grid directions to either side of it (any candidate bounds the minimum from above).  On the benchmark scene that takes
-// the windows from 18.4 x 25.2 to 16.2 x 22.8 (directions x speeds) for two more 8-probe bisections per pixel.
+// the windows from 18.4 x 25.2 to 16.2 x 22.8 (directions x speeds) for two short bisections more per pixel
+// (measured, band kernel at 20000^2: 1 ray 93.9 ms; 3 full rays 85.3; side rays seeded, 4 / 3 steps 84.5 / 83.9; 5 and 7 rays 87.7 / 88.8).
+#ifndef XSW_RAY_SIDE_STEPS
+#define XSW_RAY_SIDE_STEPS 3
+#endif
 template <int NRAYS = 1, int RAY_D = 2>
 __device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pixel &P, double inv_dsig, bool &loose)
 {
@@ -367,14 +371,18 @@ __device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pi
     // column that is not unimodal merely loosens the bound.  For a unimodal column the minimum itself is seen.
     const int npairs = (L.n_w + 1) >> 1;
     double rbest = inf;
+    int seed = 0;  // row pair where the first ray ended: the side rays look around it only (RAY_SIDE_STEPS bisection steps)
 #pragma unroll
     for (int q = 0; q < NRAYS; ++q) {
         const int dq = ((q + 1) >> 1) * RAY_D + (q > 2 ? 1 : 0);  // 0, -D, +D, -(2D+1), +(2D+1), ...
         const int ipr = fin ? min(max(P.ipr + ((q & 1) ? -dq : dq), 0), L.n_phi - 1) : 0;
         const double ur = 2.0 * (ah * L.cphi[ipr] + bh * L.sphi[ipr]);
         const double *__restrict__ ray = L.coT + ((size_t)(fin ? P.i_inc : 0) * L.n_phi + ipr) * L.w_pad;
-        int lo = 0, hi = npairs;
-        for (int it = 32 - __clz(npairs); it > 0; --it) {  // wave-uniform trip count
+        // q > 0: any score seen is a valid upper bound, so a side ray may start from a bracket around the first ray's
+        // result (the minimum moves by a row or two per degree); a minimum outside the bracket only loosens the bound
+        constexpr int half = 1 << (XSW_RAY_SIDE_STEPS - 1);
+        int lo = q == 0 ? 0 : max(seed - half, 0), hi = q == 0 ? npairs : min(seed + half, npairs);
+        for (int it = (q == 0 ? 32 - __clz(npairs) : XSW_RAY_SIDE_STEPS); it > 0; --it) {  // wave-uniform trip count
             const int mid = min((lo + hi) >> 1, npairs - 1);
             const double2 v = *(const double2 *)(ray + 2 * mid);  // w_pad is even: the pad row is masked below
             const double wh_a = fma((double)(2 * mid), whs, wh0), wh_b = wh_a + whs;
@@ -386,6 +394,7 @@ __device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pi
             lo = (open && right) ? mid + 1 : lo;
             hi = (open && !right) ? mid : hi;
         }
+        if (q == 0) seed = lo;
     }
     const double jub = (rbest + m2) * (1.0 + 1e-9) + 1e-9;
     loose = fin && !(jub <= 500.0 * (1.0 + m2));
