@@ -372,7 +372,7 @@ __device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pi
     const int npairs = (L.n_w + 1) >> 1;
     double rbest = inf;
     int seed = 0;  // row pair where the first ray ended: the side rays look around it only (RAY_SIDE_STEPS bisection steps)
-#pragma unroll
+#pragma unroll 1
     for (int q = 0; q < NRAYS; ++q) {
         const int dq = ((q + 1) >> 1) * RAY_D + (q > 2 ? 1 : 0);  // 0, -D, +D, -(2D+1), +(2D+1), ...
         const int ipr = fin ? min(max(P.ipr + ((q & 1) ? -dq : dq), 0), L.n_phi - 1) : 0;
