@@ -651,9 +651,12 @@ __device__ __forceinline__ bool search_cr_interval(const DevTables &L, bool need
     const double f = (fast && have_co) ? 1.0 : 0.0;
     const double g = (fast && have_co) ? -0.5 * aco : 0.0;
     const int n = L.n_wcr;
+    // w/2 of candidate k from the (uniform: cr_monotone implies it) axis instead of a table load; the screening tolerance
+    // below covers the last-bit difference to the tabulated 0.5 * w[k]
+    const double whs = 0.5 / L.inv_wcrstep, wh0 = 0.5 * L.wcr0;
     auto score = [&](int k) {
         const double dd = fma(row[k], invf, sn);
-        const double t = fma(L.wcrh[k], f, g);
+        const double t = fma(fma((double)k, whs, wh0), f, g);
         return fma(t, t, dd * dd);
     };
     // upper bound from three candidates
@@ -664,9 +667,22 @@ __device__ __forceinline__ bool search_cr_interval(const DevTables &L, bool need
     double jub = vmin(score(ka), vmin(score(kp), score(have_co ? kw : ka)));
     jub = jub * (1.0 + 1e-9) + 1e-300;
     const double d = fabs(fast ? dsig : 1.0) * sqrt(jub) * (1.0 + 1e-9) + 1e-12 * (1.0 + fabs(sq));
-    int lo = max(lower_bound_row(row, n, sq - d) - 1, 0);
-    int hi = min(lower_bound_row(row, n, sq + d * (1.0 + 1e-15) + 1e-300) + 1, n - 1);  // >= upper_bound(s + d)
-    while (hi < n - 1 && row[hi] <= sq + d) ++hi;  // plateau at exactly s + d (never more than a step or two)
+    // the wind term is >= 0 too: ((w - |co|)/2)^2 <= J_ub, i.e. |w - |co|| <= 2 sqrt(J_ub): the index window [a0, a1] (with a
+    // margin; uniform axis to 1e-12: csrc/xsw.hip uniform_axis).  The sigma0 interval is then looked for inside it only
+    // (shorter bisections); the three seed candidates satisfy both bounds.
+    int a0 = 0, a1 = n - 1;
+    if (fast && have_co) {
+        const double rw = 2.0 * sqrt(jub) * (1.0 + 1e-9) + 1e-9;
+        const double xl = (aco - rw - L.wcr0) * L.inv_wcrstep, xh = (aco + rw - L.wcr0) * L.inv_wcrstep;
+        const double nn = (double)n;
+        a0 = max((int)ceil(fmin(fmax(xl - 1e-5 - 1e-9 * fabs(xl), -4.0), nn + 4.0)), 0);
+        a1 = min((int)floor(fmin(fmax(xh + 1e-5 + 1e-9 * fabs(xh), -4.0), nn + 4.0)), n - 1);
+        if (a1 < a0) { a0 = 0; a1 = n - 1; }  // cannot happen (the best seed lies inside); stay safe
+    }
+    const int span = a1 - a0 + 1;
+    int lo = max(a0 + lower_bound_row(row + a0, span, sq - d) - 1, a0);
+    int hi = min(a0 + lower_bound_row(row + a0, span, sq + d * (1.0 + 1e-15) + 1e-300) + 1, a1);  // >= upper_bound(s + d) within the window
+    while (hi < a1 && row[hi] <= sq + d) ++hi;  // plateau at exactly s + d (never more than a step or two)
     const int len = fast ? (hi - lo + 1) : 0;
     if (__ballot(len > 160) != 0ULL) return false;  // a long interval somewhere in the wave: full sweep instead
     int maxlen = len;
