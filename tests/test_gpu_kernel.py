@@ -372,6 +372,32 @@ def test_cmod7_shaped_lut(gpu_ctx, tmp_path):
     assert_complex_close(got, o[0], what="cmod7")
 
 
+def test_netcdf_lut_model_inversion(gpu_ctx, tmp_path):
+    """a LUT stored in the xsarsea netCDF format (written by `Model.to_netcdf`, read back by `NcLutModel`; classic
+    netCDF-3 through scipy where xarray is absent) drives the inversion; the oracle is fed the LUT the model prepared."""
+    import warnings
+    from oracle import lut as olut
+    from xsarsea_amd import windspeed
+    from xsarsea_amd.windspeed import models
+    if models.xr is not None:
+        pytest.skip("xarray present: covered by the xarray route")
+    windspeed.get_model("gmf_cmod5n").to_netcdf(str(tmp_path / "nc_lut_gpu_cmod5n.nc"))
+    windspeed.register_nc_luts(str(tmp_path))
+    try:
+        m = windspeed.get_model("nc_lut_gpu_cmod5n")
+        lut = m._lut(units="dB")
+        assert lut.shape == (501, 499, 181)
+        lco = olut.Lut(lut.values, lut.incidence, lut.wspd, lut.phi, "dB", "high", m.name, "VV")
+        inc, s_vv, _, _, anc = synthetic_scene(36, 140, np.float64, 91)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = windspeed.invert_from_model(inc, s_vv, ancillary_wind=anc, model="nc_lut_gpu_cmod5n")
+        o = oracle_full(inc, s_vv, None, None, anc, lco, None)
+        assert_complex_close(got, o[0], what="netCDF LUT model")
+    finally:
+        models.Model._available_models.pop("nc_lut_gpu_cmod5n", None)
+
+
 @pytest.mark.parametrize("kind", ["constant", "plateaus"])
 def test_exact_ties_resolve_to_first_index(gpu_ctx, kind):
     """numpy argmin returns the FIRST minimum.  A constant (or piecewise-constant) LUT on binary-fraction axes

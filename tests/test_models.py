@@ -228,3 +228,45 @@ def test_pickle_lut_directories(tmp_path):
     assert np.array_equal(lcr.values, cr) and lcr.phi is None
     lin = mcr._lut(units="linear")
     assert np.allclose(lin.values, 10 ** (cr / 10))
+
+
+def test_netcdf_lut_roundtrip(tmp_path):
+    """`Model.to_netcdf` -> `register_nc_luts` -> `NcLutModel` (models.py:232-262, :350-450) without xarray: classic netCDF-3
+    through scipy, the reference's schema (sigma0_model over incidence/wspd[/phi], global attrs units, resolution, model, pol,
+    *_range, *_step).  Co-pol models are stored at low resolution in dB, cross-pol at high resolution; reading back gives the
+    same table, axes and metadata, and the model then prepares a default-resolution dB LUT like any other."""
+    from scipy.io import netcdf_file
+    from xsarsea_amd.windspeed import nc_io
+    if models.xr is not None:
+        pytest.skip("xarray present: the scipy route is not the one taken")
+    co, cr = windspeed.get_model("gmf_cmod5n"), windspeed.get_model("gmf_s1_v2")
+    p_co, p_cr = tmp_path / "nc_lut_rt_cmod5n.nc", tmp_path / "nc_lut_rt_s1_v2.nc"
+    co.to_netcdf(str(p_co))
+    cr.to_netcdf(str(p_cr))
+    assert nc_io.is_classic_netcdf(str(p_co))
+    with netcdf_file(str(p_co), "r", mmap=False) as f:
+        assert f.variables["sigma0_model"].dimensions == ("incidence", "wspd", "phi") and f.variables["sigma0_model"].shape == (51, 250, 73)
+        assert f.units == b"dB" and f.resolution == b"low" and f.model == b"cmod5n" and f.pol == b"VV"
+        assert list(f.inc_range) == [16.0, 66.0] and list(f.phi_range) == [0.0, 180.0] and float(f.wspd_step) == 0.2
+    windspeed.register_nc_luts(str(tmp_path))
+    avail = windspeed.available_models()
+    assert "nc_lut_rt_cmod5n" in avail.index and "nc_lut_rt_s1_v2" in avail.index
+    m_co, m_cr = windspeed.get_model("nc_lut_rt_cmod5n"), windspeed.get_model("nc_lut_rt_s1_v2")
+    assert isinstance(m_co, models.NcLutModel) and m_co.pol == "VV" and m_co.iscopol and m_cr.iscrosspol and m_co.short_name == "cmod5n"
+    assert m_co.inc_step_lr == 1.0 and m_co.wspd_step_lr == 0.2 and m_co.phi_step_lr == 2.5 and m_co.units == "dB"
+    raw = m_co._raw_lut()
+    ref = co._lut(units="dB", resolution="low")
+    assert np.array_equal(raw.values, ref.values) and np.array_equal(raw.wspd, ref.wspd) and raw.attrs["resolution"] == "low"
+    raw_cr = m_cr._raw_lut()
+    assert np.array_equal(raw_cr.values, cr._lut(units="dB", resolution="high").values) and raw_cr.phi is None
+    hi = m_co._lut(units="dB")  # low -> high in the LUT's own (dB) units, as the reference does for a dB table
+    assert hi.shape == (501, 499, 181) and hi.attrs["units"] == "dB"
+    assert np.allclose(hi.values[::10, ::2, ::5], raw.values[:, :, ::2], rtol=0, atol=1e-9)  # the shared grid nodes are kept
+    assert m_cr._lut(units="dB").shape == (501, 771)
+    # an HDF5-based file is refused with a clear message when xarray is absent
+    bad = tmp_path / "nc_lut_hdf5.nc"
+    bad.write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
+    with pytest.raises(ImportError, match="classic netCDF-3"):
+        models.NcLutModel(str(bad))
+    for n in ("nc_lut_rt_cmod5n", "nc_lut_rt_s1_v2"):
+        models.Model._available_models.pop(n, None)

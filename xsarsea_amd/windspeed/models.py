@@ -151,11 +151,18 @@ class Model:
         return lut.to_xarray() if xr is not None else lut
 
     def to_netcdf(self, file):
-        """Save the model as an xsarsea-format netCDF LUT (models.py:232-262).  Needs xarray."""
-        if xr is None:
-            raise ImportError("to_netcdf needs xarray")
+        """Save the model as an xsarsea-format netCDF LUT (models.py:232-262): through xarray when it is installed, else as
+        classic netCDF-3 through scipy (`nc_io.write_lut`: same variables and global attributes)."""
         resolution = "low" if self.iscopol else "high"
         lut = self._lut(resolution=resolution, units="dB")
+        if xr is None:
+            from . import nc_io
+            step = lambda ax: float(np.round(np.unique(np.diff(ax)), decimals=2)[0])
+            attrs = dict(units="dB", resolution=resolution, model=self.short_name, pol=self.pol, inc_range=self.inc_range,
+                         wspd_range=self.wspd_range, wspd_step=step(lut.wspd), inc_step=step(lut.incidence))
+            if lut.phi is not None:
+                attrs.update(phi_range=self.phi_range, phi_step=step(lut.phi))
+            return nc_io.write_lut(file, lut, attrs)
         ds = lut.to_xarray().to_dataset(promote_attrs=True)
         ds.sigma0_model.attrs.clear()
         ds.attrs.update(pol=self.pol, inc_range=self.inc_range, wspd_range=self.wspd_range, resolution=resolution,
@@ -229,7 +236,8 @@ class ArrayLutModel(LutModel):
 
 class NcLutModel(LutModel):
     """LUT stored in the xsarsea netCDF format (variable `sigma0_model`, global attrs units / pol /
-    model / resolution / *_range / *_step; models.py:361-410).  Needs xarray to read the file."""
+    model / resolution / *_range / *_step; models.py:361-410).  Read through xarray when it is installed, else classic
+    netCDF-3 files through scipy (`nc_io`)."""
 
     _priority = 10
 
@@ -238,15 +246,18 @@ class NcLutModel(LutModel):
         return self._short_name
 
     def __init__(self, path, **kwargs):
-        if xr is None:
-            raise ImportError("NcLutModel needs xarray to read netCDF LUTs")
         name = os.path.splitext(os.path.basename(path))[0]
-        with xr.open_dataset(path) as nc:
-            for attr in ("units", "pol", "model", "resolution", "inc_range", "wspd_range", "phi_range", "inc_step",
-                         "wspd_step", "phi_step"):
-                if attr in nc.attrs:
-                    v = nc.attrs[attr]
-                    kwargs[attr] = list(v) if isinstance(v, np.ndarray) else v
+        if xr is None:  # classic netCDF-3 files through scipy (nc_io); HDF5-based netCDF-4 needs xarray
+            from . import nc_io
+            file_attrs = nc_io.read_attrs(path)
+        else:
+            with xr.open_dataset(path) as nc:
+                file_attrs = dict(nc.attrs)
+        for attr in ("units", "pol", "model", "resolution", "inc_range", "wspd_range", "phi_range", "inc_step",
+                     "wspd_step", "phi_step"):
+            if attr in file_attrs:
+                v = file_attrs[attr]
+                kwargs[attr] = [float(x) for x in v] if isinstance(v, np.ndarray) else v
         self._short_name = kwargs.pop("model")
         if kwargs["resolution"] == "low":
             kwargs["inc_step_lr"] = kwargs.pop("inc_step")
@@ -261,6 +272,9 @@ class NcLutModel(LutModel):
     def _raw_lut(self, **kwargs):
         if not os.path.isfile(self.path):
             raise FileNotFoundError(self.path)
+        if xr is None:
+            from . import nc_io
+            return nc_io.read_lut(self.path)
         ds = xr.open_dataset(self.path)
         da = ds.sigma0_model
         da.attrs["units"] = ds.attrs["units"]
