@@ -36,6 +36,10 @@ total += run("default LUT, dsig_co 0.4", co, 8000, 20000, 14, dsig_co=0.4)
 total += run("default LUT, ancillary x0.3 (far from sigma0)", co, 8000, 20000, 15, scale_anc=0.3)
 total += run("default LUT, ancillary x2.5", co, 8000, 20000, 16, scale_anc=2.5)
 total += run("default LUT, incidence +12 deg (42..58)", co, 8000, 20000, 17, inc_shift=12.0)
+# low incidences: CMOD5.N turns over at 24..31 m/s there, so many windows cross the end of the monotone rows (band rule not
+# applicable: those pixels take the general kernel through the work list)
+total += run("default LUT, incidence -13 deg (17..33)", co, 8000, 20000, 21, inc_shift=-13.0)
+total += run("default LUT, incidence -13 deg, ancillary x2", co, 8000, 20000, 22, inc_shift=-13.0, scale_anc=2.0)
 low = get_model("gmf_cmod5n")._lut(units="dB", resolution="low"); col = _engine._co_dict(low)
 total += run("low-res LUT", col, 20000, 20000, 18)
 # 0..360 axis (phi_180 False): mirror the default LUT

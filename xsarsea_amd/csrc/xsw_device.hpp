@@ -1066,9 +1066,11 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert_list(
 #ifndef XSW_LIST_PX
 #define XSW_LIST_PX 16
 #endif
-    for (long long c = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); c * XSW_LIST_PX < count; c += nwaves) {  // wave-uniform
-        const long long k = c * XSW_LIST_PX + lane;
-        const bool in = lane < XSW_LIST_PX && k < count;
+    // a long list (a LUT or scene the band rule rarely applies to) fills the waves instead: 64 pixels per wave
+    const int ppw = count >= (long long)XSW_LIST_PX * nwaves ? 64 : XSW_LIST_PX;
+    for (long long c = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); c * ppw < count; c += nwaves) {  // wave-uniform
+        const long long k = c * ppw + lane;
+        const bool in = lane < ppw && k < count;
         const long long i = (long long)A.list[in ? k : count - 1];
         invert_strip<T, TO, 1, CR>(L, A, i, in, lane);
     }
