@@ -122,7 +122,11 @@ int xsw_synchronize(xsw_ctx *ctx);
 int xsw_lut_upload(xsw_ctx *ctx, const xsw_lut *co, const xsw_lut *cr);
 
 /* Replaces _invert_from_model_numpy (windspeed.py:132-331).  Asynchronous on the context's stream
- * when mem == XSW_MEM_DEVICE; synchronous (returns with outputs filled) for host memory. */
+ * when mem == XSW_MEM_DEVICE; synchronous (returns with outputs filled) for host memory.
+ * XSW_ALGO_PRUNED on a LUT whose columns rise monotonically with wind speed (every built-in GMF over most of its rows) runs
+ * as two launches: k_invert_band decides the pixels its band rule can, k_invert_list the rest from a work list owned by
+ * the context (4 bytes per pixel of the largest raster seen); any other LUT, and XSW_ALGO_EXACT, take the general kernel.
+ * Results do not depend on the route (environment variable XSW_NO_BAND=1 forces the general kernel: A/B measurements). */
 int xsw_invert(xsw_ctx *ctx, const xsw_invert_args *args);
 
 /* Enable (1) / disable (0) device-side work counters; read them after synchronising. */
