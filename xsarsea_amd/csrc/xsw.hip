@@ -1080,7 +1080,8 @@ static hipError_t launch_nesz(hipStream_t s, const void *noise, const void *inc,
     hipLaunchKernelGGL((k_nesz_colsum<T>), dim3(gx, (unsigned)nb), dim3(256), 0, s, (const T *)noise, (const T *)inc, part, lines, samples, lpb);
     hipLaunchKernelGGL(k_nesz_colmean, dim3(gx), dim3(256), 0, s, part, col, samples, nb);
     hipLaunchKernelGGL(k_nesz_center, dim3(1), dim3(1024), 0, s, col, x0, samples);
-    hipLaunchKernelGGL((k_nesz_rows<T>), dim3((unsigned)lines), dim3(256), 0, s, (const T *)noise, col, x0, out, samples);
+    hipLaunchKernelGGL((k_nesz_rows<T>), dim3((unsigned)((lines + XSW_NESZ_LINES - 1) / XSW_NESZ_LINES)), dim3(256), 0, s, (const T *)noise, col, x0, out,
+                       lines, samples);
     return hipGetLastError();
 }
 

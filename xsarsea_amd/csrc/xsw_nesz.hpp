@@ -105,57 +105,137 @@ __global__ __launch_bounds__(1024) void k_nesz_center(const double *__restrict__
     }
 }
 
+// log10 / exp10 for the arguments of this kernel (positive normal finite doubles; |t| < 300), ~1e-15 relative: frexp + atanh
+// series, and 2^k * exp(g) with a degree-13 Taylor polynomial.  About 55 float64 instructions for the pair instead of the
+// ~120 of the library calls, which are what bounds k_nesz_rows (one of each per pixel); anything else goes to the library.
+__device__ __forceinline__ double nesz_log10(double v)
+{
+    if (!(v >= 2.2250738585072014e-308 && v <= 1.7976931348623157e308)) return log10(v);  // 0, negative, denormal, inf, NaN
+    int e;
+    double m = frexp(v, &e);  // [0.5, 1)
+    if (m < 0.70710678118654752440) { m *= 2.0; e -= 1; }  // [sqrt(1/2), sqrt(2))
+    // z = (m - 1) / (m + 1) by reciprocal + one Newton step (the IEEE division sequence costs more than the series)
+    const double den = m + 1.0;
+    double rc = __builtin_amdgcn_rcp(den);
+    rc = fma(fma(-den, rc, 1.0), rc, rc);
+    rc = fma(fma(-den, rc, 1.0), rc, rc);
+    const double z = (m - 1.0) * rc, z2 = z * z;  // |z| <= 0.1716
+    double p = 1.0 / 21.0;
+    p = fma(p, z2, 1.0 / 19.0); p = fma(p, z2, 1.0 / 17.0); p = fma(p, z2, 1.0 / 15.0); p = fma(p, z2, 1.0 / 13.0);
+    p = fma(p, z2, 1.0 / 11.0); p = fma(p, z2, 1.0 / 9.0); p = fma(p, z2, 1.0 / 7.0); p = fma(p, z2, 1.0 / 5.0);
+    p = fma(p, z2, 1.0 / 3.0);
+    const double lnm = fma(2.0 * z * z2, p, 2.0 * z);  // ln(m) = 2 atanh(z)
+    // log10(v) = e log10(2) + ln(m) / ln(10), log10(2) split so that e * hi is exact
+    return fma((double)e, 0.30102999566361177, fma((double)e, 3.694239077158931e-13, lnm * 0.4342944819032518));  // hi has 40 bits: e * hi is exact
+}
+__device__ __forceinline__ double nesz_exp10(double t)
+{
+    if (!(fabs(t) < 300.0)) return exp10(t);
+    const double kf = rint(t * 3.321928094887362);  // t log2(10)
+    // g = (t - k log10(2)) ln(10), log10(2) in two parts (k * hi exact for |k| < 2^11)
+    const double r = fma(-kf, 3.694239077158931e-13, fma(-kf, 0.30102999566361177, t));
+    const double g = r * 2.302585092994046;  // |g| <= 0.3466
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, g, 1.0 / 479001600.0); p = fma(p, g, 1.0 / 39916800.0); p = fma(p, g, 1.0 / 3628800.0); p = fma(p, g, 1.0 / 362880.0);
+    p = fma(p, g, 1.0 / 40320.0); p = fma(p, g, 1.0 / 5040.0); p = fma(p, g, 1.0 / 720.0); p = fma(p, g, 1.0 / 120.0);
+    p = fma(p, g, 1.0 / 24.0); p = fma(p, g, 1.0 / 6.0); p = fma(p, g, 0.5); p = fma(p, g, 1.0); p = fma(p, g, 1.0);
+    return ldexp(p, (int)kf);
+}
+
+// XSW_NESZ_LINES lines per workgroup: the column means and abscissae (float64, L2-resident) are read once per sample and
+// serve all of them -- with one line per workgroup they were 24 of the 36 bytes a pixel moved through L1.
+#ifndef XSW_NESZ_LINES
+#define XSW_NESZ_LINES 4
+#endif
 template <typename T>
 __global__ __launch_bounds__(256) void k_nesz_rows(const T *__restrict__ noise, const double *__restrict__ col,
                                                    const double *__restrict__ x0p, double *__restrict__ out,
-                                                   long long samples)
+                                                   long long lines, long long samples)
 {
-    __shared__ double sh[5][4];
-    const long long l = blockIdx.x;
-    const T *row = noise + l * samples;
+    constexpr int R = XSW_NESZ_LINES;
+    __shared__ double sh[5][4][R];
+    const long long l0 = (long long)blockIdx.x * R;
     const double *mean = col, *xs = col + samples;
     const double x0 = *x0p;
-    double n = 0.0, sx = 0.0, sy = 0.0, sxx = 0.0, sxy = 0.0;
-    for (long long s = threadIdx.x; s < samples; s += blockDim.x) {
-        double v = (double)row[s];
-        if (v != v) v = mean[s];
-        const double y = 10.0 * log10(v);  // NaN for v < 0 or NaN, -inf for 0: dropped like the reference's isfinite mask
-        const double x = xs[s] - x0;
+    const T *row[R];
+    bool live[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) { live[j] = l0 + j < lines; row[j] = noise + (live[j] ? l0 + j : l0) * samples; }
+    double n[R], sx[R], sy[R], sxx[R], sxy[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) n[j] = sx[j] = sy[j] = sxx[j] = sxy[j] = 0.0;
+    auto take = [&](int j, double v, double m, double x) {
+        if (v != v) v = m;
+        const double y = 10.0 * nesz_log10(v);  // NaN for v < 0 or NaN, -inf for 0: dropped like the reference's isfinite mask
         // polyfit sees x[ok]: a NaN abscissa (column without valid incidence) poisons the fit there; here too
-        if (isfinite(y)) { n += 1.0; sx += x; sy += y; sxx += x * x; sxy += x * y; }
-    }
-    n = wave_sum_d(n); sx = wave_sum_d(sx); sy = wave_sum_d(sy); sxx = wave_sum_d(sxx); sxy = wave_sum_d(sxy);
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { sh[0][w] = n; sh[1][w] = sx; sh[2][w] = sy; sh[3][w] = sxx; sh[4][w] = sxy; }
-    __syncthreads();
-    n = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
-    sx = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
-    sy = sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3];
-    sxx = sh[3][0] + sh[3][1] + sh[3][2] + sh[3][3];
-    sxy = sh[4][0] + sh[4][1] + sh[4][2] + sh[4][3];
-    const double nan = __builtin_nan("");
-    double slope, icpt;  // in the uncentred abscissa: y = slope * x_raw + icpt
-    if (n == 0.0) {  // nothing to fit: the reference returns a NaN line (utils.py:146-149)
-        slope = nan; icpt = nan;
-    } else {
-        const double det = n * sxx - sx * sx;  // n^2 var(x) >= 0
-        const double xm = sx / n, ym = sy / n;
-        if (det > 1e-24 * (n * sxx + sx * sx + 1e-300)) {
-            slope = (n * sxy - sx * sy) / det;
-            icpt = ym - slope * (xm + x0);
-        } else {
-            // every fitted abscissa equal (one valid sample, or constant incidence): numpy's lstsq returns the
-            // minimum-norm solution of the column-scaled rank-1 system, slope = y/(2x), intercept = y/2
-            const double xr = xm + x0;
-            slope = ym / (2.0 * xr);
-            icpt = 0.5 * ym;
+        if (isfinite(y)) { n[j] += 1.0; sx[j] += x; sy[j] += y; sxx[j] += x * x; sxy[j] += x * y; }
+    };
+    // two samples per lane and trip (adjacent: 8/16-byte accesses when the line is aligned), R lines each, then the tail
+    const long long pairs = samples >> 1;
+    const bool al = ((samples * sizeof(T)) & (sizeof(T) * 2 - 1)) == 0 && (((size_t)noise) & (sizeof(T) * 2 - 1)) == 0 && (samples & 1) == 0;
+    for (long long q = threadIdx.x; q < pairs; q += blockDim.x) {
+        const long long s = q * 2;
+        const double m0 = mean[s], m1 = mean[s + 1], x0s = xs[s] - x0, x1s = xs[s + 1] - x0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            T v0, v1;
+            if (al) { typedef T v2 __attribute__((ext_vector_type(2))); const v2 t = *(const v2 *)(row[j] + s); v0 = t.x; v1 = t.y; }
+            else { v0 = row[j][s]; v1 = row[j][s + 1]; }
+            take(j, (double)v0, m0, x0s);
+            take(j, (double)v1, m1, x1s);
         }
     }
-    double *o = out + l * samples;
-    for (long long s = threadIdx.x; s < samples; s += blockDim.x) {
-        const double t = (xs[s] * slope + icpt - 1.0) / 10.0;
-        o[s] = exp10(t);
+    for (long long s = pairs * 2 + threadIdx.x; s < samples; s += blockDim.x)
+#pragma unroll
+        for (int j = 0; j < R; ++j) take(j, (double)row[j][s], mean[s], xs[s] - x0);
+    const int w = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        n[j] = wave_sum_d(n[j]); sx[j] = wave_sum_d(sx[j]); sy[j] = wave_sum_d(sy[j]); sxx[j] = wave_sum_d(sxx[j]); sxy[j] = wave_sum_d(sxy[j]);
+        if ((threadIdx.x & 63) == 0) { sh[0][w][j] = n[j]; sh[1][w][j] = sx[j]; sh[2][w][j] = sy[j]; sh[3][w][j] = sxx[j]; sh[4][w][j] = sxy[j]; }
     }
+    __syncthreads();
+    const double nan = __builtin_nan("");
+    double slope[R], icpt[R];  // in the uncentred abscissa: y = slope * x_raw + icpt
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const double nn = sh[0][0][j] + sh[0][1][j] + sh[0][2][j] + sh[0][3][j];
+        const double ssx = sh[1][0][j] + sh[1][1][j] + sh[1][2][j] + sh[1][3][j];
+        const double ssy = sh[2][0][j] + sh[2][1][j] + sh[2][2][j] + sh[2][3][j];
+        const double ssxx = sh[3][0][j] + sh[3][1][j] + sh[3][2][j] + sh[3][3][j];
+        const double ssxy = sh[4][0][j] + sh[4][1][j] + sh[4][2][j] + sh[4][3][j];
+        if (nn == 0.0) {  // nothing to fit: the reference returns a NaN line (utils.py:146-149)
+            slope[j] = nan; icpt[j] = nan;
+        } else {
+            const double det = nn * ssxx - ssx * ssx;  // n^2 var(x) >= 0
+            const double xm = ssx / nn, ym = ssy / nn;
+            if (det > 1e-24 * (nn * ssxx + ssx * ssx + 1e-300)) {
+                slope[j] = (nn * ssxy - ssx * ssy) / det;
+                icpt[j] = ym - slope[j] * (xm + x0);
+            } else {
+                // every fitted abscissa equal (one valid sample, or constant incidence): numpy's lstsq returns the
+                // minimum-norm solution of the column-scaled rank-1 system, slope = y/(2x), intercept = y/2
+                slope[j] = ym / (2.0 * (xm + x0));
+                icpt[j] = 0.5 * ym;
+            }
+        }
+    }
+    for (long long q = threadIdx.x; q < pairs; q += blockDim.x) {
+        const long long s = q * 2;
+        const double xa = xs[s], xb = xs[s + 1];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            if (!live[j]) continue;
+            double *o = out + (l0 + j) * samples + s;
+            const double ra = nesz_exp10((xa * slope[j] + icpt[j] - 1.0) * 0.1), rb = nesz_exp10((xb * slope[j] + icpt[j] - 1.0) * 0.1);
+            if ((((size_t)o) & 15) == 0) { double2 t; t.x = ra; t.y = rb; *(double2 *)o = t; }
+            else { o[0] = ra; o[1] = rb; }
+        }
+    }
+    for (long long s = pairs * 2 + threadIdx.x; s < samples; s += blockDim.x)
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            if (live[j]) out[(l0 + j) * samples + s] = nesz_exp10((xs[s] * slope[j] + icpt[j] - 1.0) * 0.1);
 }
 
 }  // namespace xsw
