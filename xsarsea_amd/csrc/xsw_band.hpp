@@ -58,6 +58,7 @@ struct BandSlot {  // 64 bytes per pixel, read by every lane of its segment (sam
     int i_inc, rows /* w_lo | w_hi << 16 */, ip_lo, ncols;
 };
 
+__device__ __forceinline__ unsigned long long ballot64(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 __device__ __forceinline__ double ld_co(const char *__restrict__ base, unsigned off0, int row, unsigned rowB)
 {
     return *(const double *)(base + (off0 + __umul24((unsigned)row, rowB)));
@@ -75,7 +76,7 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pend >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pend, 0u));
     const bool take = is_p && rank < NP;
     if (take) map[rank] = lane;
-    const unsigned long long taken = __ballot(take);
+    const unsigned long long taken = ballot64(take);
     const int nvalid = __popcll(taken);
     pend &= ~taken;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -93,7 +94,7 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
     const unsigned rowB = (unsigned)L.phi_pad * 8u;
     const unsigned slice0 = (unsigned)(B.i_inc * L.n_w) * rowB;
     double best = inf, second = inf;
-    int bflat = 0;
+    int brow = 0, bip = 0;
     unsigned ncand = 0;
     bool overflow = false;
     const int nchunks = S == 64 ? (__builtin_amdgcn_readfirstlane(B.ncols) + 64 * K - 1) / (64 * K) : 1;  // S == 64: one pixel, wave-uniform
@@ -133,7 +134,7 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
                 const bool down = act[j] && rr > w_lo && a >= thr_lo;
                 const bool up = act[j] && !down && rr <= w_hi && b < thr_lo;
                 rr += (up ? 1 : 0) - (down ? 1 : 0);
-                if (__ballot(up || down) == 0ULL) break;
+                if (ballot64(up || down) == 0ULL) break;
                 if (it >= XSW_BAND_WALK_MAX) { overflow = overflow || up || down; break; }
             }
             r[j] = rr;
@@ -142,8 +143,8 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
 #pragma unroll
         for (int j = 0; j < K; ++j) { more[j] = act[j] && r[j] <= w_hi; any = any || more[j]; }
 #pragma unroll 1
-        for (int t = 0; __ballot(any) != 0ULL; ++t) {
-            if (t >= XSW_BAND_MAX) { overflow = overflow || any; break; }
+        for (int t = 0; t < XSW_BAND_MAX; ++t) {  // scalar trip counter; the loop leaves as soon as no lane has rows left
+            if (ballot64(any) == 0ULL) break;
             any = false;
 #pragma unroll
             for (int j = 0; j < K; ++j) {
@@ -155,7 +156,9 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
                 double J = fma(dd, dd, wh * (wh - U[j]));
                 J = inb ? J : inf;
                 second = vmin(second, vmax(J, best));
-                bflat = J < best ? (int)__umul24((unsigned)rc, (unsigned)L.n_phi) + ip[j] : bflat;
+                const bool lt = J < best;
+                brow = lt ? rc : brow;
+                if (K > 1 || S == 64) bip = lt ? ip[j] : bip;  // S == 64: the best may sit in an earlier chunk
                 best = vmin(best, J);
                 if (COUNT) ncand += inb ? 1u : 0u;
                 r[j] += 1;
@@ -163,10 +166,13 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
                 any = any || more[j];
             }
         }
+        overflow = overflow || any;  // rows left after XSW_BAND_MAX trips
+        if (K == 1 && S != 64) bip = ip[0];
     }
+    const int bflat = (int)__umul24((unsigned)brow, (unsigned)L.n_phi) + bip;
     const double gmin = S == 64 ? wave_min_d(best) : seg_min_d<S>(best);
     const double T = gmin + 1e-9 * (1.0 + fabs(gmin) + slots[owner].m2);  // re-read: not kept live through the sweep
-    const unsigned long long amb = __ballot(valid && (second <= T || overflow)), surv = __ballot(valid && best <= T);
+    const unsigned long long amb = ballot64(valid && (second <= T || overflow)), surv = ballot64(valid && best <= T);
     const unsigned long long segmask = S == 64 ? ~0ULL : (((1ULL << (S & 63)) - 1ULL) << ((q * S) & 63));
     const bool bad = (amb & segmask) != 0ULL || __popcll(surv & segmask) != 1 || !(gmin < 1e300);
     if (valid && ((!bad && best <= T) || (bad && sl == 0))) res[q] = bad ? -1 : bflat;

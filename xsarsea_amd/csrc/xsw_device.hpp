@@ -94,6 +94,9 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_d(double v)
 {
     const int lo = __double2loint(v), hi = __double2hiint(v);
+    if (ROW_MASK == 0xF)  // every lane is written (quad_perm / mirrors always have a source): no `old` operand to set up
+        return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true),
+                                __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true));
     return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false),
                             __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false));
 }
