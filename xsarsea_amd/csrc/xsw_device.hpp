@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert_list(
 #define XSW_LIST_PX 16
 #endif
     // a long list (a LUT or scene the band rule rarely applies to) fills the waves instead: 64 pixels per wave
-    const int ppw = count >= (long long)XSW_LIST_PX * nwaves ? 64 : XSW_LIST_PX;
+    const int ppw = count >= 64LL * nwaves ? 64 : XSW_LIST_PX;  // measured at 2.3e5 pixels: 16 per wave 2.6 ms, 64 per wave 3.5 ms
     for (long long c = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); c * ppw < count; c += nwaves) {  // wave-uniform
         const long long k = c * ppw + lane;
         const bool in = lane < ppw && k < count;
