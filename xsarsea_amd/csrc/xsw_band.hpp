@@ -239,12 +239,24 @@ __global__ __launch_bounds__(256, XSW_BAND_WAVES) void k_invert_band(DevTables L
             if (COUNT) cand += (unsigned)__popcll(__ballot(eligb)) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)) + (XSW_BAND_RAYS - 1) * 2 * XSW_RAY_SIDE_STEPS);
         }
         constexpr int BK = XSW_BAND_K;
+        // class of a window: widths (1..2, 3..4, 5..8, 9..16, 17..32, more) * K directions.  The bisection trip count of a
+        // class is the largest bit length of its windows' heights: one OR-reduction of thermometer codes (16 bits per class,
+        // two classes per dword) instead of six max-reductions
+        const int wq = (ncols_p + BK - 1) / BK;
+        const int myc = !eligb ? 6 : (wq <= 2 ? 0 : min(31 - __clz(wq - 1), 5));
+        unsigned th[3] = {0u, 0u, 0u};
+        if (eligb) th[myc >> 1] = ((1u << bits) - 1u) << (16 * (myc & 1));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) th[k] |= (unsigned)__shfl_xor((int)th[k], off);
+        }
         unsigned long long seen = 0;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            cls[c] = (c < 5 ? __ballot(eligb && ncols_p <= (2 << c) * BK) : __ballot(eligb)) & ~seen;
+            cls[c] = __ballot(myc == c);
             seen |= cls[c];
-            ns[c] = cls[c] ? wave_max_i(((cls[c] >> lane) & 1ULL) ? bits : 0) : 0;
+            ns[c] = __popc((__builtin_amdgcn_readfirstlane((int)th[c >> 1]) >> (16 * (c & 1))) & 0xffff);
         }
         seen_all = seen;
     }
