@@ -166,6 +166,50 @@ def test_bit_exact_vs_numpy_oracle(gpu_ctx, default_luts):
     assert bits_equal(got[1], o[1]), "dual complex128 output is not bit-identical"
 
 
+def test_sign_choice_and_dual_select_near_ties(gpu_ctx, default_luts):
+    """The +phi / -phi choice (windspeed.py:234-242) is decided on the device by the sign of Im(anc) * sin(phi) away from
+    ties and by the emulated complex division + angle next to them; the dual select (windspeed.py:426-428) by wspd_dual
+    away from 5 m/s and the emulated hypot next to it.  Pixels built ON those ties: Im(anc) = 0, -0, +-1e-300 ... +-1e-3,
+    solutions at phi = 0, 1, 179, 180 deg, wspd_dual = 4.9 / 5.0 / 5.1.  All kernels, bit-identical to the numpy oracle."""
+    from oracle import gmf
+    from oracle import invert as oinv
+    lco, lcr = default_luts
+    co, cr = lut_dicts(lco, lcr)
+    gpu_ctx.upload_luts(co=co, cr=cr)
+    phis = [0.0, 0.3, 1.0, 37.0, 90.0, 179.0, 179.7, 180.0]
+    ims = [0.0, -0.0, 1e-300, -1e-300, 1e-17, -1e-17, 1e-10, -1e-10, 1e-8, -1e-8, 1e-3, -1e-3, None, "neg"]
+    wds = [4.9, 5.0, 5.1, 12.0]
+    rows = []
+    for w in (2.0, 4.9, 8.0):
+        for ph in phis:
+            for im in ims:
+                for wd in wds:
+                    a_im = w * np.sin(np.radians(ph)) * (1 if im is None else -1) if im in (None, "neg") else im
+                    rows.append((35.0, w, ph, w * np.cos(np.radians(ph)), a_im, wd))
+    r = np.array(rows)
+    inc = r[:, 0].reshape(1, -1).copy()
+    s_vv = gmf.gmf_cmod5n(inc, r[:, 1].reshape(1, -1), r[:, 2].reshape(1, -1))
+    s_vh = gmf.GMFS["gmf_s1_v2"][0](inc, r[:, 5].reshape(1, -1))
+    anc = (r[:, 3] + 1j * r[:, 4]).reshape(1, -1)
+    dsig = np.full(inc.shape, 0.01)
+    o = oracle_full(inc, s_vv, s_vh, dsig, anc, lco, lcr, fast_c=False)
+    sel = np.where((np.abs(o[0]) < 5) | (np.abs(o[1]) < 5), o[0], o[1])  # windspeed.py:426-428
+    assert np.sum(np.abs(o[1]) < 5) > 50 and np.sum(np.abs(o[1]) >= 5) > 50
+    assert len(np.unique(o[2][..., 2])) >= 3
+    for algo in ALGOS_ALL:
+        got = gpu_ctx.invert_host(inc, sigma0_co=oinv.to_db(s_vv), sigma0_cr=oinv.to_db(s_vh), dsig_cr=dsig, anc=anc,
+                                  sigma0_is_db=True, algo=algo, want_idx=True)
+        assert np.array_equal(got[2], o[2]), algo
+        assert bits_equal(got[0], o[0]), f"{algo}: co-pol sign choice"
+        assert bits_equal(got[1], o[1]), f"{algo}: dual"
+        got = gpu_ctx.invert_host(inc, sigma0_co=oinv.to_db(s_vv), sigma0_cr=oinv.to_db(s_vh), dsig_cr=dsig, anc=anc,
+                                  sigma0_is_db=True, algo=algo, dual_select=True)
+        assert bits_equal(got[1], sel), f"{algo}: dual select"
+    # mono route (the two-kernel path's CR = false instantiation)
+    got = gpu_ctx.invert_host(inc, sigma0_co=oinv.to_db(s_vv), anc=anc, sigma0_is_db=True, algo="pruned")
+    assert bits_equal(got[0], o[0])
+
+
 def test_u10_v10_tolerance(gpu_ctx, default_luts):
     """north_star: (u10, v10) = (Re, Im) within 1e-4 relative of the CPU path, complex64 outputs."""
     lco, lcr = default_luts

@@ -376,6 +376,11 @@ static int install_co(xsw_ctx *c, const xsw_lut *l, const double *d_dense)
     T.phi_last = l->phi[nP - 1];
     T.inv_wstep = nW > 1 ? (nW - 1) / (l->wspd[nW - 1] - l->wspd[0]) : 0.0;
     T.inv_dphi = nP > 1 ? (nP - 1) / (l->phi[nP - 1] - l->phi[0]) : 0.0;
+    T.wstep_half = 0.5 / T.inv_wstep;  // the kernels' (w/2)-per-row step: same IEEE quotient they used to form per wave
+    T.inv_nphi = 1.0 / (double)nP;
+    T.inc_uniform = uniform_axis(l->inc, nI) && nI >= 2 ? 1 : 0;
+    T.inc0 = l->inc[0];
+    T.inv_incstep = nI > 1 ? (nI - 1) / (l->inc[nI - 1] - l->inc[0]) : 0.0;
     T.prunable = (nW >= 2 && nP >= 2 && nW < 32768 && nP < 65536 && (int64_t)nW * ppad < ((int64_t)1 << 30) && uniform_axis(l->wspd, nW) && uniform_axis(l->phi, nP) && trig_ok &&
                   (l->phi[nP - 1] - l->phi[0]) <= 360.0 + 1e-9 && lut_finite)
                      ? 1 : 0;
@@ -421,6 +426,10 @@ static int upload_cr(xsw_ctx *c, const xsw_lut *l)
     T.cr_monotone = mono ? 1 : 0;
     T.wcr0 = l->wspd[0];
     T.inv_wcrstep = nW > 1 ? (nW - 1) / (l->wspd[nW - 1] - l->wspd[0]) : 0.0;
+    T.wcrstep_half = 0.5 / T.inv_wcrstep;
+    T.inc_cr_uniform = uniform_axis(l->inc, nI) && nI >= 2 ? 1 : 0;
+    T.inc_cr0 = l->inc[0];
+    T.inv_inccrstep = nI > 1 ? (nI - 1) / (l->inc[nI - 1] - l->inc[0]) : 0.0;
     c->have_cr = true;
     return XSW_OK;
 }
@@ -469,7 +478,6 @@ static int launch_invert(xsw_ctx *c, const KArgs &A, int algo)
         (!A.s_cr || c->T.cr_monotone) && A.n < (1LL << 32)) {
         if ((size_t)A.n > c->list_cap) {
             if (c->d_list) (void)hipFree(c->d_list);
-    for (hipEvent_t e : c->timing_events) (void)hipEventDestroy(e);
             c->d_list = nullptr;
             c->list_cap = 0;
             if (hipMalloc((void **)&c->d_list, ((size_t)A.n + 16) * sizeof(unsigned)) != hipSuccess)
@@ -481,19 +489,23 @@ static int launch_invert(xsw_ctx *c, const KArgs &A, int algo)
         B.list = c->d_list + 16;
         HIPCHK(c, hipMemsetAsync(c->d_list, 0, sizeof(unsigned), c->stream));
         const unsigned list_blocks = (unsigned)std::min<long long>(nblocks, 256 * 8);  // 8 waves per SIMD
+        // k_invert_band: x = XCD lane + 8 * line group, y = tile column inside the XCD's range (see the kernel)
+        const long long cols_per_xcd = (strips_per_line + 7) / 8;
+        if (8 * line_groups > 0x7fffffffLL || cols_per_xcd > 65535) return fail(c, XSW_EINVAL, "raster too large for one launch");
+        const dim3 band_grid((unsigned)(8 * line_groups), (unsigned)cols_per_xcd);
         timing_mark(c);
         if (A.stats) {  // statistics instantiation (counts the scored candidates)
-            if (!A.s_cr && !A.out_cr) hipLaunchKernelGGL((k_invert_band<T, TO, false, true>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, B);
-            else hipLaunchKernelGGL((k_invert_band<T, TO, true, true>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, B);
+            if (!A.s_cr && !A.out_cr) hipLaunchKernelGGL((k_invert_band<T, TO, false, true>), band_grid, dim3(256), 0, c->stream, c->T, B);
+            else hipLaunchKernelGGL((k_invert_band<T, TO, true, true>), band_grid, dim3(256), 0, c->stream, c->T, B);
             timing_mark(c);
             if (!A.s_cr && !A.out_cr) hipLaunchKernelGGL((k_invert_list<T, TO, false>), dim3(list_blocks), dim3(256), 0, c->stream, c->T, B);
             else hipLaunchKernelGGL((k_invert_list<T, TO, true>), dim3(list_blocks), dim3(256), 0, c->stream, c->T, B);
         } else if (!A.s_cr && !A.out_cr) {
-            hipLaunchKernelGGL((k_invert_band<T, TO, false, false>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, B);
+            hipLaunchKernelGGL((k_invert_band<T, TO, false, false>), band_grid, dim3(256), 0, c->stream, c->T, B);
             timing_mark(c);
             hipLaunchKernelGGL((k_invert_list<T, TO, false>), dim3(list_blocks), dim3(256), 0, c->stream, c->T, B);
         } else {
-            hipLaunchKernelGGL((k_invert_band<T, TO, true, false>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, B);
+            hipLaunchKernelGGL((k_invert_band<T, TO, true, false>), band_grid, dim3(256), 0, c->stream, c->T, B);
             timing_mark(c);
             hipLaunchKernelGGL((k_invert_list<T, TO, true>), dim3(list_blocks), dim3(256), 0, c->stream, c->T, B);
         }

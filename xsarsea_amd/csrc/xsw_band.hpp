@@ -89,7 +89,7 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
     if (!valid) { B.i_inc = 0; B.rows = 0; B.ip_lo = 0; B.ncols = 0; }  // idle segment: harmless addresses, nothing scored
     const int w_lo = B.rows & 0xffff, w_hi = B.rows >> 16;
     const double thr_lo = B.thr_lo, thr_hi = B.thr_hi, sn = B.sn;
-    const double wh0 = 0.5 * L.w0, whs = 0.5 / L.inv_wstep;
+    const double wh0 = 0.5 * L.w0, whs = L.wstep_half;
     const char *__restrict__ base = (const char *)L.co;
     const unsigned rowB = (unsigned)L.phi_pad * 8u;
     const unsigned slice0 = (unsigned)(B.i_inc * L.n_w) * rowB;
@@ -196,13 +196,15 @@ __global__ __launch_bounds__(256, XSW_BAND_WAVES) void k_invert_band(DevTables L
     __shared__ BandSlot slots[4][64];  // search parameters of the wave's 64 pixels
     __shared__ int map_[4][32];        // pass: segment -> owner lane
     __shared__ int res_[4][32];        // pass: segment -> winning flat index (or -1)
-    // same tile walk as k_invert (XCD x owns a contiguous range of tile columns, line groups fastest)
-    const long long strips_per_line = (A.samples + 63) >> 6, line_groups = (A.lines + 3) >> 2;
+    // same tile walk as k_invert (XCD x owns a contiguous range of tile columns, line groups fastest), as a 2-D grid so that
+    // no division is needed: blockIdx.x = xcd + 8 * line group, blockIdx.y = tile column inside the XCD's range (workgroups
+    // are dealt to the XCDs round-robin in linear order, x fastest: the XCD of a workgroup is still blockIdx.x & 7)
+    const long long strips_per_line = (A.samples + 63) >> 6;
     const long long cols_per_xcd = (strips_per_line + 7) >> 3;
-    const long long xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const long long col = xcd * cols_per_xcd + jb / line_groups;
-    const long long line = (jb % line_groups) * 4 + wv;
-    if (jb / line_groups >= cols_per_xcd || col >= strips_per_line || line >= A.lines) return;  // wave-uniform
+    const long long xcd = blockIdx.x & 7;
+    const long long col = xcd * cols_per_xcd + blockIdx.y;
+    const long long line = (long long)(blockIdx.x >> 3) * 4 + wv;
+    if (col >= strips_per_line || line >= A.lines) return;  // wave-uniform
     const long long smp = col * 64 + lane;
     const bool in = smp < A.samples;
     const long long i = line * A.samples + (in ? smp : A.samples - 1);
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256, XSW_BAND_WAVES) void k_invert_band(DevTables L
         int ncols_p = 0, bits = 0;
         if (todo) {
             bool loose = false;
-            const CoWindow W = co_window_lanes<XSW_BAND_RAYS, XSW_BAND_RAY_D>(L, P, A.inv_dsig_co, loose);
+            const CoWindow W = co_window_lanes<XSW_BAND_RAYS, XSW_BAND_RAY_D>(L, P, A.inv_dsig_co, fabs(A.dsig_co), loose);
             const int nrows_p = W.w_hi - W.w_lo + 1;
             ncols_p = W.ip_hi - W.ip_lo + 1;
             const bool need = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0 && !loose && ncols_p >= 1 && nrows_p >= 1;
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(256, XSW_BAND_WAVES) void k_invert_band(DevTables L
         const double dsig = A.dsig_cr ? (double)((const T *)A.dsig_cr)[i] : (double)(T)(x * (T)0 + (T)A.dsig_cr_scalar);
         need_cr = in && !(flags & F_EARLY_NAN) && s_cr == s_cr && dsig == dsig;
         const bool here = need_cr && !unresolved;
-        const int i_inc_cr = here ? nearest_index(L.inc_cr, L.n_inc_cr, inc) : 0;
+        const int i_inc_cr = here ? nearest_index(L.inc_cr, L.n_inc_cr, inc, L.inc_cr_uniform != 0, L.inc_cr0, L.inv_inccrstep) : 0;
         const double aco = (here && need_co) ? L.abs_co[my_flat] : nan;  // np.abs(wind_co), table [n_w][n_phi]
         bool undecided = here;
         const bool done = search_cr_interval(L, here, i_inc_cr, s_cr, dsig, need_co, aco, my_icr, undecided);

@@ -42,12 +42,18 @@ struct DevTables {
     int co_off32;  // the padded co table is < 4 GB: 32-bit byte offsets from its base address every word
     const int *mono_rows;  // [n_inc] every column of slice i is non-decreasing in wind speed over rows [0, mono_rows[i]) (band pruning)
     double w0, inv_wstep, phi0, phi_last, inv_dphi;
+    double wstep_half;  // 0.5 / inv_wstep (host: one IEEE division instead of one per wave and pass)
+    double inv_nphi;    // 1 / n_phi: flat index -> (row, direction) without an integer division
+    int inc_uniform;    // incidence axis uniform (xsw.hip uniform_axis): nearest_index starts from the computed bin
+    double inc0, inv_incstep;
     // cross-pol LUT, dB
     const double *cr;    // [n_inc_cr][wcr_pad]
     const double *inc_cr, *wcr, *wcrh;
     int n_inc_cr, n_wcr, wcr_pad, cr_finite;
     int cr_monotone;   // every row non-decreasing in wind speed and the speed axis uniform: interval pruning allowed
-    double wcr0, inv_wcrstep;
+    double wcr0, inv_wcrstep, wcrstep_half;
+    int inc_cr_uniform;
+    double inc_cr0, inv_inccrstep;
 };
 
 struct KArgs {
@@ -167,11 +173,13 @@ __device__ __forceinline__ int wave_min_i(int v)
 // ------------------------------------------------------------------------------------------------
 // sigma0 -> dB exactly as invert_from_model does on the host (windspeed.py:126-130): the arithmetic
 // runs in the raster's dtype; log10 itself is evaluated in float64 and rounded once.
+__device__ __forceinline__ double log10_fast(double v);
 __device__ __forceinline__ double to_db(float x, int is_db)
 {
     if (is_db) return (double)x;
     float y = x + 1e-15f;
-    float l = (float)log10((double)y);
+    // float32 log10 rounded from a float64 one good to ~1e-15: the correctly rounded value but for ~2e-8 of the arguments
+    float l = (float)log10_fast((double)y);
     return (double)(10.0f * l);
 }
 __device__ __forceinline__ double to_db(double x, int is_db)
@@ -181,10 +189,26 @@ __device__ __forceinline__ double to_db(double x, int is_db)
 }
 
 // np.argmin(np.abs(dim - x)) for a strictly ascending axis (windspeed.py:212, :254): first minimum.
-__device__ __forceinline__ int nearest_index(const double *__restrict__ dim, int n, double x)
+// `uniform` (host: the axis is uniform to 1e-12): the lower bound is looked for from the computed bin (a step or two, two
+// loads in flight) instead of by a bisection of dependent loads; the invariant  dim[lo-1] < x <= dim[lo]  is what decides either way.
+__device__ __forceinline__ int nearest_index(const double *__restrict__ dim, int n, double x, bool uniform = false, double x0 = 0.0,
+                                             double inv_step = 0.0)
 {
     if (isinf(x)) return 0;  // every |dim - x| is inf: argmin returns 0
     int lo = 0, hi = n;
+    if (uniform) {
+        const double g = fmin(fmax((x - x0) * inv_step, -1.0), (double)n);  // NaN -> -1 (callers never pass one)
+        int k = min(max((int)ceil(g), 0), n);
+        bool ok = false;
+#pragma unroll 1
+        for (int it = 0; it < 4 && !ok; ++it) {
+            const double below = dim[max(k - 1, 0)], here = dim[min(k, n - 1)];
+            const bool down = k > 0 && !(below < x), up = k < n && here < x;
+            k += (up ? 1 : 0) - (down ? 1 : 0);
+            ok = !up && !down;
+        }
+        if (ok) lo = hi = k;  // else: not where the arithmetic said (cannot happen on a uniform axis): bisect
+    }
     while (lo < hi) {
         int mid = (lo + hi) >> 1;
         if (dim[mid] < x) lo = mid + 1; else hi = mid;
@@ -193,6 +217,28 @@ __device__ __forceinline__ int nearest_index(const double *__restrict__ dim, int
     if (lo == n) return n - 1;
     double dl = fabs(dim[lo - 1] - x), dh = fabs(dim[lo] - x);
     return (dh < dl) ? lo : lo - 1;
+}
+
+// log10 of a positive normal finite double to ~1e-15 relative (frexp + atanh series, reciprocal + Newton instead of the
+// IEEE division): a third of the instructions of the library call; anything else goes to the library.
+__device__ __forceinline__ double log10_fast(double v)
+{
+    if (!(v >= 2.2250738585072014e-308 && v <= 1.7976931348623157e308)) return log10(v);  // 0, negative, denormal, inf, NaN
+    int e;
+    double m = frexp(v, &e);  // [0.5, 1)
+    if (m < 0.70710678118654752440) { m *= 2.0; e -= 1; }  // [sqrt(1/2), sqrt(2))
+    const double den = m + 1.0;
+    double rc = __builtin_amdgcn_rcp(den);
+    rc = fma(fma(-den, rc, 1.0), rc, rc);
+    rc = fma(fma(-den, rc, 1.0), rc, rc);
+    const double z = (m - 1.0) * rc, z2 = z * z;  // |z| <= 0.1716
+    double p = 1.0 / 21.0;
+    p = fma(p, z2, 1.0 / 19.0); p = fma(p, z2, 1.0 / 17.0); p = fma(p, z2, 1.0 / 15.0); p = fma(p, z2, 1.0 / 13.0);
+    p = fma(p, z2, 1.0 / 11.0); p = fma(p, z2, 1.0 / 9.0); p = fma(p, z2, 1.0 / 7.0); p = fma(p, z2, 1.0 / 5.0);
+    p = fma(p, z2, 1.0 / 3.0);
+    const double lnm = fma(2.0 * z * z2, p, 2.0 * z);  // ln(m) = 2 atanh(z)
+    // log10(v) = e log10(2) + ln(m) / ln(10), log10(2) split so that e * hi is exact (hi has 40 bits)
+    return fma((double)e, 0.30102999566361177, fma((double)e, 3.694239077158931e-13, lnm * 0.4342944819032518));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -360,14 +406,14 @@ __device__ __forceinline__ CoWindow box_from_jub(const DevTables &L, double mag,
 #define XSW_RAY_SIDE_STEPS 3
 #endif
 template <int NRAYS = 1, int RAY_D = 2>
-__device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pixel &P, double inv_dsig, bool &loose)
+__device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pixel &P, double inv_dsig, double abs_dsig, bool &loose)
 {
     const double inf = __builtin_inf();
     const bool fin = (P.flags & F_CO_FINITE) != 0;
     const double a = fin ? P.a_re : 0.0, b = fin ? P.b_eff : 0.0, s = fin ? P.s_co : 0.0;
     const double mag = fin ? P.mag : 0.0, theta = fin ? P.theta : 0.0;
     const double ah = 0.5 * a, bh = 0.5 * b, m2 = ah * ah + bh * bh, sn = -s * inv_dsig;
-    const double wh0 = 0.5 * L.w0, whs = 0.5 / L.inv_wstep;
+    const double wh0 = 0.5 * L.w0, whs = L.wstep_half;
     // J along a ray is (nearly always) unimodal: a convex wind term plus the squared distance of a monotone
     // LUT column to the observed sigma0.  Bisect on the sign of its discrete slope, J(2k+1) - J(2k), over aligned
     // row pairs (one 16-byte load per step); every score seen on the way bounds the minimum from above, so a
@@ -404,7 +450,7 @@ __device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pi
     CoWindow W = box_from_jub(L, mag, theta, jub);
     // the sigma0 term alone is >= 0 as well: ((LUT - s)/dsig)^2 <= J_ub is necessary, i.e. |LUT - s| <= |dsig| sqrt(J_ub)
     // (inflated: a candidate outside scores > J_ub (1 + 1e-9), above the exact score of the ray's best candidate)
-    W.band_d = sqrt(jub) * (1.0 + 1e-9) / fabs(inv_dsig) + 1e-12;
+    W.band_d = sqrt(jub) * (1.0 + 1e-9) * abs_dsig + 1e-12;  // abs_dsig = |dsig_co| = 1 / |inv_dsig| to an ulp, far inside the inflation
     return W;
 }
 
@@ -431,7 +477,7 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
 {
     const double inf = __builtin_inf(), BIG = 1e300;
     const double ah = 0.5 * a, bh = 0.5 * b, m2 = ah * ah + bh * bh, sn = -s * inv_dsig;
-    const double wh0 = 0.5 * L.w0, whs = 0.5 / L.inv_wstep;
+    const double wh0 = 0.5 * L.w0, whs = L.wstep_half;
     const int nrows = w_hi - w_lo + 1, ncols = ip_hi - ip_lo + 1;
     // nrows/ncols <= 0 cannot happen in exact arithmetic (stay safe).  More than XSW_MAX_FD_TRIPS trips: the forward
     // differences would accumulate too much rounding error (see co_window_lanes) -> exact full scan.
@@ -564,7 +610,7 @@ __device__ __forceinline__ void co_seg_pass(const DevTables &L, const Pixel &P, 
     const int ncols = __shfl(W.ip_hi - W.ip_lo + 1, src), geom = __shfl(W.geom, src), mdiv = __shfl(W.mdiv, src);
 
     const double ah = 0.5 * a, bh = 0.5 * b, m2 = ah * ah + bh * bh, sn = -s * inv_dsig;
-    const double wh0 = 0.5 * L.w0, whs = 0.5 / L.inv_wstep;
+    const double wh0 = 0.5 * L.w0, whs = L.wstep_half;
     const int G = geom & 0xff;
     const int grp = (sl * mdiv) >> 16, col = sl - grp * ncols;
     const int rows_pass = t_max * 2 * G;
@@ -656,7 +702,7 @@ __device__ __forceinline__ bool search_cr_interval(const DevTables &L, bool need
     const int n = L.n_wcr;
     // w/2 of candidate k from the (uniform: cr_monotone implies it) axis instead of a table load; the screening tolerance
     // below covers the last-bit difference to the tabulated 0.5 * w[k]
-    const double whs = 0.5 / L.inv_wcrstep, wh0 = 0.5 * L.wcr0;
+    const double whs = L.wcrstep_half, wh0 = 0.5 * L.wcr0;
     auto score = [&](int k) {
         const double dd = fma(row[k], invf, sn);
         const double t = fma(fma((double)k, whs, wh0), f, g);
@@ -843,12 +889,12 @@ __device__ __forceinline__ void load_pixel(const DevTables &L, const KArgs &A, l
         else {
             if (P.s_co == P.s_co) {
                 P.flags |= F_NEED_CO;
-                P.i_inc = nearest_index(L.inc, L.n_inc, inc);
+                P.i_inc = nearest_index(L.inc, L.n_inc, inc, L.inc_uniform != 0, L.inc0, L.inv_incstep);
                 if (fabs(P.s_co) < 1e100 && fabs(P.a_re) < 1e100 && fabs(P.a_im) < 1e100) P.flags |= F_CO_FINITE;  // NaN/inf/absurd: exact scan
             }
             if (P.s_cr == P.s_cr && P.dsig == P.dsig) {
                 P.flags |= F_NEED_CR;
-                P.i_inc_cr = nearest_index(L.inc_cr, L.n_inc_cr, inc);
+                P.i_inc_cr = nearest_index(L.inc_cr, L.n_inc_cr, inc, L.inc_cr_uniform != 0, L.inc_cr0, L.inv_inccrstep);
             }
         }
     }
@@ -876,7 +922,8 @@ __device__ __forceinline__ void store_pixel(const DevTables &L, const KArgs &A, 
     } else {
         int sgn = 0;
         if (P.flags & F_NEED_CO) {
-            o_iw = my_flat / L.n_phi;
+            // flat < 2^30, n_phi < 2^16: (flat + 0.5) / n_phi is at least 0.5 / n_phi away from an integer, the product's error ~1e-7 of that
+            o_iw = (int)(((double)my_flat + 0.5) * L.inv_nphi);
             o_ip = my_flat - o_iw * L.n_phi;
             const double w = L.w[o_iw];
             const double2 e1 = ((const double2 *)L.out_dir)[o_ip];
@@ -885,9 +932,19 @@ __device__ __forceinline__ void store_pixel(const DevTables &L, const KArgs &A, 
             if (L.phi_180) {
                 const double2 e2 = ((const double2 *)L.out_dir)[L.n_phi + o_ip];
                 const double s2r = w * e2.x, s2i = w * e2.y + 0.0 * e2.x;
-                const double d1 = angle_of_quotient(P.a_re, P.a_im, s1r, s1i);
-                const double d2 = angle_of_quotient(P.a_re, P.a_im, s2r, s2i);
-                if (!(fabs(d1) <= fabs(d2))) { co_re = s2r; co_im = s2i; sgn = 1; }
+                // |angle(a / s1)| <= |angle(a / s2)|  with  s1,2 = w e^{+-i phi}:  cos(angle1) - cos(angle2) = 2 sin(theta_a) sin(phi),
+                // so away from sin(theta_a) sin(phi) = 0 the choice is the sign of Im(a) * sin(phi) (the computed angles are good
+                // to ~1e-15; the margin asked for here is 1e-9).  Only the near-ties go through the emulated division + atan2.
+                const double xs = P.a_im * e1.y, mag = fabs(P.a_re) + fabs(P.a_im);
+                const bool clear = fabs(xs) > 1e-9 * mag && mag > 1e-100 && mag < 1e100 && w > 1e-100 && w < 1e100 && e2.y == -e1.y &&
+                                   e2.x == e1.x;
+                bool second = xs < 0.0;
+                if (!clear) {
+                    const double d1 = angle_of_quotient(P.a_re, P.a_im, s1r, s1i);
+                    const double d2 = angle_of_quotient(P.a_re, P.a_im, s2r, s2i);
+                    second = !(fabs(d1) <= fabs(d2));
+                }
+                if (second) { co_re = s2r; co_im = s2i; sgn = 1; }
             }
         } else {
             co_re = nan; co_im = nan;  // np.nan * 1j
@@ -912,8 +969,15 @@ __device__ __forceinline__ void store_pixel(const DevTables &L, const KArgs &A, 
     }
     if (CR && A.out_cr) {
         if (A.dual_select) {  // xr.where((|co| < 5) | (|dual| < 5), co, dual)  (windspeed.py:426-428)
-            const double aco = (P.flags & F_NEED_CO) ? L.abs_co[(size_t)o_iw * L.n_phi + o_ip] : hypot_glibc(co_re, co_im);
-            if (aco < 5.0 || hypot_glibc(cr_re, cr_im) < 5.0) { cr_re = co_re; cr_im = co_im; }
+            // without a co-pol search wind_co is (nan, nan) or (nan, 0): |wind_co| is NaN, never < 5
+            const double aco = (P.flags & F_NEED_CO) ? L.abs_co[(size_t)o_iw * L.n_phi + o_ip] : nan;
+            // |wind_dual| = wspd_dual * |unit vector| = wspd_dual (1 +- 1e-15): the emulated hypot only decides next to 5 m/s
+            bool dual_small = false;  // no cross-pol search: (nan, nan)
+            if (!(P.flags & F_EARLY_NAN) && (P.flags & F_NEED_CR)) {
+                const double wd = L.wcr[my_icr];
+                dual_small = wd < 5.0 - 1e-9 ? true : (wd > 5.0 + 1e-9 ? false : hypot_glibc(cr_re, cr_im) < 5.0);
+            }
+            if (aco < 5.0 || dual_small) { cr_re = co_re; cr_im = co_im; }
         }
         cx_t z; z.x = (TO)cr_re; z.y = (TO)cr_im;
         ((cx_t *)A.out_cr)[i] = z;
@@ -953,7 +1017,7 @@ __device__ __forceinline__ void invert_strip(const DevTables &L, const KArgs &A,
     unsigned long long relay = 0;  // pixels laid out for a 16/32-lane segment that co_box_search has to lay out again
     if (use_prune && todo) {
         bool loose = false;
-        W = co_window_lanes(L, P, A.inv_dsig_co, loose);
+        W = co_window_lanes(L, P, A.inv_dsig_co, fabs(A.dsig_co), loose);
         if (loose) P.flags &= ~F_CO_FINITE;  // -> exact_scan_co
         const unsigned long long fin_m = __ballot((P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0);
         cand += (unsigned)__popcll(fin_m) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)));
