@@ -491,21 +491,22 @@ static int launch_invert(xsw_ctx *c, const KArgs &A, int algo)
         const unsigned list_blocks = (unsigned)std::min<long long>(nblocks, 256 * 8);  // 8 waves per SIMD
         // k_invert_band: x = XCD lane + 8 * line group, y = tile column inside the XCD's range (see the kernel)
         const long long cols_per_xcd = (strips_per_line + 7) / 8;
-        if (8 * line_groups > 0x7fffffffLL || cols_per_xcd > 65535) return fail(c, XSW_EINVAL, "raster too large for one launch");
-        const dim3 band_grid((unsigned)(8 * line_groups), (unsigned)cols_per_xcd);
+        const long long band_groups = (A.lines + XSW_BAND_WG_WAVES - 1) / XSW_BAND_WG_WAVES;
+        if (8 * band_groups > 0x7fffffffLL || cols_per_xcd > 65535) return fail(c, XSW_EINVAL, "raster too large for one launch");
+        const dim3 band_grid((unsigned)(8 * band_groups), (unsigned)cols_per_xcd), band_block(64 * XSW_BAND_WG_WAVES);
         timing_mark(c);
         if (A.stats) {  // statistics instantiation (counts the scored candidates)
-            if (!A.s_cr && !A.out_cr) hipLaunchKernelGGL((k_invert_band<T, TO, false, true>), band_grid, dim3(256), 0, c->stream, c->T, B);
-            else hipLaunchKernelGGL((k_invert_band<T, TO, true, true>), band_grid, dim3(256), 0, c->stream, c->T, B);
+            if (!A.s_cr && !A.out_cr) hipLaunchKernelGGL((k_invert_band<T, TO, false, true>), band_grid, band_block, 0, c->stream, c->T, B);
+            else hipLaunchKernelGGL((k_invert_band<T, TO, true, true>), band_grid, band_block, 0, c->stream, c->T, B);
             timing_mark(c);
             if (!A.s_cr && !A.out_cr) hipLaunchKernelGGL((k_invert_list<T, TO, false>), dim3(list_blocks), dim3(256), 0, c->stream, c->T, B);
             else hipLaunchKernelGGL((k_invert_list<T, TO, true>), dim3(list_blocks), dim3(256), 0, c->stream, c->T, B);
         } else if (!A.s_cr && !A.out_cr) {
-            hipLaunchKernelGGL((k_invert_band<T, TO, false, false>), band_grid, dim3(256), 0, c->stream, c->T, B);
+            hipLaunchKernelGGL((k_invert_band<T, TO, false, false>), band_grid, band_block, 0, c->stream, c->T, B);
             timing_mark(c);
             hipLaunchKernelGGL((k_invert_list<T, TO, false>), dim3(list_blocks), dim3(256), 0, c->stream, c->T, B);
         } else {
-            hipLaunchKernelGGL((k_invert_band<T, TO, true, false>), band_grid, dim3(256), 0, c->stream, c->T, B);
+            hipLaunchKernelGGL((k_invert_band<T, TO, true, false>), band_grid, band_block, 0, c->stream, c->T, B);
             timing_mark(c);
             hipLaunchKernelGGL((k_invert_list<T, TO, true>), dim3(list_blocks), dim3(256), 0, c->stream, c->T, B);
         }

@@ -47,6 +47,9 @@ namespace xsw {
 #define XSW_BAND_RAY_D 2
 #endif
 #ifndef XSW_BAND_RAYS
+#ifndef XSW_BAND_WG_WAVES
+#define XSW_BAND_WG_WAVES 4  // waves (= raster lines) per workgroup
+#endif
 #define XSW_BAND_RAYS 3   // rays of the upper bound (co_window_lanes)
 #endif
 #ifndef XSW_BAND_WAVES
@@ -190,12 +193,12 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
 // COUNT = true: the statistics instantiation (xsw_stats_enable): candidates are counted per pass; its own kernel so that the
 // production kernel carries one copy of each pass (half the code).
 template <typename T, typename TO, bool CR, bool COUNT>
-__global__ __launch_bounds__(256, XSW_BAND_WAVES) void k_invert_band(DevTables L, KArgs A)
+__global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_invert_band(DevTables L, KArgs A)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __shared__ BandSlot slots[4][64];  // search parameters of the wave's 64 pixels
-    __shared__ int map_[4][32];        // pass: segment -> owner lane
-    __shared__ int res_[4][32];        // pass: segment -> winning flat index (or -1)
+    __shared__ BandSlot slots[XSW_BAND_WG_WAVES][64];  // search parameters of the wave's 64 pixels
+    __shared__ int map_[XSW_BAND_WG_WAVES][32];        // pass: segment -> owner lane
+    __shared__ int res_[XSW_BAND_WG_WAVES][32];        // pass: segment -> winning flat index (or -1)
     // same tile walk as k_invert (XCD x owns a contiguous range of tile columns, line groups fastest), as a 2-D grid so that
     // no division is needed: blockIdx.x = xcd + 8 * line group, blockIdx.y = tile column inside the XCD's range (workgroups
     // are dealt to the XCDs round-robin in linear order, x fastest: the XCD of a workgroup is still blockIdx.x & 7)
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(256, XSW_BAND_WAVES) void k_invert_band(DevTables L
     const long long cols_per_xcd = (strips_per_line + 7) >> 3;
     const long long xcd = blockIdx.x & 7;
     const long long col = xcd * cols_per_xcd + blockIdx.y;
-    const long long line = (long long)(blockIdx.x >> 3) * 4 + wv;
+    const long long line = (long long)(blockIdx.x >> 3) * XSW_BAND_WG_WAVES + wv;
     if (col >= strips_per_line || line >= A.lines) return;  // wave-uniform
     const long long smp = col * 64 + lane;
     const bool in = smp < A.samples;
