@@ -313,6 +313,23 @@ static int install_co(xsw_ctx *c, const xsw_lut *l, const double *d_dense)
             e = hipGetLastError();
         }
         T.mono_rows = d_mono;
+        // inverse of the monotone rows (co_band_pass starts its sweep from a table look-up instead of a bisection)
+        T.inv_rows = nullptr; T.inv_grid = nullptr;
+        const size_t inv_n = (size_t)nI * XSW_INV_BINS * ppad;
+        if (e == hipSuccess && nW < 65536 && nI < 65536 && inv_n * sizeof(unsigned short) < ((size_t)1 << 32)) {
+            unsigned short *d_inv = nullptr;
+            double *d_grid = nullptr;
+            e = hipMalloc((void **)&d_inv, inv_n * sizeof(unsigned short) + 64);
+            if (e == hipSuccess) { c->co_allocs.push_back(d_inv); e = hipMalloc((void **)&d_grid, (size_t)3 * nI * sizeof(double) + 64); }
+            if (e == hipSuccess) { c->co_allocs.push_back(d_grid); e = hipMemsetAsync(d_inv, 0, inv_n * sizeof(unsigned short), c->stream); }
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_inv_range, dim3((unsigned)nI), dim3(256), 0, c->stream, d_dense, nW, nP, d_mono, d_grid);
+                hipLaunchKernelGGL(k_inv_rows, dim3((unsigned)(((long long)nI * nP + 255) / 256)), dim3(256), 0, c->stream, d_dense, nI, nW, nP,
+                                   ppad, d_mono, d_grid, d_inv);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) { T.inv_rows = d_inv; T.inv_grid = d_grid; }
+        }
         if (e == hipSuccess) e = hipMemcpyAsync(h_flags, d_flags, sizeof h_flags, hipMemcpyDeviceToHost, c->stream);
         hipError_t se = hipStreamSynchronize(c->stream);
         if (e == hipSuccess) e = se;
@@ -474,7 +491,7 @@ static int launch_invert(xsw_ctx *c, const KArgs &A, int algo)
     // Two-kernel fast path: k_invert_band finishes every pixel the band rule decides (monotone LUT rows, finite inputs,
     // unique minimum; cross-pol by the interval rule) and appends the rest to a work list; k_invert_list inverts those.
     static const bool band_off = getenv("XSW_NO_BAND") != nullptr;  // experiments / A-B measurements only
-    if (algo == XSW_ALGO_PRUNED && !band_off && A.s_co && c->T.prunable && c->T.mono_rows && c->T.co_off32 &&
+    if (algo == XSW_ALGO_PRUNED && !band_off && A.s_co && c->T.prunable && c->T.mono_rows && c->T.inv_rows && c->T.co_off32 &&
         (!A.s_cr || c->T.cr_monotone) && A.n < (1LL << 32)) {
         if ((size_t)A.n > c->list_cap) {
             if (c->d_list) (void)hipFree(c->d_list);

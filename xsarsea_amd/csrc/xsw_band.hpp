@@ -47,10 +47,10 @@ namespace xsw {
 #define XSW_BAND_RAY_D 2
 #endif
 #ifndef XSW_BAND_RAYS
-#ifndef XSW_BAND_WG_WAVES
-#define XSW_BAND_WG_WAVES 4  // waves (= raster lines) per workgroup
-#endif
 #define XSW_BAND_RAYS 3   // rays of the upper bound (co_window_lanes)
+#endif
+#ifndef XSW_BAND_WG_WAVES
+#define XSW_BAND_WG_WAVES 4  // waves (= raster lines) per workgroup; measured 1 / 2 / 4 / 8 / 16: 81.0 / 79.4 / 77.3 / 82.6 / 91.2 ms
 #endif
 #ifndef XSW_BAND_WAVES
 #define XSW_BAND_WAVES 8
@@ -58,7 +58,7 @@ namespace xsw {
 
 struct BandSlot {  // 64 bytes per pixel, read by every lane of its segment (same address: LDS broadcast)
     double sn, thr_lo, thr_hi, ah, bh, m2;
-    int i_inc, rows /* w_lo | w_hi << 16 */, ip_lo, ncols;
+    int inc_bin /* i_inc | threshold bin of s - d << 16 */, rows /* w_lo | w_hi << 16 */, ip_lo, ncols;
 };
 
 __device__ __forceinline__ unsigned long long ballot64(bool b) { return __builtin_amdgcn_ballot_w64(b); }
@@ -68,7 +68,7 @@ __device__ __forceinline__ double ld_co(const char *__restrict__ base, unsigned 
 }
 
 template <int S, int K, bool COUNT>
-__device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig, int nsteps, int lane,
+__device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig, int lane,
                                              const BandSlot *slots /* this wave's [64], by pixel lane */, int *map /* [32] */,
                                              int *res /* [32] */, unsigned long long &pend, int &my_flat, unsigned &cand)
 {
@@ -89,13 +89,16 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
     const bool valid = q < nvalid;
     const int owner = valid ? map[q] : lane;
     BandSlot B = slots[owner];
-    if (!valid) { B.i_inc = 0; B.rows = 0; B.ip_lo = 0; B.ncols = 0; }  // idle segment: harmless addresses, nothing scored
+    if (!valid) { B.inc_bin = 0; B.rows = 0; B.ip_lo = 0; B.ncols = 0; }  // idle segment: harmless addresses, nothing scored
     const int w_lo = B.rows & 0xffff, w_hi = B.rows >> 16;
     const double thr_lo = B.thr_lo, thr_hi = B.thr_hi, sn = B.sn;
     const double wh0 = 0.5 * L.w0, whs = L.wstep_half;
     const char *__restrict__ base = (const char *)L.co;
     const unsigned rowB = (unsigned)L.phi_pad * 8u;
-    const unsigned slice0 = (unsigned)(B.i_inc * L.n_w) * rowB;
+    const int i_inc = B.inc_bin & 0xffff;
+    const unsigned slice0 = (unsigned)(i_inc * L.n_w) * rowB;
+    // row of the inverse table: thresholds <= s - d of this slice, one entry per direction (2-byte entries, < 4 GB: xsw.hip)
+    const unsigned inv0 = (unsigned)(i_inc * XSW_INV_BINS + ((unsigned)B.inc_bin >> 16)) * (unsigned)L.phi_pad * 2u;
     double best = inf, second = inf;
     int brow = 0, bip = 0;
     unsigned ncand = 0;
@@ -116,32 +119,10 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
             U[j] = 2.0 * (B.ah * *(const double *)((const char *)L.cphi + ipB) + B.bh * *(const double *)((const char *)L.sphi + ipB));
             off0[j] = slice0 + ipB;
         }
-        // first column: lower_bound(s - d) over the window rows
-        int lo = w_lo, hi = w_hi + 1;
-#pragma unroll 1
-        for (int it = 0; it < nsteps; ++it) {
-            const int mid = (lo + hi) >> 1;
-            const double v = ld_co(base, off0[0], min(mid, w_hi), rowB);
-            const bool open = lo < hi, below = v < thr_lo;
-            lo = (open && below) ? mid + 1 : lo;
-            hi = (open && !below) ? mid : hi;
-        }
-        r[0] = lo;
-        // next columns: from the neighbour's row, walk until  LUT[r - 1] < s - d <= LUT[r]  (window ends count as -inf / +inf)
+        // start of the sweep: the tabulated first row with LUT >= (a grid threshold <= s - d), i.e. at or below the band's first row
 #pragma unroll
-        for (int j = 1; j < K; ++j) {
-            int rr = r[j - 1];
-#pragma unroll 1
-            for (int it = 0;; ++it) {
-                const double a = ld_co(base, off0[j], max(rr - 1, w_lo), rowB), b = ld_co(base, off0[j], min(rr, w_hi), rowB);
-                const bool down = act[j] && rr > w_lo && a >= thr_lo;
-                const bool up = act[j] && !down && rr <= w_hi && b < thr_lo;
-                rr += (up ? 1 : 0) - (down ? 1 : 0);
-                if (ballot64(up || down) == 0ULL) break;
-                if (it >= XSW_BAND_WALK_MAX) { overflow = overflow || up || down; break; }
-            }
-            r[j] = rr;
-        }
+        for (int j = 0; j < K; ++j)
+            r[j] = max((int)*(const unsigned short *)((const char *)L.inv_rows + (inv0 + (unsigned)ip[j] * 2u)), w_lo);
         bool any = false;
 #pragma unroll
         for (int j = 0; j < K; ++j) { more[j] = act[j] && r[j] <= w_hi; any = any || more[j]; }
@@ -153,7 +134,8 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
             for (int j = 0; j < K; ++j) {
                 const int rc = min(r[j], w_hi);
                 const double v = ld_co(base, off0[j], rc, rowB);
-                const bool inb = more[j] && v <= thr_hi;
+                const bool cont = more[j] && v <= thr_hi;  // rows still below the band are passed over
+                const bool inb = cont && v >= thr_lo;
                 const double wh = fma((double)rc, whs, wh0);
                 const double dd = fma(v, inv_dsig, sn);
                 double J = fma(dd, dd, wh * (wh - U[j]));
@@ -165,7 +147,7 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
                 best = vmin(best, J);
                 if (COUNT) ncand += inb ? 1u : 0u;
                 r[j] += 1;
-                more[j] = inb && r[j] <= w_hi;
+                more[j] = cont && r[j] <= w_hi;
                 any = any || more[j];
             }
         }
@@ -216,7 +198,6 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_inve
     int flags, my_flat = -1, my_icr = -1;
     unsigned cand = 0;
     unsigned long long cls[6], seen_all = 0;
-    int ns[6];
     {
         // ---- stage 1, one pixel per lane: classify, incidence bin, upper bound along the a-priori direction, window
         Pixel P;
@@ -224,7 +205,7 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_inve
         flags = P.flags;
         const unsigned long long todo = __ballot((P.flags & F_NEED_CO) != 0);
         bool eligb = false;
-        int ncols_p = 0, bits = 0;
+        int ncols_p = 0;
         if (todo) {
             bool loose = false;
             const CoWindow W = co_window_lanes<XSW_BAND_RAYS, XSW_BAND_RAY_D>(L, P, A.inv_dsig_co, fabs(A.dsig_co), loose);
@@ -232,52 +213,48 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_inve
             ncols_p = W.ip_hi - W.ip_lo + 1;
             const bool need = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0 && !loose && ncols_p >= 1 && nrows_p >= 1;
             eligb = need && W.w_hi < L.mono_rows[need ? P.i_inc : 0];  // the window stays inside the monotone rows
-            bits = eligb ? 32 - __clz(nrows_p) : 0;                    // bisection steps this window needs
             if (eligb) {
                 BandSlot b;
                 const double ah = 0.5 * P.a_re, bh = 0.5 * P.b_eff;
                 b.sn = -P.s_co * A.inv_dsig_co; b.thr_lo = P.s_co - W.band_d; b.thr_hi = P.s_co + W.band_d;
                 b.ah = ah; b.bh = bh; b.m2 = ah * ah + bh * bh;
-                b.i_inc = P.i_inc; b.rows = W.w_lo | (W.w_hi << 16); b.ip_lo = W.ip_lo; b.ncols = ncols_p;
+                // threshold bin of the slice's inverse table: the largest grid threshold <= s - d (bin 0 also stands for
+                // anything below the grid); the check repeats the builder's own expression (k_inv_rows)
+                const double *g = L.inv_grid + 3 * P.i_inc;
+                const double t0 = g[0], width = g[1];
+                int bin = (int)fmin(fmax((b.thr_lo - t0) * g[2], 0.0), (double)(XSW_INV_BINS - 1));
+                if (bin > 0 && fma((double)bin, width, t0) > b.thr_lo) --bin;
+                if (bin > 0 && fma((double)bin, width, t0) > b.thr_lo) bin = 0;
+                b.inc_bin = P.i_inc | (bin << 16); b.rows = W.w_lo | (W.w_hi << 16); b.ip_lo = W.ip_lo; b.ncols = ncols_p;
                 slots[wv][lane] = b;
             }
             if (COUNT) cand += (unsigned)__popcll(__ballot(eligb)) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)) + (XSW_BAND_RAYS - 1) * 2 * XSW_RAY_SIDE_STEPS);
         }
         constexpr int BK = XSW_BAND_K;
-        // class of a window: widths (1..2, 3..4, 5..8, 9..16, 17..32, more) * K directions.  The bisection trip count of a
-        // class is the largest bit length of its windows' heights: one OR-reduction of thermometer codes (16 bits per class,
-        // two classes per dword) instead of six max-reductions
+        // class of a window: widths (1..2, 3..4, 5..8, 9..16, 17..32, more) * K directions
         const int wq = (ncols_p + BK - 1) / BK;
         const int myc = !eligb ? 6 : (wq <= 2 ? 0 : min(31 - __clz(wq - 1), 5));
-        unsigned th[3] = {0u, 0u, 0u};
-        if (eligb) th[myc >> 1] = ((1u << bits) - 1u) << (16 * (myc & 1));
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) th[k] |= (unsigned)__shfl_xor((int)th[k], off);
-        }
         unsigned long long seen = 0;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             cls[c] = __ballot(myc == c);
             seen |= cls[c];
-            ns[c] = __popc((__builtin_amdgcn_readfirstlane((int)th[c >> 1]) >> (16 * (c & 1))) & 0xffff);
         }
         seen_all = seen;
     }
     // ---- stage 2: band passes, narrowest windows first (most pixels per pass)
     {
         constexpr int BK = XSW_BAND_K;
-        auto run = [&](auto seg, unsigned long long m, int nsteps) {
+        auto run = [&](auto seg, unsigned long long m) {
             constexpr int S = decltype(seg)::value;
-            while (m) co_band_pass<S, BK, COUNT>(L, A.inv_dsig_co, nsteps, lane, slots[wv], map_[wv], res_[wv], m, my_flat, cand);
+            while (m) co_band_pass<S, BK, COUNT>(L, A.inv_dsig_co, lane, slots[wv], map_[wv], res_[wv], m, my_flat, cand);
         };
-        run(std::integral_constant<int, 2>{}, cls[0], ns[0]);
-        run(std::integral_constant<int, 4>{}, cls[1], ns[1]);
-        run(std::integral_constant<int, 8>{}, cls[2], ns[2]);
-        run(std::integral_constant<int, 16>{}, cls[3], ns[3]);
-        run(std::integral_constant<int, 32>{}, cls[4], ns[4]);
-        run(std::integral_constant<int, 64>{}, cls[5], ns[5]);
+        run(std::integral_constant<int, 2>{}, cls[0]);
+        run(std::integral_constant<int, 4>{}, cls[1]);
+        run(std::integral_constant<int, 8>{}, cls[2]);
+        run(std::integral_constant<int, 16>{}, cls[3]);
+        run(std::integral_constant<int, 32>{}, cls[4]);
+        run(std::integral_constant<int, 64>{}, cls[5]);
     }
     const bool need_co = (flags & F_NEED_CO) != 0;
     bool unresolved = in && need_co && my_flat < 0;  // not eligible, or undecided by its pass

@@ -25,6 +25,10 @@
 
 namespace xsw {
 
+#ifndef XSW_INV_BINS
+#define XSW_INV_BINS 2048  // thresholds per slice of the inverse-row table (DevTables::inv_rows)
+#endif
+
 struct DevTables {
     // co-pol LUT, dB
     const double *co;    // [n_inc][n_w][phi_pad]   incidence-major slices (722 KB each at default size)
@@ -41,6 +45,10 @@ struct DevTables {
     int prunable;  // uniform axes, finite LUT: branch-and-bound allowed
     int co_off32;  // the padded co table is < 4 GB: 32-bit byte offsets from its base address every word
     const int *mono_rows;  // [n_inc] every column of slice i is non-decreasing in wind speed over rows [0, mono_rows[i]) (band pruning)
+    // inverse of the monotone rows (band pruning): inv_rows[i][b][p] = first row r < mono_rows[i] of column p with
+    // LUT >= fma(b, inv_grid[3i+1], inv_grid[3i]) (a uniform dB grid per slice, XSW_INV_BINS bins), else mono_rows[i]
+    const unsigned short *inv_rows;  // [n_inc][XSW_INV_BINS][phi_pad]
+    const double *inv_grid;          // [n_inc][3]: t0, bin width, 1 / bin width
     double w0, inv_wstep, phi0, phi_last, inv_dphi;
     double wstep_half;  // 0.5 / inv_wstep (host: one IEEE division instead of one per wave and pass)
     double inv_nphi;    // 1 / n_phi: flat index -> (row, direction) without an integer division

@@ -82,4 +82,49 @@ __global__ __launch_bounds__(256) void k_mono_rows(const double *__restrict__ de
     if (first < n_w) atomicMin(&out[i], first);
 }
 
+// dB range of the monotone rows of each slice -> the slice's uniform threshold grid {t0, width, 1 / width}
+__global__ __launch_bounds__(256) void k_inv_range(const double *__restrict__ dense, int n_w, int n_phi, const int *__restrict__ mono,
+                                                   double *__restrict__ grid)
+{
+    const int i = blockIdx.x;
+    const double *sl = dense + (size_t)i * n_w * n_phi;
+    const long long n = (long long)mono[i] * n_phi;
+    double lo = __builtin_inf(), hi = -__builtin_inf();
+    for (long long k = threadIdx.x; k < n; k += blockDim.x) { const double v = sl[k]; lo = fmin(lo, v); hi = fmax(hi, v); }
+    __shared__ double slo[256], shi[256];
+    slo[threadIdx.x] = lo; shi[threadIdx.x] = hi;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) { slo[threadIdx.x] = fmin(slo[threadIdx.x], slo[threadIdx.x + st]); shi[threadIdx.x] = fmax(shi[threadIdx.x], shi[threadIdx.x + st]); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double width = (shi[0] - slo[0]) / (double)XSW_INV_BINS;
+        const bool ok = width > 0.0 && width < 1e300 && slo[0] > -1e300;
+        grid[3 * i + 0] = ok ? slo[0] : 0.0;
+        grid[3 * i + 1] = ok ? width : 0.0;
+        grid[3 * i + 2] = ok ? 1.0 / width : 0.0;  // not ok (flat or non-finite slice): every threshold falls in bin 0, whose rows are 0
+    }
+}
+// one thread per (slice, direction): merge of the ascending thresholds with the non-decreasing column
+__global__ __launch_bounds__(256) void k_inv_rows(const double *__restrict__ dense, int n_inc, int n_w, int n_phi, int phi_pad,
+                                                  const int *__restrict__ mono, const double *__restrict__ grid,
+                                                  unsigned short *__restrict__ inv)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n_inc * n_phi) return;
+    const int i = (int)(t / n_phi), p = (int)(t % n_phi);
+    const double *col = dense + (size_t)i * n_w * n_phi + p;
+    unsigned short *out = inv + (size_t)i * XSW_INV_BINS * phi_pad + p;
+    const double t0 = grid[3 * i], width = grid[3 * i + 1];
+    const int m = mono[i];
+    int r = 0;
+    out[0] = 0;  // bin 0 also serves thresholds below the grid: row 0 is a lower estimate of any lower bound
+    for (int b = 1; b < XSW_INV_BINS; ++b) {
+        const double thr = fma((double)b, width, t0);
+        while (r < m && col[(size_t)r * n_phi] < thr) ++r;
+        out[(size_t)b * phi_pad] = (unsigned short)r;
+    }
+}
+
 }  // namespace xsw
