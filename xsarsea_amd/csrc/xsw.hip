@@ -444,6 +444,21 @@ static int upload_cr(xsw_ctx *c, const xsw_lut *l)
     T.wcr0 = l->wspd[0];
     T.inv_wcrstep = nW > 1 ? (nW - 1) / (l->wspd[nW - 1] - l->wspd[0]) : 0.0;
     T.wcrstep_half = 0.5 / T.inv_wcrstep;
+    T.inv_cr = nullptr; T.inv_cr_grid = nullptr;
+    if (mono && nW < 65536) {  // inverse of the monotone rows (search_cr_scan): first k with row[k] >= t0 + b * width
+        std::vector<unsigned short> inv((size_t)nI * XSW_INV_BINS);
+        std::vector<double> grid((size_t)3 * nI);
+        for (int r = 0; r < nI; ++r) {
+            const double *row = l->db + (size_t)r * nW;
+            const double t0 = row[0], width = (row[nW - 1] - row[0]) / (double)XSW_INV_BINS;
+            const bool ok = width > 0.0 && width < 1e300;
+            grid[3 * r] = ok ? t0 : 0.0; grid[3 * r + 1] = ok ? width : 0.0; grid[3 * r + 2] = ok ? 1.0 / width : 0.0;
+            for (int b = 0; b < XSW_INV_BINS; ++b)
+                inv[(size_t)r * XSW_INV_BINS + b] = (unsigned short)(b == 0 || !ok ? 0 : std::lower_bound(row, row + nW, std::fma((double)b, width, t0)) - row);
+        }
+        if ((rc = upload(c, c->cr_allocs, inv.data(), inv.size(), &T.inv_cr))) return rc;
+        if ((rc = upload(c, c->cr_allocs, grid.data(), grid.size(), &T.inv_cr_grid))) return rc;
+    }
     T.inc_cr_uniform = uniform_axis(l->inc, nI) && nI >= 2 ? 1 : 0;
     T.inc_cr0 = l->inc[0];
     T.inv_inccrstep = nI > 1 ? (nI - 1) / (l->inc[nI - 1] - l->inc[0]) : 0.0;

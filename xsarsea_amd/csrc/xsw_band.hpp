@@ -271,7 +271,8 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_inve
         const int i_inc_cr = here ? nearest_index(L.inc_cr, L.n_inc_cr, inc, L.inc_cr_uniform != 0, L.inc_cr0, L.inv_inccrstep) : 0;
         const double aco = (here && need_co) ? L.abs_co[my_flat] : nan;  // np.abs(wind_co), table [n_w][n_phi]
         bool undecided = here;
-        const bool done = search_cr_interval(L, here, i_inc_cr, s_cr, dsig, need_co, aco, my_icr, undecided);
+        const bool done = L.inv_cr ? search_cr_scan(L, here, i_inc_cr, s_cr, dsig, need_co, aco, my_icr, undecided)
+                                   : search_cr_interval(L, here, i_inc_cr, s_cr, dsig, need_co, aco, my_icr, undecided);
         unresolved = unresolved || (need_cr && (undecided || !done));
         if (need_cr) flags |= F_NEED_CR;
     }

@@ -60,6 +60,9 @@ struct DevTables {
     int n_inc_cr, n_wcr, wcr_pad, cr_finite;
     int cr_monotone;   // every row non-decreasing in wind speed and the speed axis uniform: interval pruning allowed
     double wcr0, inv_wcrstep, wcrstep_half;
+    // inverse of the (monotone) cross-pol rows: inv_cr[i][b] = first k with cr[i][k] >= fma(b, grid[3i+1], grid[3i]), else n_wcr
+    const unsigned short *inv_cr;  // [n_inc_cr][XSW_INV_BINS]   (null: not monotone / too long: search_cr_interval is used)
+    const double *inv_cr_grid;     // [n_inc_cr][3]: t0, bin width, 1 / bin width
     int inc_cr_uniform;
     double inc_cr0, inv_inccrstep;
 };
@@ -841,6 +844,86 @@ __device__ __forceinline__ double hypot_glibc(double x, double y)
     return h;
 }
 
+// The interval rule of search_cr_interval without its bisections (L.inv_cr present): seeds are the rows around the tabulated
+// crossing LUT ~ sigma0 plus the row nearest to |wind_co|; the best seed is admissible by construction (its score IS the
+// bound), and the admissible set -- window |w - |co|| <= 2 sqrt(J_ub) AND band |LUT - s| <= |dsig| sqrt(J_ub) -- is an
+// interval of the monotone row: it is scanned from the best seed upwards, then downwards, until the first inadmissible row on
+// either side (one load per trip, trip count = the longest interval in the wave + 2).  Always returns true; an interval longer
+// than XSW_CR_SCAN_MAX leaves the pixel undecided (exact scan by the caller).
+#ifndef XSW_CR_SCAN_MAX
+#define XSW_CR_SCAN_MAX 176
+#endif
+__device__ __forceinline__ bool search_cr_scan(const DevTables &L, bool need, int i_inc, double s, double dsig,
+                                               bool have_co, double aco, int &icr, bool &undecided)
+{
+    const double inf = __builtin_inf();
+    const double inv = 1.0 / dsig;
+    const bool fast = need && L.cr_finite && isfinite(inv) && isfinite(s) && (!have_co || isfinite(aco));
+    const bool windy = fast && have_co;  // the wind term ((w - |co|) / 2)^2 takes part
+    const int ii = fast ? i_inc : 0;
+    const double *__restrict__ row = L.cr + (size_t)ii * L.wcr_pad;
+    const double sn = fast ? -s * inv : 0.0, invf = fast ? inv : 0.0;
+    const double hco = windy ? 0.5 * aco : 0.0;
+    const int n = L.n_wcr;
+    const double whs = L.wcrstep_half, wh0 = 0.5 * L.wcr0;
+    auto score_v = [&](int k, double v) {
+        const double dd = fma(v, invf, sn);
+        const double t = windy ? fma((double)k, whs, wh0) - hco : 0.0;
+        return fma(t, t, dd * dd);
+    };
+    const double sq = fast ? s : 0.0;
+    // seeds: three rows around the tabulated crossing, and the row nearest to |wind_co|
+    const double *gr = L.inv_cr_grid + 3 * ii;
+    const int bin = (int)fmin(fmax((sq - gr[0]) * gr[2], 0.0), (double)(XSW_INV_BINS - 1));
+    const int k0 = (int)L.inv_cr[(size_t)ii * XSW_INV_BINS + bin];
+    const int kw = min(max((int)rint(((have_co ? aco : 0.0) - L.wcr0) * L.inv_wcrstep), 0), n - 1);
+    double jbest = inf;
+    int ks = 0;
+#pragma unroll
+    for (int j = -1; j <= 2; ++j) {
+        const int k = j == 2 ? (have_co ? kw : min(max(k0, 0), n - 1)) : min(max(k0 + j, 0), n - 1);
+        const double J = score_v(k, row[k]);
+        ks = J < jbest ? k : ks;
+        jbest = vmin(jbest, J);
+    }
+    const double jub = jbest * (1.0 + 1e-9) + 1e-300;
+    const double sj = sqrt(jub);
+    const double d = fabs(fast ? dsig : 1.0) * sj * (1.0 + 1e-9) + 1e-12 * (1.0 + fabs(sq));
+    int a0 = 0, a1 = n - 1;
+    if (fast && have_co) {  // |w - |co|| <= 2 sqrt(J_ub), as an index window with a margin (see search_cr_interval)
+        const double rw = 2.0 * sj * (1.0 + 1e-9) + 1e-9;
+        const double xl = (aco - rw - L.wcr0) * L.inv_wcrstep, xh = (aco + rw - L.wcr0) * L.inv_wcrstep;
+        const double nn = (double)n;
+        a0 = max((int)ceil(fmin(fmax(xl - 1e-5 - 1e-9 * fabs(xl), -4.0), nn + 4.0)), 0);
+        a1 = min((int)floor(fmin(fmax(xh + 1e-5 + 1e-9 * fabs(xh), -4.0), nn + 4.0)), n - 1);
+    }
+    a0 = min(a0, ks); a1 = max(a1, ks);  // the best seed is admissible whatever the rounding of the window did
+    const double t_hi = sq + d, t_lo = sq - d;
+    double best = jbest, second = inf;
+    int code = ks, ku = ks + 1, kd = ks - 1;
+    bool up = true, alive = fast;
+#pragma unroll 1
+    for (int t = 0; t < XSW_CR_SCAN_MAX; ++t) {
+        if (__ballot(alive) == 0ULL) break;
+        const int k = up ? ku : kd, kc = min(max(k, 0), n - 1);
+        const double v = row[kc];
+        const bool ok = alive && (up ? (k <= a1 && v <= t_hi) : (k >= a0 && v >= t_lo));
+        double J = score_v(kc, v);
+        J = ok ? J : inf;
+        second = vmin(second, vmax(J, best));
+        code = J < best ? kc : code;
+        best = vmin(best, J);
+        ku += (ok && up) ? 1 : 0;
+        kd -= (ok && !up) ? 1 : 0;
+        alive = alive && (ok || up);  // first miss going up: turn round; first miss going down: done
+        up = up && ok;
+    }
+    const double T = best + 1e-9 * (1.0 + fabs(best));
+    icr = code;
+    undecided = need && (!fast || alive || !(best < inf) || second <= T);
+    return true;
+}
+
 // numpy's complex128 true-divide (Smith) followed by np.angle, for the +phi / -phi choice
 // (windspeed.py:236-242).
 __device__ __forceinline__ double angle_of_quotient(double ar, double ai, double br, double bi)
@@ -1081,7 +1164,8 @@ __device__ __forceinline__ void invert_strip(const DevTables &L, const KArgs &A,
         bool undecided = need_cr;
         if (ALGO == 1) {
             bool done = false;
-            if (L.cr_monotone) done = search_cr_interval(L, need_cr, P.i_inc_cr, P.s_cr, P.dsig, have_co, aco, my_icr, undecided);
+            if (L.cr_monotone && L.inv_cr) done = search_cr_scan(L, need_cr, P.i_inc_cr, P.s_cr, P.dsig, have_co, aco, my_icr, undecided);
+            else if (L.cr_monotone) done = search_cr_interval(L, need_cr, P.i_inc_cr, P.s_cr, P.dsig, have_co, aco, my_icr, undecided);
             if (!done) search_cr_lanes(L, need_cr, P.i_inc_cr, P.s_cr, P.dsig, have_co, aco, my_icr, undecided);
         }
         n_cr = (unsigned)__popcll(__ballot(need_cr));
