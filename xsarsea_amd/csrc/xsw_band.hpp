@@ -58,7 +58,8 @@ namespace xsw {
 
 struct BandSlot {  // 64 bytes per pixel, read by every lane of its segment (same address: LDS broadcast)
     double sn, thr_lo, thr_hi, ah, bh, m2;
-    int inc_bin /* i_inc | threshold bin of s - d << 16 */, rows /* w_lo | w_hi << 16 */, ip_lo, ncols;
+    int inc_bin /* i_inc | threshold bin of s - d << 16 */, rows /* w_lo | w_hi << 16 */, ipn /* ip_lo | ncols << 16 */;
+    int bin_hi /* threshold bin above s + d, or -1 */;
 };
 
 __device__ __forceinline__ unsigned long long ballot64(bool b) { return __builtin_amdgcn_ballot_w64(b); }
@@ -89,7 +90,8 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
     const bool valid = q < nvalid;
     const int owner = valid ? map[q] : lane;
     BandSlot B = slots[owner];
-    if (!valid) { B.inc_bin = 0; B.rows = 0; B.ip_lo = 0; B.ncols = 0; }  // idle segment: harmless addresses, nothing scored
+    if (!valid) { B.inc_bin = 0; B.rows = 0; B.ipn = 0; B.bin_hi = -1; }  // idle segment: harmless addresses, nothing scored
+    const int B_ip_lo = B.ipn & 0xffff, B_ncols = (int)((unsigned)B.ipn >> 16);
     const int w_lo = B.rows & 0xffff, w_hi = B.rows >> 16;
     const double thr_lo = B.thr_lo, thr_hi = B.thr_hi, sn = B.sn;
     const double wh0 = 0.5 * L.w0, whs = L.wstep_half;
@@ -97,45 +99,49 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
     const unsigned rowB = (unsigned)L.phi_pad * 8u;
     const int i_inc = B.inc_bin & 0xffff;
     const unsigned slice0 = (unsigned)(i_inc * L.n_w) * rowB;
-    // row of the inverse table: thresholds <= s - d of this slice, one entry per direction (2-byte entries, < 4 GB: xsw.hip)
+    // rows of the inverse table (2-byte entries, one per direction, < 4 GB: xsw.hip): the largest threshold <= s - d gives a
+    // row at or below the band's first, the smallest threshold > s + d one past a row at or above its last
     const unsigned inv0 = (unsigned)(i_inc * XSW_INV_BINS + ((unsigned)B.inc_bin >> 16)) * (unsigned)L.phi_pad * 2u;
+    const unsigned inv1 = (unsigned)(i_inc * XSW_INV_BINS + max(B.bin_hi, 0)) * (unsigned)L.phi_pad * 2u;
     double best = inf, second = inf;
     int brow = 0, bip = 0;
     unsigned ncand = 0;
     bool overflow = false;
-    const int nchunks = S == 64 ? (__builtin_amdgcn_readfirstlane(B.ncols) + 64 * K - 1) / (64 * K) : 1;  // S == 64: one pixel, wave-uniform
+    const int nchunks = S == 64 ? (__builtin_amdgcn_readfirstlane(B_ncols) + 64 * K - 1) / (64 * K) : 1;  // S == 64: one pixel, wave-uniform
 #pragma unroll 1
     for (int ch = 0; ch < nchunks; ++ch) {
-        bool act[K], more[K];
-        int ip[K], r[K];
+        bool act[K];
+        int ip[K], r[K], nrow[K];
         unsigned off0[K];
         double U[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const int col = K * sl + j + S * K * ch;
-            act[j] = valid && col < B.ncols;
-            ip[j] = B.ip_lo + (act[j] ? col : 0);
+            act[j] = valid && col < B_ncols;
+            ip[j] = B_ip_lo + (act[j] ? col : 0);
             const unsigned ipB = (unsigned)ip[j] * 8u;
             U[j] = 2.0 * (B.ah * *(const double *)((const char *)L.cphi + ipB) + B.bh * *(const double *)((const char *)L.sphi + ipB));
             off0[j] = slice0 + ipB;
         }
-        // start of the sweep: the tabulated first row with LUT >= (a grid threshold <= s - d), i.e. at or below the band's first row
+        // rows to look at: from the tabulated row at or below the band's first to the one at or above its last, inside the window
+        int nmax = 0;
 #pragma unroll
-        for (int j = 0; j < K; ++j)
-            r[j] = max((int)*(const unsigned short *)((const char *)L.inv_rows + (inv0 + (unsigned)ip[j] * 2u)), w_lo);
-        bool any = false;
-#pragma unroll
-        for (int j = 0; j < K; ++j) { more[j] = act[j] && r[j] <= w_hi; any = any || more[j]; }
+        for (int j = 0; j < K; ++j) {
+            const int ra = (int)*(const unsigned short *)((const char *)L.inv_rows + (inv0 + (unsigned)ip[j] * 2u));
+            const int rb = (int)*(const unsigned short *)((const char *)L.inv_rows + (inv1 + (unsigned)ip[j] * 2u));
+            r[j] = max(ra, w_lo);
+            const int last = B.bin_hi >= 0 ? min(rb - 1, w_hi) : w_hi;
+            nrow[j] = act[j] ? last - r[j] + 1 : 0;
+            nmax = max(nmax, nrow[j]);
+        }
 #pragma unroll 1
         for (int t = 0; t < XSW_BAND_MAX; ++t) {  // scalar trip counter; the loop leaves as soon as no lane has rows left
-            if (ballot64(any) == 0ULL) break;
-            any = false;
+            if (ballot64(t < nmax) == 0ULL) break;
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                const int rc = min(r[j], w_hi);
+                const int rc = min(r[j] + t, w_hi);
                 const double v = ld_co(base, off0[j], rc, rowB);
-                const bool cont = more[j] && v <= thr_hi;  // rows still below the band are passed over
-                const bool inb = cont && v >= thr_lo;
+                const bool inb = t < nrow[j] && v >= thr_lo && v <= thr_hi;  // the end rows may lie just outside the band
                 const double wh = fma((double)rc, whs, wh0);
                 const double dd = fma(v, inv_dsig, sn);
                 double J = fma(dd, dd, wh * (wh - U[j]));
@@ -146,11 +152,9 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
                 if (K > 1 || S == 64) bip = lt ? ip[j] : bip;  // S == 64: the best may sit in an earlier chunk
                 best = vmin(best, J);
                 if (COUNT) ncand += inb ? 1u : 0u;
-                r[j] += 1;
-                more[j] = cont && r[j] <= w_hi;
-                any = any || more[j];
             }
         }
+        const bool any = nmax > XSW_BAND_MAX;
         overflow = overflow || any;  // rows left after XSW_BAND_MAX trips
         if (K == 1 && S != 64) bip = ip[0];
     }
@@ -225,7 +229,12 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_inve
                 int bin = (int)fmin(fmax((b.thr_lo - t0) * g[2], 0.0), (double)(XSW_INV_BINS - 1));
                 if (bin > 0 && fma((double)bin, width, t0) > b.thr_lo) --bin;
                 if (bin > 0 && fma((double)bin, width, t0) > b.thr_lo) bin = 0;
-                b.inc_bin = P.i_inc | (bin << 16); b.rows = W.w_lo | (W.w_hi << 16); b.ip_lo = W.ip_lo; b.ncols = ncols_p;
+                // the smallest grid threshold > s + d (none: the band may reach the window's last row)
+                int bhi = (int)fmin(fmax((b.thr_hi - t0) * g[2], -1.0), (double)XSW_INV_BINS) + 1;
+                if (bhi < XSW_INV_BINS && !(fma((double)bhi, width, t0) > b.thr_hi)) ++bhi;
+                if (bhi < XSW_INV_BINS && !(fma((double)bhi, width, t0) > b.thr_hi)) bhi = XSW_INV_BINS;
+                b.inc_bin = P.i_inc | (bin << 16); b.rows = W.w_lo | (W.w_hi << 16); b.ipn = W.ip_lo | (ncols_p << 16);
+                b.bin_hi = bhi < XSW_INV_BINS ? bhi : -1;
                 slots[wv][lane] = b;
             }
             if (COUNT) cand += (unsigned)__popcll(__ballot(eligb)) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)) + (XSW_BAND_RAYS - 1) * 2 * XSW_RAY_SIDE_STEPS);
