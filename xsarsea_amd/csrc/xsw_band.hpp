@@ -207,6 +207,11 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_inve
         Pixel P;
         load_pixel<T, false>(L, A, i, in, P);
         flags = P.flags;
+        if (CR && A.s_cr) {  // touch the cross-pol inputs now: by the time the passes are over their lines sit in L2, not in HBM
+            const T x = ((const T *)A.s_cr)[i];
+            const T dr = A.dsig_cr ? ((const T *)A.dsig_cr)[i] : (T)0;
+            if (x != x || dr != dr) flags |= F_CR_RAW_NAN;
+        }
         const unsigned long long todo = __ballot((P.flags & F_NEED_CO) != 0);
         bool eligb = false;
         int ncols_p = 0;
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_inve
         const T x = ((const T *)A.s_cr)[i];
         const double s_cr = to_db(x, A.is_db);
         const double dsig = A.dsig_cr ? (double)((const T *)A.dsig_cr)[i] : (double)(T)(x * (T)0 + (T)A.dsig_cr_scalar);
-        need_cr = in && !(flags & F_EARLY_NAN) && s_cr == s_cr && dsig == dsig;
+        need_cr = in && !(flags & (F_EARLY_NAN | F_CR_RAW_NAN)) && s_cr == s_cr && dsig == dsig;
         const bool here = need_cr && !unresolved;
         const int i_inc_cr = here ? nearest_index(L.inc_cr, L.n_inc_cr, inc, L.inc_cr_uniform != 0, L.inc_cr0, L.inv_inccrstep) : 0;
         const double aco = (here && need_co) ? L.abs_co[my_flat] : nan;  // np.abs(wind_co), table [n_w][n_phi]

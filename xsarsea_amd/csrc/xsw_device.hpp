@@ -79,7 +79,7 @@ struct KArgs {
     int is_db, dual_select;
 };
 
-enum : int { F_NEED_CO = 1, F_NEED_CR = 2, F_EARLY_NAN = 4, F_CO_FINITE = 8 };
+enum : int { F_NEED_CO = 1, F_NEED_CR = 2, F_EARLY_NAN = 4, F_CO_FINITE = 8, F_CR_RAW_NAN = 16 /* band kernel: a raw cross-pol input is NaN */ };
 
 // ------------------------------------------------------------------------------------------------
 // wave64 helpers
