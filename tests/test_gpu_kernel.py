@@ -546,6 +546,57 @@ def test_random_configurations(gpu_ctx):
             assert np.array_equal(got[2][..., :2], o[2][..., :2]), (case, algo, co.shape, shape, dt)
 
 
+@pytest.mark.parametrize("quantum", [0.25, 1.0, 4.0])
+def test_inverse_row_table_on_quantised_luts(gpu_ctx, quantum):
+    """The band pass finds its rows through the inverse-row table (first row with LUT >= a grid threshold).  LUTs rounded to
+    a quantum are monotone with plateaus everywhere (lower-bound semantics, many equal LUT values, thresholds that coincide
+    with table values), sigma0 is put exactly ON LUT values and ON the table's own thresholds, and dsig_co makes the band
+    a fraction of a plateau (0.01) or most of the table (5.0).  Indices must equal the oracle's, co- and cross-pol."""
+    from oracle import gmf, lut as olut
+    from oracle import invert as oinv
+    rng = np.random.default_rng(int(quantum * 100))
+    inc_ax = np.linspace(30.0, 40.0, 6)
+    w_ax = np.linspace(0.5, 40.0, 159)
+    phi_ax = np.linspace(0.0, 180.0, 61)
+    co = 10 * np.log10(gmf.gmf_cmod5n(inc_ax[:, None, None], w_ax[None, :, None], phi_ax[None, None, :]) + 1e-15)
+    co = np.round(co / quantum) * quantum
+    wcr_ax = np.linspace(3.0, 60.0, 115)
+    cr = np.round(10 * np.log10(gmf.GMFS["gmf_s1_v2"][0](inc_ax[:, None], wcr_ax[None, :]) + 1e-15) / quantum) * quantum
+    assert np.all(np.diff(cr, axis=1) >= 0)
+    lco = olut.Lut(co, inc_ax, w_ax, phi_ax, "dB", "x", "co", "VV")
+    lcr = olut.Lut(cr, inc_ax, wcr_ax, None, "dB", "x", "cr", "VH")
+    c, r = lut_dicts(lco, lcr)
+    gpu_ctx.upload_luts(co=c, cr=r)
+    n = 1536
+    inc = rng.uniform(29, 41, n)
+    ii = np.abs(inc_ax[None, :] - inc[:, None]).argmin(1)
+    wt, pt = rng.uniform(1.0, 30.0, n), rng.uniform(0, 180, n)
+    iw, ip = np.abs(w_ax[None, :] - wt[:, None]).argmin(1), np.abs(phi_ax[None, :] - pt[:, None]).argmin(1)
+    s_db = co[ii, iw, ip].copy()                       # exactly a LUT value
+    lo, hi = co.min(axis=(1, 2)), co.max(axis=(1, 2))
+    k = np.arange(n) % 4 == 1                          # exactly a threshold of the slice's grid (2048 bins over its range)
+    s_db[k] = lo[ii[k]] + rng.integers(0, 2049, k.sum()) * ((hi[ii[k]] - lo[ii[k]]) / 2048.0)
+    k = np.arange(n) % 4 == 2                          # off the values, inside the range
+    s_db[k] += rng.uniform(-quantum, quantum, k.sum())
+    k = np.arange(n) % 16 == 3                         # below / above every LUT value
+    s_db[k] = np.where(rng.random(k.sum()) < 0.5, lo[ii[k]] - 3.0, hi[ii[k]] + 3.0)
+    s_cr_db = cr[ii, np.abs(wcr_ax[None, :] - np.maximum(wt, 3.0)[:, None]).argmin(1)] + rng.choice([0.0, 0.1, -quantum], n)
+    anc = wt * np.exp(1j * np.deg2rad(pt)) + rng.normal(0, 1.5, n) + 1j * rng.normal(0, 1.5, n)
+    dsig = 10 ** rng.uniform(-2, 0.5, n)
+    shape = (12, 128)
+    inc, s_db, s_cr_db, dsig, anc = (a.reshape(shape) for a in (inc, s_db, s_cr_db, dsig, anc))
+    for dsig_co in (0.01, 0.1, 5.0):
+        p = oinv.Prepared(lco, lcr, dsig_co)
+        o = oinv.invert_numpy(p, inc, s_db, s_cr_db, dsig, anc, return_idx=True)
+        got = gpu_ctx.invert_host(inc, sigma0_co=s_db, sigma0_cr=s_cr_db, dsig_cr=dsig, anc=anc, dsig_co=dsig_co,
+                                  sigma0_is_db=True, algo="pruned", want_idx=True)
+        assert np.array_equal(got[2], o[2]), (quantum, dsig_co)
+        assert_complex_close(got[0], o[0], what=f"q {quantum} dsig_co {dsig_co} co")
+        assert_complex_close(got[1], o[1], rtol=1e-9, what=f"q {quantum} dsig_co {dsig_co} cr")
+        got = gpu_ctx.invert_host(inc, sigma0_co=s_db, anc=anc, dsig_co=dsig_co, sigma0_is_db=True, algo="exhaustive_f64", want_idx=True)
+        assert np.array_equal(got[2][..., :2], o[2][..., :2]), (quantum, dsig_co, "exhaustive")
+
+
 def test_random_configurations_large_axes(gpu_ctx):
     """Windows wider than one 64-direction chunk, taller than the lane layout's trip granularity, clipped at the axis
     ends and covering whole axes: large direction / speed axes with loose dsig_co and far-off ancillary winds."""
