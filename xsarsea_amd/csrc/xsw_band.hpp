@@ -70,25 +70,13 @@ __device__ __forceinline__ double ld_co(const char *__restrict__ base, unsigned 
 
 template <int S, int K, bool COUNT>
 __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig, int lane,
-                                             const BandSlot *slots /* this wave's [64], by pixel lane */, int *map /* [32] */,
-                                             int *res /* [32] */, unsigned long long &pend, int &my_flat, unsigned &cand)
+                                             const BandSlot *slots /* this wave's [64], sorted by class */, int *res /* [64], by slot */,
+                                             int first, int count /* slots [first, first + count) -> segments 0 .. count-1 */, unsigned &cand)
 {
-    constexpr int NP = 64 / S;
     const double inf = __builtin_inf();
-    // the first NP pending pixels, in lane order: pixel of rank r -> segment r
-    const bool is_p = ((pend >> lane) & 1ULL) != 0;
-    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pend >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pend, 0u));
-    const bool take = is_p && rank < NP;
-    if (take) map[rank] = lane;
-    const unsigned long long taken = ballot64(take);
-    const int nvalid = __popcll(taken);
-    pend &= ~taken;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int q = lane / S, sl = lane & (S - 1);
-    const bool valid = q < nvalid;
-    const int owner = valid ? map[q] : lane;
+    const bool valid = q < count;
+    const int owner = valid ? first + q : lane;  // slot index (idle segment: any slot, its contents are overridden below)
     BandSlot B = slots[owner];
     if (!valid) { B.inc_bin = 0; B.rows = 0; B.ipn = 0; B.bin_hi = -1; }  // idle segment: harmless addresses, nothing scored
     const int B_ip_lo = B.ipn & 0xffff, B_ncols = (int)((unsigned)B.ipn >> 16);
@@ -164,11 +152,7 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
     const unsigned long long amb = ballot64(valid && (second <= T || overflow)), surv = ballot64(valid && best <= T);
     const unsigned long long segmask = S == 64 ? ~0ULL : (((1ULL << (S & 63)) - 1ULL) << ((q * S) & 63));
     const bool bad = (amb & segmask) != 0ULL || __popcll(surv & segmask) != 1 || !(gmin < 1e300);
-    if (valid && ((!bad && best <= T) || (bad && sl == 0))) res[q] = bad ? -1 : bflat;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (take) my_flat = res[rank];  // -1: undecided here, left to k_invert
+    if (valid && ((!bad && best <= T) || (bad && sl == 0))) res[owner] = bad ? -1 : bflat;  // -1: undecided here, left to k_invert_list
     if (COUNT) {
         unsigned c = ncand;
         for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
@@ -182,9 +166,8 @@ template <typename T, typename TO, bool CR, bool COUNT>
 __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_invert_band(DevTables L, KArgs A)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __shared__ BandSlot slots[XSW_BAND_WG_WAVES][64];  // search parameters of the wave's 64 pixels
-    __shared__ int map_[XSW_BAND_WG_WAVES][32];        // pass: segment -> owner lane
-    __shared__ int res_[XSW_BAND_WG_WAVES][32];        // pass: segment -> winning flat index (or -1)
+    __shared__ BandSlot slots[XSW_BAND_WG_WAVES][64];  // search parameters of the wave's eligible pixels, sorted by window class
+    __shared__ int res_[XSW_BAND_WG_WAVES][64];        // slot -> winning flat index (or -1)
     // same tile walk as k_invert (XCD x owns a contiguous range of tile columns, line groups fastest), as a 2-D grid so that
     // no division is needed: blockIdx.x = xcd + 8 * line group, blockIdx.y = tile column inside the XCD's range (workgroups
     // are dealt to the XCDs round-robin in linear order, x fastest: the XCD of a workgroup is still blockIdx.x & 7)
@@ -201,7 +184,7 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_inve
 
     int flags, my_flat = -1, my_icr = -1;
     unsigned cand = 0;
-    unsigned long long cls[6], seen_all = 0;
+    int pos = -1, first[6] = {0, 0, 0, 0, 0, 0}, ncls[6] = {0, 0, 0, 0, 0, 0};  // slot of this lane's pixel; slot range of each class
     {
         // ---- stage 1, one pixel per lane: classify, incidence bin, upper bound along the a-priori direction, window
         Pixel P;
@@ -222,6 +205,35 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_inve
             ncols_p = W.ip_hi - W.ip_lo + 1;
             const bool need = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0 && !loose && ncols_p >= 1 && nrows_p >= 1;
             eligb = need && W.w_hi < L.mono_rows[need ? P.i_inc : 0];  // the window stays inside the monotone rows
+            if (COUNT) cand += (unsigned)__popcll(__ballot(eligb)) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)) + (XSW_BAND_RAYS - 1) * 2 * XSW_RAY_SIDE_STEPS);
+            // class of a window: widths (1..2, 3..4, 5..8, 9..16, 17..32, more) * K directions.  The slots are written SORTED by
+            // class (slot = pixels of narrower classes + rank inside the class): a pass takes the next 64/S slots of its class,
+            // no per-pass ranking, and a lane picks its result up from its slot once, after the last pass
+            constexpr int BK = XSW_BAND_K;
+            const int wq = (ncols_p + BK - 1) / BK;
+            const int myc = !eligb ? 6 : (wq <= 2 ? 0 : min(31 - __clz(wq - 1), 5));
+            int base = 0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const unsigned long long m = __ballot(myc == c);
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                pos = myc == c ? base + rank : pos;
+                first[c] = base;
+                ncls[c] = __popcll(m);
+                base += ncls[c];
+            }
+#ifndef XSW_BAND_NO_PROMOTE
+            // the pixels a class would leave for a part-filled last pass move up into the next wider class when they fit into
+            // ITS part-filled last pass (their slots lie right before that class's: only the boundary moves; a narrow window in
+            // a wide segment merely leaves lanes idle): one pass less each time
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                const int np = 64 / (2 << c), npn = np / 2;  // pixels per pass of this class / of the next
+                const int rem = ncls[c] % np;
+                const int added = (ncls[c + 1] + rem + npn - 1) / npn - (ncls[c + 1] + npn - 1) / npn;
+                if (rem > 0 && added == 0) { ncls[c] -= rem; ncls[c + 1] += rem; first[c + 1] -= rem; }
+            }
+#endif
             if (eligb) {
                 BandSlot b;
                 const double ah = 0.5 * P.a_re, bh = 0.5 * P.b_eff;
@@ -240,36 +252,33 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_inve
                 if (bhi < XSW_INV_BINS && !(fma((double)bhi, width, t0) > b.thr_hi)) bhi = XSW_INV_BINS;
                 b.inc_bin = P.i_inc | (bin << 16); b.rows = W.w_lo | (W.w_hi << 16); b.ipn = W.ip_lo | (ncols_p << 16);
                 b.bin_hi = bhi < XSW_INV_BINS ? bhi : -1;
-                slots[wv][lane] = b;
+                slots[wv][pos] = b;
+                res_[wv][pos] = -1;
             }
-            if (COUNT) cand += (unsigned)__popcll(__ballot(eligb)) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)) + (XSW_BAND_RAYS - 1) * 2 * XSW_RAY_SIDE_STEPS);
         }
-        constexpr int BK = XSW_BAND_K;
-        // class of a window: widths (1..2, 3..4, 5..8, 9..16, 17..32, more) * K directions
-        const int wq = (ncols_p + BK - 1) / BK;
-        const int myc = !eligb ? 6 : (wq <= 2 ? 0 : min(31 - __clz(wq - 1), 5));
-        unsigned long long seen = 0;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            cls[c] = __ballot(myc == c);
-            seen |= cls[c];
-        }
-        seen_all = seen;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- stage 2: band passes, narrowest windows first (most pixels per pass)
     {
         constexpr int BK = XSW_BAND_K;
-        auto run = [&](auto seg, unsigned long long m) {
+        auto run = [&](auto seg, int c) {
             constexpr int S = decltype(seg)::value;
-            while (m) co_band_pass<S, BK, COUNT>(L, A.inv_dsig_co, lane, slots[wv], map_[wv], res_[wv], m, my_flat, cand);
+            for (int p = 0; p < ncls[c]; p += 64 / S)
+                co_band_pass<S, BK, COUNT>(L, A.inv_dsig_co, lane, slots[wv], res_[wv], first[c] + p, min(64 / S, ncls[c] - p), cand);
         };
-        run(std::integral_constant<int, 2>{}, cls[0]);
-        run(std::integral_constant<int, 4>{}, cls[1]);
-        run(std::integral_constant<int, 8>{}, cls[2]);
-        run(std::integral_constant<int, 16>{}, cls[3]);
-        run(std::integral_constant<int, 32>{}, cls[4]);
-        run(std::integral_constant<int, 64>{}, cls[5]);
+        run(std::integral_constant<int, 2>{}, 0);
+        run(std::integral_constant<int, 4>{}, 1);
+        run(std::integral_constant<int, 8>{}, 2);
+        run(std::integral_constant<int, 16>{}, 3);
+        run(std::integral_constant<int, 32>{}, 4);
+        run(std::integral_constant<int, 64>{}, 5);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (pos >= 0) my_flat = res_[wv][pos];  // -1: undecided by its pass
     const bool need_co = (flags & F_NEED_CO) != 0;
     bool unresolved = in && need_co && my_flat < 0;  // not eligible, or undecided by its pass
 
@@ -293,7 +302,7 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_inve
     if (COUNT && A.stats) {
         const unsigned long long done_co = __ballot(in && need_co && my_flat >= 0), done_cr = __ballot(need_cr && !unresolved);
 #ifdef XSW_DEBUG_REASONS  // pixels_exact := not-eligible count | undecided-by-pass count << 32 (experiments only)
-        const unsigned long long noel = __ballot(in && need_co && !((seen_all >> lane) & 1ULL)), und = __ballot(in && need_co && ((seen_all >> lane) & 1ULL) && my_flat < 0);
+        const unsigned long long noel = __ballot(in && need_co && !(pos >= 0)), und = __ballot(in && need_co && (pos >= 0) && my_flat < 0);
         if (lane == 0) atomicAdd(&A.stats[2], (unsigned long long)__popcll(noel) | ((unsigned long long)__popcll(und) << 32));
 #endif
         if (lane == 0) {
