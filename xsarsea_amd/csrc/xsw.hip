@@ -361,6 +361,11 @@ static int install_co(xsw_ctx *c, const xsw_lut *l, const double *d_dense)
     if ((rc = upload(c, c->co_allocs, l->phi, nP, &T.phi))) return rc;
     if ((rc = upload(c, c->co_allocs, cp.data(), nP, &T.cphi))) return rc;
     if ((rc = upload(c, c->co_allocs, sp.data(), nP, &T.sphi))) return rc;
+    {
+        std::vector<double> cs((size_t)2 * nP);
+        for (int i = 0; i < nP; ++i) { cs[2 * i] = cp[i]; cs[2 * i + 1] = sp[i]; }
+        if ((rc = upload(c, c->co_allocs, cs.data(), cs.size(), &T.csphi))) return rc;
+    }
     // output-side tables: caller's values, or the host libm's (see xsw.h)
     {
         std::vector<double> od((size_t)4 * nP), ab((size_t)nW * nP), dd((size_t)4 * nW * nP);

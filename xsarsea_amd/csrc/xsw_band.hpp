@@ -108,7 +108,8 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
             act[j] = valid && col < B_ncols;
             ip[j] = B_ip_lo + (act[j] ? col : 0);
             const unsigned ipB = (unsigned)ip[j] * 8u;
-            U[j] = 2.0 * (B.ah * *(const double *)((const char *)L.cphi + ipB) + B.bh * *(const double *)((const char *)L.sphi + ipB));
+            const double2 cs = *(const double2 *)((const char *)L.csphi + 2u * ipB);
+            U[j] = 2.0 * (B.ah * cs.x + B.bh * cs.y);
             off0[j] = slice0 + ipB;
         }
         // rows to look at: from the tabulated row at or below the band's first to the one at or above its last, inside the window
