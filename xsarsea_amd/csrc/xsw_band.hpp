@@ -36,12 +36,14 @@ namespace xsw {
 #ifndef XSW_BAND_WALK_MAX
 #define XSW_BAND_WALK_MAX 16
 #endif
-// K directions per lane and the occupancy the kernel is compiled for.  Measured at 20000 x 20000 (band kernel alone):
-// K = 1 at 8 waves/SIMD (63 VGPRs, no scratch) 94.7 ms; K = 2 at 6 waves (80 VGPRs) 101.0 ms, forced to 7 / 8 waves
-// 101.5 / 101.9 ms (spills at 8); K = 1 at 7 waves 116 ms per step: with one direction per lane the pass is short enough
-// for the eighth wave to pay, and the walk that seeds the second direction costs what the wider lane saves.
+// K directions per lane and the occupancy the kernel is compiled for.  Measured at 20000 x 20000 (band kernel alone).
+// With the per-column bisection (first half of round 2): K = 1 at 8 waves/SIMD 94.7 ms; K = 2 (adjacent directions, the second
+// seeded from the first by a walk) at 6 / 7 / 8 waves 101.0 / 101.5 / 101.9 ms.  With the inverse-row table no direction needs
+// its neighbour: K directions are taken BLOCKED (lane sl: directions sl, sl + S, ...), so every load of a segment reads
+// contiguous table / LUT words (interleaved, each load touched the same cache lines twice: 61.6 ms against 56.2 for K = 1);
+// blocked K = 1 / 2 / 3 / 4: 53.9 / 52.8 / 57.2 / 63.3 ms (K = 3, 4 spill): half the passes, the same loads.
 #ifndef XSW_BAND_K
-#define XSW_BAND_K 1
+#define XSW_BAND_K 2
 #endif
 #ifndef XSW_BAND_RAY_D
 #define XSW_BAND_RAY_D 2
@@ -104,7 +106,7 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
         double U[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const int col = K * sl + j + S * K * ch;
+            const int col = sl + S * j + S * K * ch;  // blocked: the lanes of a segment read contiguous directions in every load
             act[j] = valid && col < B_ncols;
             ip[j] = B_ip_lo + (act[j] ? col : 0);
             const unsigned ipB = (unsigned)ip[j] * 8u;
