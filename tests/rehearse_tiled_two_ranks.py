@@ -1,0 +1,53 @@
+"""Hand-run rehearsal (not collected by pytest): `multi_gpu.invert_from_model_tiled` with REAL inversions, two ranks on ONE
+MI355X (gloo gather through host memory; RCCL needs two devices), compared on rank 0 with the single-process call on the
+full raster.  The parent never touches the GPU (its children are started by spawn).
+    python tests/rehearse_tiled_two_ranks.py        -> profiles/r02_tiled_two_ranks.txt holds the output of the run kept"""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import warnings
+        import xsarsea_amd
+        from xsarsea_amd import multi_gpu, windspeed
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_gpu_kernel import synthetic_scene
+        xsarsea_amd.options.device = 0
+        warnings.simplefilter("ignore")
+        inc, s_vv, s_vh, dsig, anc = synthetic_scene(301, 517, np.float32, 9)
+        mono = multi_gpu.invert_from_model_tiled(inc, s_vv, ancillary_wind=anc, model="gmf_cmod5n")
+        dual = multi_gpu.invert_from_model_tiled(inc, s_vv, s_vh, ancillary_wind=anc, dsig_cr=dsig, model=("gmf_cmod5n", "gmf_s1_v2"))
+        if rank == 0:
+            ref_m = windspeed.invert_from_model(inc, s_vv, ancillary_wind=anc, model="gmf_cmod5n")
+            ref_d = windspeed.invert_from_model(inc, s_vv, s_vh, ancillary_wind=anc, dsig_cr=dsig, model=("gmf_cmod5n", "gmf_s1_v2"))
+            eq = lambda a, b: bool(np.array_equal(np.asarray(a).view(np.uint64), np.asarray(b).view(np.uint64)))
+            ret["mono"] = eq(mono, ref_m)
+            ret["dual"] = eq(dual[0], ref_d[0]) and eq(dual[1], ref_d[1])
+            ret["shape"] = tuple(np.shape(mono))
+        else:
+            assert mono is None and dual is None
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(worker, args=(2, port, ret), nprocs=2, join=True)
+        print("invert_from_model_tiled, 2 ranks on one device (gloo): raster", ret.get("shape"), "mono bit-equal to the single-process call:",
+              ret.get("mono"), "dual:", ret.get("dual"))
+        sys.exit(0 if ret.get("mono") and ret.get("dual") else 1)

@@ -117,3 +117,57 @@ def test_gather_rows_gloo_world2(lines):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), lines, samples, ret), nprocs=world, join=True)
     assert ret.get("ok") is True
+
+
+def _tiled_worker(rank, world, port, lines, samples, ret):
+    import numpy as np
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(5)  # the same full rasters on every rank
+        inc = rng.uniform(20, 45, (lines, samples)).astype(np.float32)
+        s_co = rng.uniform(0.01, 0.2, (lines, samples)).astype(np.float32)
+        s_cr = rng.uniform(0.001, 0.01, (lines, samples)).astype(np.float32)
+        anc = (rng.normal(0, 8, (lines, samples)) + 1j * rng.normal(0, 8, (lines, samples))).astype(np.complex64)
+        dsig = rng.uniform(0.05, 0.5, (lines, samples)).astype(np.float32)
+        seen = {}
+
+        def fake_invert(i, a, b=None, /, ancillary_wind=None, dsig_cr=0.1, model=None):  # stands in for the GPU call
+            seen["shape"] = a.shape
+            assert i.shape == a.shape == ancillary_wind.shape and (b is None or b.shape == a.shape)
+            co = (i + 2 * a).astype(np.float64) * ancillary_wind.astype(np.complex128)
+            if b is None:
+                return co
+            return co, (b * np.asarray(dsig_cr)).astype(np.complex128)
+
+        mono = multi_gpu.invert_from_model_tiled(inc, s_co, ancillary_wind=anc, model="m", invert=fake_invert)
+        l0, l1 = multi_gpu.tile_bounds(lines, world, rank)
+        ok = seen["shape"] == (l1 - l0, samples)
+        dual = multi_gpu.invert_from_model_tiled(inc, s_co, s_cr, ancillary_wind=anc, dsig_cr=dsig, model=("a", "b"), invert=fake_invert)
+        if rank == 0:
+            ok = ok and np.array_equal(mono, fake_invert(inc, s_co, ancillary_wind=anc))
+            e0, e1 = fake_invert(inc, s_co, s_cr, ancillary_wind=anc, dsig_cr=dsig)
+            ok = ok and isinstance(dual, tuple) and np.array_equal(dual[0], e0) and np.array_equal(dual[1], e1)
+            ret["ok"] = bool(ok)
+        else:
+            assert mono is None and dual is None
+            ret[f"ok{rank}"] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,lines", [(2, 11), (3, 8)])
+def test_invert_from_model_tiled_gloo(world, lines):
+    """User-level entry: every rank passes the full rasters, inverts its own lines (stand-in callable: no GPU here), rank 0
+    gets the full mono / dual results, the others None; uneven tiles, raster-valued dsig_cr sliced with the rest."""
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_tiled_worker, args=(world, _free_port(), lines, 37, ret), nprocs=world, join=True)
+        assert ret.get("ok") is True and all(ret.get(f"ok{r}") for r in range(1, world))
+
+
+def test_invert_from_model_tiled_without_a_process_group():
+    import numpy as np
+    a = np.ones((4, 5), np.float32)
+    out = multi_gpu.invert_from_model_tiled(a, a, ancillary_wind=a.astype(np.complex64), invert=lambda i, s, ancillary_wind=None: s * 3)
+    assert np.array_equal(out, a * 3)

@@ -101,3 +101,43 @@ def gather_rows(tile, lines, dst=0, group=None, out=None):
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return out if rank == dst else None
+
+
+def invert_from_model_tiled(inc, sigma0, sigma0_dual=None, /, *, dst=0, group=None, invert=None, **kwargs):
+    """`windspeed.invert_from_model` on a raster tiled over the ranks of a `torch.distributed` job (one process per GPU;
+    the reference's way to parallelise the same call is dask row blocks, windspeed/windspeed.py:350-364).
+
+    Every rank calls this with the SAME full-size array-likes (numpy or anything sliceable along axis 0: memory-mapped files,
+    lazily loaded arrays -- only the rank's own lines `tile_bounds(lines, world, rank)` are touched); `ancillary_wind` and a
+    raster `dsig_cr` in `kwargs` are sliced the same way.  The rank inverts its lines on its own GPU (`options.device`, which
+    `xsarsea_amd` sets from LOCAL_RANK) and the tiles are gathered on rank `dst` (RCCL send/recv under the "nccl" backend,
+    through host memory under "gloo").  Returns what `invert_from_model` returns (an array, or a tuple of two for dual-pol)
+    for the full raster on rank `dst`, None on the other ranks.  Without an initialised process group it is the plain call.
+    `invert`: the per-tile callable (default `windspeed.invert_from_model`; tests on machines without a GPU pass a stand-in).
+    """
+    import numpy as np
+
+    if invert is None:
+        from .windspeed import invert_from_model as invert
+    if not (dist.is_available() and dist.is_initialized()):
+        return invert(inc, sigma0, *(() if sigma0_dual is None else (sigma0_dual,)), **kwargs)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lines = int(np.shape(sigma0)[0])
+    l0, l1 = tile_bounds(lines, world, rank)
+
+    def cut(a):
+        return a[l0:l1] if (a is not None and np.ndim(a) >= 1 and np.shape(a)[0] == lines) else a
+
+    kw = {k: (cut(v) if k in ("ancillary_wind", "dsig_cr") else v) for k, v in kwargs.items()}
+    res = invert(cut(inc), cut(sigma0), *(() if sigma0_dual is None else (cut(sigma0_dual),)), **kw)
+    parts = res if isinstance(res, tuple) else (res,)
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    outs = []
+    for p in parts:
+        t = torch.as_tensor(np.ascontiguousarray(np.asarray(p))).to(dev)
+        full = gather_rows(t, lines, dst=dst, group=group)
+        outs.append(full.cpu().numpy() if rank == dst else None)
+    if rank != dst:
+        return None
+    return tuple(outs) if isinstance(res, tuple) else outs[0]
