@@ -5,26 +5,34 @@
 // own: both cost terms are >= 0, so ((LUT - s)/dsig)^2 <= J_ub, i.e. |LUT - s| <= d = |dsig| sqrt(J_ub), is necessary for
 // the argmin.  Where the LUT columns are non-decreasing in wind speed over the rows of the window (L.mono_rows, checked at
 // upload; CMOD5.N itself turns over beyond 24..40 m/s below 41 deg of incidence), that is ONE row interval per direction
-// -- 1..4 candidates instead of the 7..40 rows of the window column: 31 instead of 638 candidates per pixel on the
-// benchmark scene.
+// -- 1..4 candidates instead of the 7..40 rows of the window column: 22 (three-ray bound) instead of 552 candidates per
+// pixel on the benchmark scene.
 //
-// Two kernels share a launch (xsw.hip: launch_invert): this one finishes every pixel the band rule decides and writes a
-// status byte per pixel; `k_invert` (the general kernel: window sweep, exact scan, any LUT) then handles the pixels left
-// over (status 1: window outside the monotone rows, non-finite inputs, near-ties, cross-pol sweeps the interval rule
-// cannot do) and returns at once on strips that have none.  Keeping the rare, register-hungry paths out of this kernel is
-// what lets it run at a higher occupancy than the one-kernel form did.
+// Two kernels make one inversion (xsw.hip: launch_invert): this one finishes every pixel the band rule decides and appends
+// the others to a work list (one atomicAdd per wave); `k_invert_list` (the general algorithm: window sweep, exact scan, any
+// LUT) then inverts exactly those (window outside the monotone rows, non-finite inputs, near-ties, bands longer than
+// XSW_BAND_MAX rows, cross-pol pixels the interval rule cannot decide).  Keeping the rare, register-hungry paths out of this
+// kernel is what lets it run at 8 waves per SIMD.
+//
+// Finding the interval: a monotone column is inverted ONCE, at LUT install (L.inv_rows: for 2048 dB thresholds per incidence
+// slice, the first row of every direction at or above the threshold; xsw_lutbuild.hpp).  The largest threshold <= s - d
+// gives a row at or below the band's first, the smallest threshold > s + d one past a row at or above its last: two 2-byte
+// reads per direction instead of a bisection, and the number of rows to score is known before the sweep starts.
 //
 // Work decomposition: a workgroup = 4 waves = a tile of 4 lines x 64 samples (as k_invert); lane i loads pixel i, finds its
-// incidence bin, the upper bound along the a-priori direction and the window (co_window_lanes), and parks the pixel's search
-// parameters in an LDS slot.  Then the wave takes 64/S pixels per pass, one per S-lane segment; a lane owns K adjacent
-// directions of one pixel (classes S*K = 4, 8, ..., 128 directions; wider windows loop over chunks in the S = 64 class):
-//   * the lane bisects its first column inside the window for the first row with LUT >= s - d (wave-uniform trip count);
-//     the next column starts from its neighbour's row and walks (the contour moves by 0..2 rows per degree);
-//   * it then scores upwards while LUT <= s + d (a few trips; scores are formed directly, no forward differences);
+// incidence bin, the upper bound along the a-priori direction and two neighbours (co_window_lanes), the window and the two
+// threshold bins, and parks the pixel's search parameters in an LDS slot -- slots SORTED by window class, so that a pass takes
+// the next 64/S slots of its class (no per-pass ranking) and every lane picks its result up once, after the last pass.  The
+// wave then takes 64/S pixels per pass, one per S-lane segment; a lane owns K directions of one pixel, blocked (sl, sl + S:
+// every load of a segment reads contiguous words); classes S*K = 4, 8, ..., 128 directions, wider windows loop over chunks
+// in the S = 64 class:
+//   * the lane reads its directions' first / last candidate rows from the table, clips them to the window, and scores that
+//     many rows (a row counts if s - d <= LUT <= s + d; scores are formed directly, no forward differences);
 //   * segment argmin by DPP; the unique candidate within eps of the minimum is the reference's argmin (same settle rule as
-//     co_box_search); the winner lane posts it to the owner lane through LDS.  Near-ties, several survivors, bands longer
-//     than XSW_BAND_MAX -> left to k_invert.
-// The cross-pol search (dual-pol) runs one pixel per lane with the interval rule of search_cr_interval.
+//     co_box_search); the winner lane writes it next to the slot.  Near-ties, several survivors, runs longer than
+//     XSW_BAND_MAX -> work list.
+// The cross-pol search (dual-pol) runs one pixel per lane: search_cr_scan (table + scan of the admissible interval), or the
+// interval rule of search_cr_interval when the cross-pol table is absent.
 #pragma once
 #include "xsw_device.hpp"
 
@@ -32,9 +40,6 @@ namespace xsw {
 
 #ifndef XSW_BAND_MAX
 #define XSW_BAND_MAX 64
-#endif
-#ifndef XSW_BAND_WALK_MAX
-#define XSW_BAND_WALK_MAX 16
 #endif
 // K directions per lane and the occupancy the kernel is compiled for.  Measured at 20000 x 20000 (band kernel alone).
 // With the per-column bisection (first half of round 2): K = 1 at 8 waves/SIMD 94.7 ms; K = 2 (adjacent directions, the second
