@@ -216,3 +216,42 @@ def band_pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig, 
     if len(keep) != 1:
         return fallback()  # the device settles near-ties in the window sweep
     return keep[0][1], keep[0][2], len(cand) + nray, True
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Inverse-row table (round 2, second half): the band's rows without a search.  A monotone column is inverted once:
+# inv[b] = first row r < mono with col[r] >= t_b,  t_b = fma(b, width, t0)  (else mono),  inv[0] = 0  (xsw_lutbuild.hpp:
+# k_inv_range / k_inv_rows).  For a pixel, the largest t_b <= s - d gives a row at or below the band's first row, the
+# smallest t_b > s + d one past a row at or above its last (co_band_pass / stage 1 of k_invert_band, xsw_band.hpp).
+def inverse_rows(col, mono, t0, width, bins):
+    """The table of one column: numpy restatement of k_inv_rows."""
+    out = np.zeros(bins, dtype=np.int64)
+    r = 0
+    for b in range(1, bins):
+        thr = b * width + t0  # the kernel uses fma; the rounding difference is what the in-kernel checks absorb either way
+        while r < mono and col[r] < thr:
+            r += 1
+        out[b] = r
+    return out
+
+
+def table_bins(t0, width, inv_width, bins, thr_lo, thr_hi):
+    """(lower bin, upper bin or -1) as stage 1 of k_invert_band picks them."""
+    b = int(min(max((thr_lo - t0) * inv_width, 0.0), float(bins - 1)))
+    if b > 0 and b * width + t0 > thr_lo:
+        b -= 1
+    if b > 0 and b * width + t0 > thr_lo:
+        b = 0
+    bh = int(min(max((thr_hi - t0) * inv_width, -1.0), float(bins))) + 1
+    if bh < bins and not (bh * width + t0 > thr_hi):
+        bh += 1
+    if bh < bins and not (bh * width + t0 > thr_hi):
+        bh = bins
+    return b, (bh if bh < bins else -1)
+
+
+def band_rows_from_table(inv, b_lo, b_hi, w_lo, w_hi):
+    """[first, last] rows a lane looks at (last < first: none), as co_band_pass clips them."""
+    first = max(int(inv[b_lo]), w_lo)
+    last = min(int(inv[b_hi]) - 1, w_hi) if b_hi >= 0 else w_hi
+    return first, last

@@ -106,3 +106,61 @@ def test_band_rule_never_excludes_the_argmin(kind):
         assert used > 0.3 * n and np.mean(evaluated) < 120, (used, np.mean(evaluated))
     # CMOD5.N itself saturates and decreases at high wind / low incidence: the monotone prefix is a per-slice property
     assert pm.mono_rows(co[0]) < len(w_ax) and (kind in ("noisy", "rolloff") or pm.mono_rows(co[-1]) == len(w_ax))
+
+
+@pytest.mark.parametrize("kind", ["smooth", "quantised", "steps", "flat"])
+def test_inverse_row_table_interval_is_a_tight_superset_of_the_band(kind):
+    """The rows a lane reads off the inverse-row table always contain the exact band  {r in window: s - d <= col[r] <= s + d}
+    of a monotone column -- for thresholds ON table values, ON grid thresholds, below / above the column, and windows
+    clipped anywhere -- and exceed it by no more than the rows that share a grid bin with its ends (thresholds inside the grid)."""
+    import prune_model as pm
+    rng = np.random.default_rng({"smooth": 1, "quantised": 2, "steps": 3, "flat": 4}[kind])
+    bins = 256
+    for case in range(300):
+        n = int(rng.integers(2, 200))
+        if kind == "flat":
+            col = np.full(n, rng.normal())
+        else:
+            col = np.cumsum(rng.gamma(0.7, 0.08, n)) + rng.normal(-20, 5)
+            if kind == "quantised":
+                col = np.round(col / 0.25) * 0.25
+            if kind == "steps":
+                col = np.repeat(col[:: 7], 7)[:n] if n >= 7 else col
+        mono = n if rng.random() < 0.7 else int(rng.integers(1, n + 1))
+        lo, hi = col[:mono].min(), col[:mono].max()
+        width = (hi - lo) / bins
+        ok = width > 0
+        t0, width, inv_width = (lo, width, 1.0 / width) if ok else (0.0, 0.0, 0.0)
+        inv = pm.inverse_rows(col, mono, t0, width, bins)
+        assert inv[0] == 0 and np.all(np.diff(inv) >= 0) and inv[-1] <= mono
+        for _ in range(20):
+            mode = rng.integers(0, 5)
+            if mode == 0:
+                s = col[rng.integers(0, mono)]
+            elif mode == 1:
+                s = t0 + rng.integers(0, bins + 1) * width
+            elif mode == 2:
+                s = rng.uniform(lo - 1, hi + 1)
+            elif mode == 3:
+                s = lo - rng.uniform(0, 3)
+            else:
+                s = hi + rng.uniform(0, 3)
+            d = float(rng.choice([0.0, 1e-12, 0.01, 0.3, 5.0]))
+            thr_lo, thr_hi = s - d, s + d
+            w_hi = int(rng.integers(0, mono))            # eligible windows end inside the monotone rows
+            w_lo = int(rng.integers(0, w_hi + 1))
+            b_lo, b_hi = pm.table_bins(t0, width, inv_width, bins, thr_lo, thr_hi)
+            assert b_lo == 0 or b_lo * width + t0 <= thr_lo
+            assert b_hi == -1 or b_hi * width + t0 > thr_hi
+            first, last = pm.band_rows_from_table(inv, b_lo, b_hi, w_lo, w_hi)
+            rows = np.arange(w_lo, w_hi + 1)
+            exact = rows[(col[rows] >= thr_lo) & (col[rows] <= thr_hi)]
+            if exact.size:
+                assert first <= exact[0] and exact[-1] <= last, (kind, case, s, d)
+            # tightness: rows read but outside the band lie within one grid bin of its ends (or the grid is degenerate)
+            if ok and last >= first:
+                extra = [r for r in range(first, last + 1) if not (thr_lo <= col[r] <= thr_hi)]
+                for r in extra:
+                    assert (col[r] < thr_lo and col[r] >= thr_lo - width * (1 + 1e-9) - 1e-12 and b_lo > 0) or \
+                           (col[r] < thr_lo and b_lo in (0, bins - 1)) or \
+                           (col[r] > thr_hi and (b_hi == -1 or col[r] < thr_hi + width * (1 + 1e-9) + 1e-12)), (kind, case, r)
