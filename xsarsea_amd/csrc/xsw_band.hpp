@@ -132,9 +132,13 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
         }
 #pragma unroll 1
         for (int t = 0; t < XSW_BAND_MAX; ++t) {  // scalar trip counter; the loop leaves as soon as no lane has rows left
-            if (ballot64(t < nmax) == 0ULL) break;
+            unsigned long long left[K], any_left = 0ULL;
+#pragma unroll
+            for (int j = 0; j < K; ++j) { left[j] = ballot64(t < nrow[j]); any_left |= left[j]; }
+            if (any_left == 0ULL) break;
 #pragma unroll
             for (int j = 0; j < K; ++j) {
+                if (left[j] == 0ULL) continue;  // wave-uniform: the j-th directions of this pass have no rows left (often the upper half)
                 const int rc = min(r[j] + t, w_hi);
                 const double v = ld_co(base, off0[j], rc, rowB);
                 const bool inb = t < nrow[j] && v >= thr_lo && v <= thr_hi;  // the end rows may lie just outside the band
