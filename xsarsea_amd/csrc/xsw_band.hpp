@@ -196,7 +196,8 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_inve
 
     int flags, my_flat = -1, my_icr = -1;
     unsigned cand = 0;
-    int pos = -1, first[6] = {0, 0, 0, 0, 0, 0}, ncls[6] = {0, 0, 0, 0, 0, 0};  // slot of this lane's pixel; slot range of each class
+    constexpr int NC = 11;  // window classes: S lanes x K directions = 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128 (and wider: chunks)
+    int pos = -1, first[NC] = {}, ncls[NC] = {};  // slot of this lane's pixel; slot range of each class
     {
         // ---- stage 1, one pixel per lane: classify, incidence bin, upper bound along the a-priori direction, window
         Pixel P;
@@ -218,15 +219,19 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_inve
             const bool need = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0 && !loose && ncols_p >= 1 && nrows_p >= 1;
             eligb = need && W.w_hi < L.mono_rows[need ? P.i_inc : 0];  // the window stays inside the monotone rows
             if (COUNT) cand += (unsigned)__popcll(__ballot(eligb)) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)) + (XSW_BAND_RAYS - 1) * 2 * XSW_RAY_SIDE_STEPS);
-            // class of a window: widths (1..2, 3..4, 5..8, 9..16, 17..32, more) * K directions.  The slots are written SORTED by
-            // class (slot = pixels of narrower classes + rank inside the class): a pass takes the next 64/S slots of its class,
-            // no per-pass ranking, and a lane picks its result up from its slot once, after the last pass
-            constexpr int BK = XSW_BAND_K;
-            const int wq = (ncols_p + BK - 1) / BK;
-            const int myc = !eligb ? 6 : (wq <= 2 ? 0 : min(31 - __clz(wq - 1), 5));
+            // class of a window by its number of directions n: the smallest of 4, 6, 8, 12, ..., 96, 128 that holds it, i.e. S lanes
+            // x K directions per lane with K = 2 (capacity 2S) or 3 (capacity 3S, S half as large: twice the pixels per pass of
+            // the next power of two).  The slots are written SORTED by class (slot = pixels of narrower classes + rank inside the
+            // class): a pass takes the next 64/S slots of its class, no per-pass ranking, and a lane picks its result up from its
+            // slot once, after the last pass
+            int myc = NC;
+            if (eligb) {
+                const int p2 = 31 - __clz(max(ncols_p, 2) - 1);  // 2^p2 < n <= 2^(p2 + 1)
+                myc = ncols_p <= 4 ? 0 : min(2 * p2 - 3 + (ncols_p > (3 << (p2 - 1)) ? 1 : 0), NC - 1);
+            }
             int base = 0;
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
+            for (int c = 0; c < NC; ++c) {
                 const unsigned long long m = __ballot(myc == c);
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                 pos = myc == c ? base + rank : pos;
@@ -239,8 +244,8 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_inve
             // ITS part-filled last pass (their slots lie right before that class's: only the boundary moves; a narrow window in
             // a wide segment merely leaves lanes idle): one pass less each time
 #pragma unroll
-            for (int c = 0; c < 5; ++c) {
-                const int np = 64 / (2 << c), npn = np / 2;  // pixels per pass of this class / of the next
+            for (int c = 0; c + 1 < NC; ++c) {
+                const int np = 64 / (2 << (c >> 1)), npn = 64 / (2 << ((c + 1) >> 1));  // pixels per pass of this class / of the next
                 const int rem = ncls[c] % np;
                 const int added = (ncls[c + 1] + rem + npn - 1) / npn - (ncls[c + 1] + npn - 1) / npn;
                 if (rem > 0 && added == 0) { ncls[c] -= rem; ncls[c + 1] += rem; first[c + 1] -= rem; }
@@ -274,18 +279,24 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_inve
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- stage 2: band passes, narrowest windows first (most pixels per pass)
     {
-        constexpr int BK = XSW_BAND_K;
-        auto run = [&](auto seg, int c) {
-            constexpr int S = decltype(seg)::value;
+        auto run = [&](auto seg, auto kk, int c) {
+            constexpr int S = decltype(seg)::value, K = decltype(kk)::value;
             for (int p = 0; p < ncls[c]; p += 64 / S)
-                co_band_pass<S, BK, COUNT>(L, A.inv_dsig_co, lane, slots[wv], res_[wv], first[c] + p, min(64 / S, ncls[c] - p), cand);
+                co_band_pass<S, K, COUNT>(L, A.inv_dsig_co, lane, slots[wv], res_[wv], first[c] + p, min(64 / S, ncls[c] - p), cand);
         };
-        run(std::integral_constant<int, 2>{}, 0);
-        run(std::integral_constant<int, 4>{}, 1);
-        run(std::integral_constant<int, 8>{}, 2);
-        run(std::integral_constant<int, 16>{}, 3);
-        run(std::integral_constant<int, 32>{}, 4);
-        run(std::integral_constant<int, 64>{}, 5);
+        using two = std::integral_constant<int, 2>;
+        using three = std::integral_constant<int, 3>;
+        run(std::integral_constant<int, 2>{}, two{}, 0);
+        run(std::integral_constant<int, 2>{}, three{}, 1);
+        run(std::integral_constant<int, 4>{}, two{}, 2);
+        run(std::integral_constant<int, 4>{}, three{}, 3);
+        run(std::integral_constant<int, 8>{}, two{}, 4);
+        run(std::integral_constant<int, 8>{}, three{}, 5);
+        run(std::integral_constant<int, 16>{}, two{}, 6);
+        run(std::integral_constant<int, 16>{}, three{}, 7);
+        run(std::integral_constant<int, 32>{}, two{}, 8);
+        run(std::integral_constant<int, 32>{}, three{}, 9);
+        run(std::integral_constant<int, 64>{}, two{}, 10);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
