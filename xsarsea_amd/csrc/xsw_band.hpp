@@ -23,9 +23,9 @@
 // incidence bin, the upper bound along the a-priori direction and two neighbours (co_window_lanes), the window and the two
 // threshold bins, and parks the pixel's search parameters in an LDS slot -- slots SORTED by window class, so that a pass takes
 // the next 64/S slots of its class (no per-pass ranking) and every lane picks its result up once, after the last pass.  The
-// wave then takes 64/S pixels per pass, one per S-lane segment; a lane owns K directions of one pixel, blocked (sl, sl + S:
-// every load of a segment reads contiguous words); classes S*K = 4, 8, ..., 128 directions, wider windows loop over chunks
-// in the S = 64 class:
+// wave then takes 64/S pixels per pass, one per S-lane segment; a lane owns K = 2 or 3 directions of one pixel, blocked (sl,
+// sl + S, ...: every load of a segment reads contiguous words); classes S*K = 4, 6, 8, 12, ..., 96, 128 directions, wider
+// windows loop over chunks in the S = 64 class; on each trip a direction group whose lanes have no rows left is skipped:
 //   * the lane reads its directions' first / last candidate rows from the table, clips them to the window, and scores that
 //     many rows (a row counts if s - d <= LUT <= s + d; scores are formed directly, no forward differences);
 //   * segment argmin by DPP; the unique candidate within eps of the minimum is the reference's argmin (same settle rule as
@@ -47,6 +47,8 @@ namespace xsw {
 // its neighbour: K directions are taken BLOCKED (lane sl: directions sl, sl + S, ...), so every load of a segment reads
 // contiguous table / LUT words (interleaved, each load touched the same cache lines twice: 61.6 ms against 56.2 for K = 1);
 // blocked K = 1 / 2 / 3 / 4: 53.9 / 52.8 / 57.2 / 63.3 ms (K = 3, 4 spill): half the passes, the same loads.
+// Final form: K is a property of the window class (2 or 3: capacities S*K = 4, 6, 8, 12, ..., 96, 128; k_invert_band below);
+// XSW_BAND_K only names the K of the measurements above.
 #ifndef XSW_BAND_K
 #define XSW_BAND_K 2
 #endif
