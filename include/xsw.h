@@ -113,7 +113,9 @@ int xsw_ctx_destroy(xsw_ctx *ctx);
 const char *xsw_last_error(const xsw_ctx *ctx); /* ctx may be NULL: last creation error */
 
 /* Launch on a caller-provided hipStream_t (e.g. torch's current stream; NULL = the default stream).
- * A new context launches on a private non-blocking stream; xsw_use_own_stream() returns to it. */
+ * A new context launches on a private non-blocking stream; xsw_use_own_stream() returns to it.
+ * XSW_MEM_DEVICE buffers are read and written in stream order ON THAT STREAM ONLY: a caller whose producers run on another
+ * stream (torch's, say) must either hand that stream over here or synchronise it before xsw_invert / xsw_detrend / ... */
 int xsw_set_stream(xsw_ctx *ctx, void *hip_stream);
 int xsw_use_own_stream(xsw_ctx *ctx);
 int xsw_synchronize(xsw_ctx *ctx);
