@@ -41,7 +41,8 @@ LANE_OPS_PEAK = 7.86e13  # 256 CU x 128 lanes x 2.4 GHz, non-packed (SURVEY.md 8
 OPS_PER_CANDIDATE = 6    # sub, scale, square-accumulate, separable wind term, compare, select
 BYTES_READ_PX = 16       # inc f32 + sigma0 f32 + ancillary complex64   
 BYTES_WRITE_PX = 8       # complex64 wind
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
+PCIE_PEAK_GBS = 64.0      # PCIe Gen5 x16, one direction (MI355X_MICROARCH.md host link)
 
 CONFIGS = {  # BASELINE.json configs (1 is the CPU plumbing case: tests/test_gpu_api.py::test_sigma0_detrend)
     "metric": dict(lines=20000, samples=20000, mode="mono", lut="cmod5n", note="the metric's raster"),
@@ -204,6 +205,18 @@ def cpu_baseline_and_parity(ctx, inc, s_vv, anc, algo, budget_s=14.0):
     cpu = {"value": round(ci.size / t_cpu / 1e6, 6), "unit": "Mpixels/s", "cores": cores, "kind": "port",
            "sample": f"{side}x{side} centre crop of the same raster ({ci.size} px, {t_cpu:.1f} s), "
                      f"oracle/invert_c.c with the reference's (wspd,phi,inc) LUT layout, OpenMP rows"}
+    # the numpy restatement beside it (same temporaries, hence the same memory behaviour, as the reference's
+    # per-pixel numpy expressions; one core -- numba's thread pool is what the C port's OpenMP rows stand for)
+    nside = int(max(8, min(side, math.isqrt(max(int(2.0 / 2e-3), 64)))))  # ~2 s at ~2 ms per pixel
+    l0n, s0n = (ci.shape[0] - nside) // 2, (ci.shape[1] - nside) // 2
+    sub = (slice(l0n, l0n + nside), slice(s0n, s0n + nside))
+    nan_s = np.full((nside, nside), np.nan)
+    t0 = time.perf_counter()
+    n_co, _, n_idx = oinv.invert_numpy(prep, ci[sub], oinv.to_db(cs[sub]), nan_s, nan_s, ca[sub], return_idx=True)
+    t_np = time.perf_counter() - t0
+    cpu["numpy_restatement"] = {"value": round(nside * nside / t_np / 1e6, 6), "unit": "Mpixels/s", "cores": 1,
+                                "sample": f"{nside}x{nside} centre of that crop ({t_np:.1f} s), oracle/invert.py (numpy, float64 temporaries of 499x181 per pixel)",
+                                "equals_c_port": bool(np.array_equal(n_idx[..., :2], o_idx[sub][..., :2]))}
     # GPU on the same crop: strict (host dB, as the reference computes it) and fused device dB
     ctx.synchronize()
     g_strict = ctx.invert_host(ci, sigma0_co=oinv.to_db(cs), anc=ca, sigma0_is_db=True, algo=algo, want_idx=True,
@@ -211,19 +224,31 @@ def cpu_baseline_and_parity(ctx, inc, s_vv, anc, algo, budget_s=14.0):
     g_fused = ctx.invert_host(ci, sigma0_co=cs, anc=ca, algo=algo, want_idx=True, out_dtype=np.complex64)
     valid = o_idx[..., 0] >= 0
 
-    def rel_err(g):
-        ok = valid & np.all(g[2][..., :2] == o_idx[..., :2], axis=-1)
+    def rel_err(g, matched_only):
+        """max over the valid pixels of |(u,v)_gpu - (u,v)_ref| / max(|ref|, 1e-3); matched_only: pixels on the same grid point"""
+        ok = valid & (np.all(g[2][..., :2] == o_idx[..., :2], axis=-1) if matched_only else True)
         if not ok.any():
-            return None
+            return None, 0
         ref = o_co[ok]
-        return float(np.max(np.abs(g[0][ok].astype(np.complex128) - ref) / np.maximum(np.abs(ref), 1e-3)))
+        err = np.abs(g[0][ok].astype(np.complex128) - ref) / np.maximum(np.abs(ref), 1e-3)
+        return float(np.max(err)), int(np.sum(err > 1e-4))
 
+    e_strict, out_strict = rel_err(g_strict, False)
+    e_fused, out_fused = rel_err(g_fused, False)
+    e_fused_same, _ = rel_err(g_fused, True)
     parity = {
-        "crop_pixels": int(ci.size),
+        "crop_pixels": int(ci.size), "valid_pixels": int(valid.sum()),
         "nan_mask_equal": bool(np.array_equal(np.isnan(g_fused[0].real), np.isnan(o_co.real))),
+        # the bit-parity route (sigma0 converted to dB by numpy on the host, as the reference does)
         "index_match_host_db": float(np.mean(np.all(g_strict[2][..., :2] == o_idx[..., :2], axis=-1))),
+        "max_rel_err_uv_c64": e_strict, "pixels_outside_1e-4_host_db": out_strict,
+        # the TIMED route (`value`: sigma0 -> dB fused on the device)
         "index_match_device_db": float(np.mean(np.all(g_fused[2][..., :2] == o_idx[..., :2], axis=-1))),
-        "max_rel_err_uv_c64": rel_err(g_strict),
+        "max_rel_err_uv_c64_device_db": e_fused, "pixels_outside_1e-4_device_db": out_fused,
+        "frac_outside_1e-4_device_db": round(out_fused / max(int(valid.sum()), 1), 8),
+        "max_rel_err_uv_c64_device_db_same_grid_point": e_fused_same,
+        "note": "device_db: the float32 log10 of the fused conversion is correctly rounded, numpy's (the reference's) is a few-ulp SIMD routine; "
+                "the pixels_outside_1e-4_device_db pixels are near-ties that land one grid step (0.1 m/s or 1 deg) away",
         "lut_interp": "unpinned vs xarray.interp (restated as sequential scipy interp1d; DESIGN.md 6)",
     }
     return cpu, parity
@@ -235,6 +260,35 @@ def _profile_json(name):
             return json.load(f)
     except Exception:
         return None
+
+
+_LOADED_CODE_SHA = []
+
+
+def loaded_code_sha():
+    """SHA-256 of the device code (.hip_fatbin) of the libxsw.so this process runs: counter figures measured on other code
+    are not reported (profiles/collect_r03.sh stamps every summary with the hash it was measured on)."""
+    if not _LOADED_CODE_SHA:
+        try:
+            from xsarsea_amd import _build
+            _LOADED_CODE_SHA.append(_build.code_object_sha256())
+        except Exception:
+            _LOADED_CODE_SHA.append(None)
+    return _LOADED_CODE_SHA[0]
+
+
+def fresh_profile(name):
+    """(summary, provenance) of a committed counter summary if it was measured on the loaded library's device code, else
+    (None, {"stale_profile": why})."""
+    tj = _profile_json(name)
+    if not tj:
+        return None, {"stale_profile": f"profiles/{name} absent"}
+    on = tj.get("measured_on") or {}
+    mine = loaded_code_sha()
+    if not on.get("code_sha256") or mine is None or on["code_sha256"] != mine:
+        return None, {"stale_profile": f"profiles/{name} was measured on device code {str(on.get('code_sha256'))[:16]} (commit {on.get('commit')}), "
+                                       f"this run loads {str(mine)[:16]}: counters not reported"}
+    return tj, {"measured_on": on}
 
 
 def time_steps(step, steps, warmup, stream, after=None):
@@ -257,6 +311,64 @@ def time_steps(step, steps, warmup, stream, after=None):
     return dt, float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
 
+def end_to_end_parity_figure(ctx, _lib, inc, s_vv, anc, out, lines, samples, algo):
+    """The bit-parity route with NOTHING left outside the timer: the linear float32 sigma0 raster starts on the host; timed =
+    numpy's float32 log10 on the host thread pool (`_engine._to_db`: the reference's own arithmetic, windspeed.py:126-130) +
+    upload of the dB raster + the kernels (incidence / ancillary wind / output stay resident, as in `value`)."""
+    from xsarsea_amd.windspeed import _engine
+    s_host = s_vv.cpu().numpy()
+    s_db_dev = torch.empty_like(s_vv)
+    best = None
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s_db = _engine._to_db(s_host)
+        t1 = time.perf_counter()
+        s_db_dev.copy_(torch.from_numpy(s_db), non_blocking=False)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        ctx.invert_raw(lines, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, inc.data_ptr(), s_db_dev.data_ptr(), None, None,
+                       anc.data_ptr(), out.data_ptr(), None, algo=algo, sigma0_is_db=True)
+        ctx.synchronize()
+        t3 = time.perf_counter()
+        if best is None or t3 - t0 < best[0]:
+            best = (t3 - t0, t1 - t0, t2 - t1, t3 - t2)
+    px = lines * samples
+    return {"value": round(px / best[0] / 1e6, 1), "unit": "Mpixels/s", "ms": round(best[0] * 1e3, 2),
+            "host_log10_ms": round(best[1] * 1e3, 2), "upload_ms": round(best[2] * 1e3, 2), "kernels_ms": round(best[3] * 1e3, 2),
+            "note": "host numpy float32 log10 (thread pool) + upload of the dB raster (pageable, torch copy) + kernels, all timed; best of 2"}
+
+
+def host_path_figure(inc, s_vv, anc, samples, lines_host=5000):
+    """The public drop-in call on HOST rasters: `invert_from_model(numpy float32 -> numpy complex128)` on the first 5000 lines of
+    the same scene (1e8 pixels at 20000 samples), default options (float32 dB by numpy on the host: bit parity).  Everything is
+    timed: dB pass, page-locked staging, PCIe both ways (16 B/px up, 4 B/px of grid codes down), kernels, host expansion."""
+    import warnings
+    import xsarsea_amd
+    from xsarsea_amd import windspeed
+    lh = min(lines_host, inc.shape[0])
+    h_inc, h_s, h_anc = (t[:lh].contiguous().cpu().numpy() for t in (inc, s_vv, anc))
+    px = lh * samples
+    times = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(4):  # the first call builds / uploads the LUT of the API's own context and pins the staging ring
+            t0 = time.perf_counter()
+            res = windspeed.invert_from_model(h_inc, h_s, ancillary_wind=h_anc, model="gmf_cmod5n")
+            times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    up, down = 16 * px, 4 * px
+    fig = {"workload": f"windspeed.invert_from_model(numpy float32 {lh}x{samples} -> numpy complex128), default options, pageable host arrays",
+           "value": round(px / best / 1e6, 1), "unit": "Mpixels/s", "ms": round(best * 1e3, 2), "first_call_ms": round(times[0] * 1e3, 1),
+           "bytes_over_pcie": up + down,
+           "roofline": {"bound": "pcie", "achieved": round((up + down) / best / 1e9, 2), "peak": PCIE_PEAK_GBS, "unit": "GB/s",
+                        "frac": round((up + down) / best / 1e9 / PCIE_PEAK_GBS, 4),
+                        "note": "16 B/px up (incidence, dB sigma0, ancillary wind) + 4 B/px down (grid codes; the complex128 raster is expanded on the host)"},
+           "host_threads": xsarsea_amd.options.host_threads or int(os.environ.get("XSW_HOST_THREADS", "8"))}
+    del res
+    return fig
+
+
 def detrend_figures(args, ctx, stream, s_vv, lines, samples):
     """`sigma0 / ratio_row` (detrend.py:63-64) on the resident float32 raster -> float64: 4 B read + 8 B written per
     pixel -- the one HBM-bound kernel of the path."""
@@ -272,7 +384,7 @@ def detrend_figures(args, ctx, stream, s_vv, lines, samples):
     px = lines * samples
     achieved = 12.0 * px / (kernel_ms * 1e-3) / 1e9
     traffic = None
-    tj = _profile_json(f"{PROFILE_ROUND}_hbm_traffic_summary.json") or _profile_json("r01_f_hbm_traffic_summary.json")
+    tj, prov = fresh_profile(f"{PROFILE_ROUND}_hbm_traffic_summary.json")
     if tj and (lines, samples) == (20000, 20000):
         try:  # k_detrend is the calibration kernel of the traffic passes: WRITE_SIZE is exact, FETCH_SIZE x the gfx950 factor 2
             raw = tj["raw_KiB"]["k_detrend"]
@@ -284,7 +396,7 @@ def detrend_figures(args, ctx, stream, s_vv, lines, samples):
             "kernel_ms": round(kernel_ms, 4), "bytes_per_pixel": 12,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_copy_rate_6290": round(achieved / 6290.0, 4),
-                         "traffic": traffic}}
+                         "traffic": traffic, "traffic_provenance": prov}}
 
 
 def nesz_figures(args, ctx, stream, noise, inc, lines, samples):
@@ -297,12 +409,8 @@ def nesz_figures(args, ctx, stream, noise, inc, lines, samples):
     def step():
         ctx.nesz_flatten_raw(lines, samples, _lib.XSW_F32, _lib.MEM_DEVICE, noise.data_ptr(), inc.data_ptr(), out.data_ptr())
 
-    step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()  # returns after the work has completed (call-local scratch)
-    dt = (time.perf_counter() - t0) / args.steps
+    _, ms = time_steps(step, args.steps, 1, stream)  # asynchronous on the stream since round 3 (context-owned scratch)
+    dt = ms * 1e-3
     del out
     px = lines * samples
     achieved = 20.0 * px / dt / 1e9
@@ -310,7 +418,7 @@ def nesz_figures(args, ctx, stream, noise, inc, lines, samples):
             "value": round(px / dt / 1e6, 1), "unit": "Mpixels/s", "ms_per_call": round(dt * 1e3, 3), "bytes_per_pixel": 20,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "note": "wall time of the synchronous call (three launches, a scratch hipMalloc/hipFree and a stream sync included)"}}
+                         "note": "HIP events on the launch stream around the call's four launches (asynchronous, context-owned scratch)"}}
 
 
 # ------------------------------------------------------------------------------------------ rank launcher
@@ -587,10 +695,11 @@ def main():
         achieved = bytes_px * lines * samples / (kernel_ms * 1e-3) / 1e9  # rank 0's tile / rank 0's kernel time
         is_metric_shape = (mode == "mono" and args.resolution == "high" and cfg["lut"] == "cmod5n" and args.algo == "pruned"
                            and (lines, samples) == (20000, 20000))
-        traffic = None
-        tj = _profile_json("hbm_traffic.json")
-        if tj and is_metric_shape:
-            traffic = tj.get("pruned_20000x20000")
+        traffic, traffic_prov = None, None
+        if is_metric_shape:
+            tj, traffic_prov = fresh_profile(f"{PROFILE_ROUND}_hbm_traffic_summary.json")
+            if tj:
+                traffic = int(tj["k_invert_20000x20000"]["hbm_bytes_per_launch"])
         cand_full = int(lut.shape[1] * lut.shape[2])
         evaluated = stats["cand_co"] / max(stats["pixels_co"], 1)
         lane_ops = OPS_PER_CANDIDATE * stats["cand_co"] / world / (kernel_ms_max * 1e-3) if args.algo == "pruned" else \
@@ -603,7 +712,10 @@ def main():
                 "achieved": float(f"{lane_ops:.4g}"), "frac": round(lane_ops / LANE_OPS_PEAK, 5),
                 "note": "useful work only: 6 lane-ops x candidates actually scored / kernel time / (256 CU x 128 lanes x 2.4 GHz); "
                         "the grid has candidates_per_pixel_full_grid points, all but the evaluated ones are excluded by an exact bound"}
-        sq = (_profile_json(f"{PROFILE_ROUND}_pmc_counters_summary.json") or {}).get("k_invert_band")
+        sq, sq_prov = (fresh_profile(f"{PROFILE_ROUND}_pmc_counters_summary.json") if is_metric_shape else (None, None))
+        sq = (sq or {}).get("k_invert_band")
+        if sq_prov and "stale_profile" in sq_prov:
+            valu["issue"] = sq_prov
         if sq and is_metric_shape:
             try:
                 pp = sq["per_pixel"]
@@ -615,6 +727,9 @@ def main():
                                  "valu_issue_frac_of_simd_cycles": round(sq["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cyc), 3),
                                  "texture_addresser_busy_frac": round(sq["TA_TA_BUSY_sum"] / (256.0 * cyc), 3),
                                  "wave_time_waiting_frac": round(sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"], 3),
+                                 "valu_int32_insts_per_pixel": round(pp.get("SQ_INSTS_VALU_INT32", float("nan")), 1),
+                                 "branch_insts_per_pixel": round(pp.get("SQ_INSTS_BRANCH", float("nan")), 1),
+                                 "measured_on": sq_prov.get("measured_on"),
                                  "source": f"profiles/{PROFILE_ROUND}_pmc_counters_summary.json (rocprofv3 --pmc passes of profiles/collect_counters.sh, "
                                            "same workload; 4 issue cycles per wave64 VALU instruction, 1024 SIMDs, 256 TAs, cycles = GRBM_GUI_ACTIVE / 8 XCDs)"}
             except Exception:
@@ -635,7 +750,7 @@ def main():
                        "baseline_config": args.config, "lines": total_lines, "samples": samples,
                        "lines_rank0": lines, "lut": [int(x) for x in lut.shape], "parallelism": par},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_provenance": traffic_prov,
                          "kernel": {"exhaustive": "k_invert_exhaustive32", "exhaustive_f64": "k_invert_exhaustive"}.get(
                              args.algo, "k_invert_band" if second_ms is not None else "k_invert"),
                          "kernel_ms": round(kernel_ms, 3), "bytes_per_pixel": bytes_px,
@@ -660,8 +775,11 @@ def main():
             dbt, db_ms = time_steps(lambda: invert_rows(0, lines, s_db.data_ptr(), True), args.steps, 1, stream)
             res["parity_config"] = {"db_mode": "host numpy float32 log10 (bit-parity with the reference CPU path), sigma0_is_db=1",
                                     "value": round(px_total * args.steps / dbt / 1e6, 3), "unit": "Mpixels/s",
-                                    "kernel_ms": round(db_ms, 3), "host_db_conversion_s_untimed": round(host_db_s, 2)}
+                                    "kernel_ms": round(db_ms, 3), "host_db_conversion_s_untimed": round(host_db_s, 2),
+                                    "note": "kernel only, dB raster resident; parity_config_end_to_end times everything"}
             del s_db
+            res["parity_config_end_to_end"] = end_to_end_parity_figure(ctx, _lib, inc, s_vv, anc, out, lines, samples, algo)
+            res["host_path"] = host_path_figure(inc, s_vv, anc, samples)
         if extras and mode == "mono" and args.algo == "pruned" and not args.no_cpu_baseline:
             # like-for-like figure: the literal exhaustive sweep (every one of the 90319 candidates scored per pixel,
             # LUT tiled through LDS, float32 screening + float64 settle) on the first lines of the same raster

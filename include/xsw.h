@@ -14,21 +14,32 @@
  *     (the reference's gufunc core dimension "(n)" is only a loop, windspeed/windspeed.py:190);
  *   - complex values are interleaved (re, im);
  *   - a context is bound to one device and one stream; calls on one context are not thread-safe,
- *     different contexts are independent (one process per GPU uses one context).
+ *     different contexts are independent (one process per GPU uses one context; one process driving several GPUs
+ *     uses one context per GPU from one host thread each -- xsarsea_amd.options.devices does exactly that).
+ *
+ * Host rasters (XSW_MEM_HOST) travel through a context-owned ring of page-locked staging buffers filled and drained by
+ * host worker threads (XSW_HOST_THREADS, default 8, at most 32), one HIP stream per worker: chunk k is staged, uploaded,
+ * inverted, downloaded and written to the caller's output while the other workers do the same for other chunks.  What
+ * comes down the link is the answer as 4-byte GRID CODES (see xsw_invert_args.out_code_co), expanded to complex values
+ * on the host from the same tables and by the same IEEE operations as on the device: bit-identical, 4 instead of 8 / 16
+ * bytes per pixel and output over PCIe.
  */
 #ifndef XSW_H
 #define XSW_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define XSW_VERSION 1
+#define XSW_VERSION 2
 
 enum { XSW_F32 = 0, XSW_F64 = 1 };           /* raster element type (complex rasters: c64 / c128) */
-enum { XSW_MEM_HOST = 0, XSW_MEM_DEVICE = 1 };
+enum { XSW_MEM_HOST = 0, XSW_MEM_DEVICE = 1,
+       XSW_MEM_HOST_PINNED = 2 /* host rasters in page-locked memory (xsw_host_alloc / hipHostMalloc): DMA reads them directly,
+                                  the staging copy of XSW_MEM_HOST is skipped for the inputs */ };
 enum {
     XSW_ALGO_AUTO = 0,       /* pruned when the LUT axes are uniform and finite, else exact        */
     XSW_ALGO_PRUNED = 1,     /* exact branch-and-bound search (production kernel)                   */
@@ -94,7 +105,23 @@ typedef struct {
     void *out_co;           /* complex; NULL allowed when sigma0_co is NULL                           */
     void *out_cr;           /* complex; NULL: not written                                             */
     int32_t *out_idx;       /* optional int32[n][3] = (i_wspd, i_phi, i_wspd_cr), -1 where no search  */
+    /* XSW_VERSION >= 2.  Optional: the answer as grid codes, 4 bytes per pixel and search -- the retrieved wind IS a grid
+     * point of the LUT (windspeed.py:228-232, :269), so this is the whole result; xsw_expand_codes turns codes into the
+     * complex values out_co / out_cr would have received, bit for bit.  When a code pointer is given the corresponding
+     * complex output may be NULL (nothing else is written for that search): 4 B/px instead of 8 or 16 to store, gather
+     * over xGMI (multi-GPU) or move over PCIe.
+     *   co code: i_wspd * n_phi + i_phi in bits 0..29, bit 30 set when the -phi solution was chosen (:234-242);
+     *            XSW_CODE_NAN_RE = (nan, 0) [incidence NaN, :198-201 / ancillary NaN, :204-207], XSW_CODE_NAN = (nan, nan) [:250]
+     *   cr code: i_wspd_cr in bits 0..29 (XSW_CODE_NO_INDEX: no cross-pol search ran, wind_dual = (nan, nan) :278), bit 30
+     *            (XSW_CODE_PICK_CO) set when dual_select picked the co-pol wind; XSW_CODE_NAN_RE as above.                  */
+    uint32_t *out_code_co;
+    uint32_t *out_code_cr;
 } xsw_invert_args;
+
+#define XSW_CODE_NAN_RE  0xFFFFFFFFu
+#define XSW_CODE_NAN     0xFFFFFFFEu
+#define XSW_CODE_PICK_CO  0x40000000u
+#define XSW_CODE_NO_INDEX 0x3FFFFFFFu
 
 /* Evaluated-work counters of the last xsw_invert call with stats enabled. */
 typedef struct {
@@ -116,6 +143,9 @@ const char *xsw_last_error(const xsw_ctx *ctx); /* ctx may be NULL: last creatio
  * A new context launches on a private non-blocking stream; xsw_use_own_stream() returns to it.
  * XSW_MEM_DEVICE buffers are read and written in stream order ON THAT STREAM ONLY: a caller whose producers run on another
  * stream (torch's, say) must either hand that stream over here or synchronise it before xsw_invert / xsw_detrend / ... */
+/* Changing the stream orders the new stream after the work the context queued on the previous one (an event the new stream
+ * waits for; the host does not block): the work list that hands pixels from k_invert_band to k_invert_list and the scratch of
+ * xsw_nesz_flatten are context-owned and reused by the next call. */
 int xsw_set_stream(xsw_ctx *ctx, void *hip_stream);
 int xsw_use_own_stream(xsw_ctx *ctx);
 int xsw_synchronize(xsw_ctx *ctx);
@@ -131,9 +161,25 @@ int xsw_lut_upload(xsw_ctx *ctx, const xsw_lut *co, const xsw_lut *cr);
  * when mem == XSW_MEM_DEVICE; synchronous (returns with outputs filled) for host memory.
  * XSW_ALGO_PRUNED on a LUT whose columns rise monotonically with wind speed (every built-in GMF over most of its rows) runs
  * as two launches: k_invert_band decides the pixels its band rule can, k_invert_list the rest from a work list owned by
- * the context (4 bytes per pixel of the largest raster seen); any other LUT, and XSW_ALGO_EXACT, take the general kernel.
+ * the context (4 bytes per EIGHTH pixel of the largest raster seen; a scene that leaves more than an eighth of its pixels
+ * undecided overflows the list, which k_invert_list answers by inverting every tile itself; if the list cannot be
+ * allocated the one-kernel path runs); any other LUT, and XSW_ALGO_EXACT, take the general kernel.
  * Results do not depend on the route (environment variable XSW_NO_BAND=1 forces the general kernel: A/B measurements). */
 int xsw_invert(xsw_ctx *ctx, const xsw_invert_args *args);
+
+/* Grid codes -> complex winds (the store of __invert_from_model_1d: wind_co = wspd * exp(1j * deg2rad(+-phi)) :235-247,
+ * wind_dual = wspd_dual * exp(1j * angle(wind_co)) :270-276), from the tables of the context's current LUTs.  code_co may be
+ * NULL when only cross-pol codes exist (cross-pol-only inversion: wind_dual = wspd_dual + 0j), code_cr / out_cr may be NULL.
+ * out_dtype XSW_F32 -> complex64, XSW_F64 -> complex128.  mem = XSW_MEM_DEVICE: one HBM-bound kernel, asynchronous on the
+ * context's stream; XSW_MEM_HOST: on the calling thread.  Both give the bits xsw_invert writes to out_co / out_cr. */
+int xsw_expand_codes(xsw_ctx *ctx, int64_t n, int32_t mem, int32_t out_dtype, const uint32_t *code_co,
+                     const uint32_t *code_cr, void *out_co, void *out_cr);
+
+/* Page-locked host memory for rasters a caller fills itself (XSW_MEM_HOST_PINNED); freed by xsw_host_free or with the context. */
+int xsw_host_alloc(xsw_ctx *ctx, size_t bytes, void **out);
+int xsw_host_free(xsw_ctx *ctx, void *p);
+/* Host worker threads of the XSW_MEM_HOST paths (0 = default: XSW_HOST_THREADS or 8; at most 32). */
+int xsw_set_host_threads(xsw_ctx *ctx, int n);
 
 /* Enable (1) / disable (0) device-side work counters; read them after synchronising. */
 int xsw_stats_enable(xsw_ctx *ctx, int on);
@@ -203,7 +249,9 @@ int xsw_detrend(xsw_ctx *ctx, int64_t lines, int64_t samples, int32_t dtype, int
  * the degree-1 least-squares fit of 10*log10(noise[l], NaNs replaced by the column nan-mean) against inc_row over the
  * finite samples of line l; a line without any finite sample is NaN.  noise/inc are `dtype` rasters (host or device per
  * `mem`), out is float64 (the reference's result dtype).  Sums are float64 and the fit is closed-form: agrees with
- * numpy's polyfit-based result to ~1e-13 relative for float64 rasters.  Returns after the work has completed. */
+ * numpy's polyfit-based result to ~1e-13 relative for float64 rasters (float32 rasters: float32 dB arithmetic like the
+ * reference's own, 1e-5).  Device rasters: asynchronous on the context's stream (scratch is context-owned); host rasters:
+ * returns with `out` filled. */
 int xsw_nesz_flatten(xsw_ctx *ctx, int64_t lines, int64_t samples, int32_t dtype, int32_t mem, const void *noise,
                      const void *inc, double *out);
 

@@ -1,7 +1,7 @@
 """GPU: BASELINE.json configs 3, 4 and 5 at their STATED shapes (device-resident float32 rasters, complex64 out), checked
 through size-independent properties -- the production kernel against an independent kernel on every pixel, row-tile
-independence -- and against the C oracle on crops.  Config 2 (10000 x 10000 mono) is a sub-case of the 20000 x 20000 mono
-raster of test_gpu_fullsize.py; config 1 is test_gpu_api.py::test_sigma0_detrend."""
+independence -- and against the C oracle on crops.  Config 2 (10000 x 10000 mono) runs at its stated shape in
+test_gpu_fullsize.py (parametrised over 10000 and 20000); config 1 is test_gpu_api.py::test_sigma0_detrend."""
 import os
 
 import numpy as np

@@ -1,5 +1,5 @@
-"""GPU: BASELINE.json's full-size raster (20000 x 20000, float32 in / complex64 out, device-resident),
-checked through size-independent properties: determinism, tile independence (row tiling == whole raster),
+"""GPU: BASELINE.json's mono-VV rasters at their STATED shapes -- config 2 (10000 x 10000) and the metric's raster
+(20000 x 20000) -- float32 in / complex64 out, device-resident, checked through size-independent properties: determinism, tile independence (row tiling == whole raster),
 grid membership of every solution, and agreement of the branch-and-bound kernel with the LDS-tiled
 exhaustive sweep and with the oracle on crops."""
 import numpy as np
@@ -7,31 +7,32 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-N = 20000
+SIZES = {"config2_10000": 10000, "metric_20000": 20000}
 
 
-@pytest.fixture(scope="module")
-def full_scene():
+@pytest.fixture(scope="module", params=sorted(SIZES))
+def full_scene(request):
     torch = pytest.importorskip("torch")
+    N = SIZES[request.param]
     import bench
     from xsarsea_amd import _lib
     dev = torch.device("cuda", 0)
     lut, co = bench.build_product_lut()
     ctx = _lib.Context(0)
     ctx.upload_luts(co=co)
-    inc, s_vv, anc = bench.make_scene(N, N, N, 0, 424242, dev)
+    inc, s_vv, anc = bench.make_scene(N, N, N, 0, 424242 if N == 20000 else 20260320 + 2, dev)
     out = torch.empty((N, N), dtype=torch.complex64, device=dev)
     torch.cuda.synchronize()  # the context launches on its own stream: the scene must be complete first
     ctx.invert_raw(N, N, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, inc.data_ptr(), s_vv.data_ptr(), None, None,
                    anc.data_ptr(), out.data_ptr(), None, algo=_lib.ALGO_PRUNED)
     ctx.synchronize()
-    yield dict(torch=torch, ctx=ctx, lut=lut, inc=inc, s_vv=s_vv, anc=anc, out=out)
+    yield dict(torch=torch, ctx=ctx, lut=lut, inc=inc, s_vv=s_vv, anc=anc, out=out, N=N)
     ctx.close()
 
 
 def test_deterministic_and_tile_independent(full_scene):
     f = full_scene
-    torch, ctx = f["torch"], f["ctx"]
+    torch, ctx, N = f["torch"], f["ctx"], f["N"]
     from xsarsea_amd import _lib
     again = torch.empty_like(f["out"])
     ctx.invert_raw(N, N, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, f["inc"].data_ptr(), f["s_vv"].data_ptr(), None, None,
@@ -41,7 +42,7 @@ def test_deterministic_and_tile_independent(full_scene):
     assert torch.equal(a.view(torch.int32), b.view(torch.int32)), "two runs differ"
     # row tiles of unequal heights (as ranks of a multi-GPU job would take them) == the whole raster
     tiled = torch.empty_like(f["out"])
-    for l0, l1 in ((0, 4999), (4999, 10002), (10002, 17001), (17001, N)):
+    for l0, l1 in ((0, N // 4 - 1), (N // 4 - 1, N // 2 + 2), (N // 2 + 2, N - 2999), (N - 2999, N)):
         off = l0 * N
         ctx.invert_raw(l1 - l0, N, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, f["inc"].data_ptr() + off * 4,
                        f["s_vv"].data_ptr() + off * 4, None, None, f["anc"].data_ptr() + off * 8, tiled.data_ptr() + off * 8,
@@ -57,7 +58,7 @@ def test_solutions_lie_on_the_lut_grid(full_scene):
     """|wind| must be one of the 499 grid speeds and its direction one of the 181 grid directions (+-), NaN
     exactly where incidence or sigma0 is NaN."""
     f = full_scene
-    torch = f["torch"]
+    torch, N = f["torch"], f["N"]
     out = f["out"]
     nan_in = torch.isnan(f["inc"]) | torch.isnan(f["s_vv"])
     assert torch.equal(torch.isnan(out.real), nan_in)
@@ -75,7 +76,7 @@ def test_solutions_lie_on_the_lut_grid(full_scene):
 
 def test_pruned_equals_exhaustive_and_oracle_on_crops(full_scene, default_luts):
     f = full_scene
-    ctx = f["ctx"]
+    ctx, N = f["ctx"], f["N"]
     from oracle import invert as oinv
     from util import oracle_full
     lco, _ = default_luts
@@ -96,11 +97,11 @@ def test_pruned_equals_exhaustive_and_oracle_on_crops(full_scene, default_luts):
 
 
 def test_pruned_equals_exhaustive_on_the_whole_raster(full_scene):
-    """All 4e8 pixels: the branch-and-bound kernel (552 candidates scored per pixel) and the LDS-tiled exhaustive sweep
+    """Every pixel of the raster (1e8 for config 2, 4e8 for the metric's): the branch-and-bound kernel (552 candidates scored per pixel) and the LDS-tiled exhaustive sweep
     (all 90 319, an independent code path: no window, no forward differences along a window, float32 screening + float64
     settle) return the same bits."""
     f = full_scene
-    torch, ctx = f["torch"], f["ctx"]
+    torch, ctx, N = f["torch"], f["ctx"], f["N"]
     from xsarsea_amd import _lib
     ex = torch.empty_like(f["out"])
     ctx.invert_raw(N, N, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, f["inc"].data_ptr(), f["s_vv"].data_ptr(), None, None,

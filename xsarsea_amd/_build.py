@@ -79,5 +79,25 @@ def write_kernel_resources(path):
     return rows
 
 
+def code_object_sha256(lib=None):
+    """SHA-256 of the .hip_fatbin section (the device code) of libxsw.so: what a counter profile was measured on."""
+    import hashlib
+    import tempfile
+    lib = lib or LIB
+    with tempfile.TemporaryDirectory() as td:
+        fat = os.path.join(td, "fat.bin")
+        subprocess.check_call(["/opt/rocm/lib/llvm/bin/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", lib,
+                               os.path.join(td, "unused.so")])
+        with open(fat, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()
+
+
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    if len(sys.argv) > 2 and sys.argv[1] == "--resources":
+        build()
+        write_kernel_resources(sys.argv[2])
+    elif len(sys.argv) > 1 and sys.argv[1] == "--code-sha":
+        print(code_object_sha256())
+    else:
+        print(build(force=True, verbose=True))

@@ -10,7 +10,8 @@ import numpy as np
 from . import _build, _host
 
 XSW_F32, XSW_F64 = 0, 1
-MEM_HOST, MEM_DEVICE = 0, 1
+MEM_HOST, MEM_DEVICE, MEM_HOST_PINNED = 0, 1, 2
+CODE_NAN_RE, CODE_NAN, CODE_PICK_CO, CODE_NO_INDEX = 0xFFFFFFFF, 0xFFFFFFFE, 0x40000000, 0x3FFFFFFF
 ALGO_AUTO, ALGO_PRUNED, ALGO_EXHAUSTIVE, ALGO_EXACT, ALGO_EXHAUSTIVE_F64 = 0, 1, 2, 3, 4
 ALGOS = {"auto": ALGO_AUTO, "pruned": ALGO_PRUNED, "exhaustive": ALGO_EXHAUSTIVE, "exact": ALGO_EXACT,
          "exhaustive_f64": ALGO_EXHAUSTIVE_F64}
@@ -22,7 +23,8 @@ GMF_IDS = {"gmf_cmod5": 0, "gmf_cmod5n": 1, "gmf_cmod5n_pr_zhangA": 2, "gmf_cmod
 EXPORTS = (
     "xsw_version", "xsw_device_count", "xsw_ctx_create", "xsw_ctx_destroy", "xsw_last_error", "xsw_set_stream", "xsw_use_own_stream",
     "xsw_synchronize", "xsw_lut_upload", "xsw_invert", "xsw_stats_enable", "xsw_stats_read", "xsw_detrend", "xsw_lut_interp", "xsw_gmf_eval",
-    "xsw_nesz_flatten", "xsw_lut_build", "xsw_lut_read", "xsw_timing_enable", "xsw_timing_read",
+    "xsw_nesz_flatten", "xsw_lut_build", "xsw_lut_read", "xsw_timing_enable", "xsw_timing_read", "xsw_expand_codes",
+    "xsw_host_alloc", "xsw_host_free", "xsw_set_host_threads",
 )
 
 
@@ -44,7 +46,8 @@ class InvertArgs(ctypes.Structure):
                 ("inc", ctypes.c_void_p), ("sigma0_co", ctypes.c_void_p), ("sigma0_cr", ctypes.c_void_p),
                 ("dsig_cr", ctypes.c_void_p), ("anc", ctypes.c_void_p),
                 ("dsig_co", ctypes.c_double), ("dsig_cr_scalar", ctypes.c_double),
-                ("out_co", ctypes.c_void_p), ("out_cr", ctypes.c_void_p), ("out_idx", ctypes.c_void_p)]
+                ("out_co", ctypes.c_void_p), ("out_cr", ctypes.c_void_p), ("out_idx", ctypes.c_void_p),
+                ("out_code_co", ctypes.c_void_p), ("out_code_cr", ctypes.c_void_p)]
 
 
 class Stats(ctypes.Structure):
@@ -118,6 +121,12 @@ def load():
         lib.xsw_lut_read.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
         lib.xsw_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.xsw_timing_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(Timing)]
+        lib.xsw_expand_codes.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 4
+        lib.xsw_host_alloc.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+        lib.xsw_host_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.xsw_set_host_threads.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        if lib.xsw_version() != 2:
+            raise XswError(f"{_build.LIB} is version {lib.xsw_version()}, this package binds version 2: rebuild it")
         _cdll = lib
     return _cdll
 
@@ -299,17 +308,51 @@ class Context:
     @_locked
     def invert_raw(self, lines, samples, dtype, out_dtype, mem, inc, sigma0_co, sigma0_cr, dsig_cr, anc, out_co,
                    out_cr, out_idx=None, dsig_co=0.1, dsig_cr_scalar=0.1, sigma0_is_db=False, algo=ALGO_AUTO,
-                   dual_select=False):
+                   dual_select=False, out_code_co=None, out_code_cr=None):
         """Thin call of xsw_invert; pointer arguments are ints (device or host addresses) or None."""
         a = InvertArgs(int(lines), int(samples), dtype, out_dtype, mem, int(bool(sigma0_is_db)), int(algo),
                        int(bool(dual_select)), inc, sigma0_co, sigma0_cr, dsig_cr, anc, float(dsig_co),
-                       float(dsig_cr_scalar), out_co, out_cr, out_idx)
+                       float(dsig_cr_scalar), out_co, out_cr, out_idx, out_code_co, out_code_cr)
         self._check(self._lib.xsw_invert(self._h, ctypes.byref(a)), "xsw_invert")
 
     @_locked
+    def expand_codes_raw(self, n, mem, out_dtype, code_co, code_cr, out_co, out_cr):
+        """Thin call of xsw_expand_codes (pointers are ints or None): grid codes -> the complex winds xsw_invert stores."""
+        self._check(self._lib.xsw_expand_codes(self._h, int(n), mem, out_dtype, code_co, code_cr, out_co, out_cr), "xsw_expand_codes")
+
+    @_locked
+    def set_host_threads(self, n):
+        """Worker threads of the host-memory paths (0 = default: XSW_HOST_THREADS or 8)."""
+        self._check(self._lib.xsw_set_host_threads(self._h, int(n)), "xsw_set_host_threads")
+
+    @_locked
+    def pinned_empty(self, shape, dtype):
+        """numpy array in page-locked memory of this context (xsw_host_alloc): rasters filled here can be handed to the
+        XSW_MEM_HOST_PINNED paths, which DMA straight out of them.  The memory lives until `pinned_free(arr)` or the context closes."""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        p = ctypes.c_void_p()
+        self._check(self._lib.xsw_host_alloc(self._h, max(nbytes, 1), ctypes.byref(p)), "xsw_host_alloc")
+        buf = (ctypes.c_char * max(nbytes, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=nbytes // dtype.itemsize).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    @_locked
+    def pinned_free(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is not None:
+            self._check(self._lib.xsw_host_free(self._h, ctypes.c_void_p(p)), "xsw_host_free")
+
+    @_locked
     def invert_host(self, inc, sigma0_co=None, sigma0_cr=None, dsig_cr=None, anc=None, dsig_co=0.1,
-                    sigma0_is_db=False, algo="auto", dual_select=False, out_dtype=np.complex128, want_idx=False):
-        """numpy-in / numpy-out wrapper of xsw_invert for host rasters of one dtype (float32 or float64)."""
+                    sigma0_is_db=False, algo="auto", dual_select=False, out_dtype=np.complex128, want_idx=False, want_codes=False,
+                    pinned=False, out_co=None, out_cr=None):
+        """numpy-in / numpy-out wrapper of xsw_invert for host rasters of one dtype (float32 or float64).
+        want_codes: also return the uint32 grid codes (co, cr) as a 4th element.  pinned: the rasters are page-locked
+        (`pinned_empty`): XSW_MEM_HOST_PINNED.  out_co / out_cr: C-contiguous arrays of the broadcast shape and `out_dtype` to
+        write into (row tiles of one raster inverted by several contexts land in place)."""
         inc = np.asarray(inc)
         dt = inc.dtype
         if dt not in (np.float32, np.float64):
@@ -338,14 +381,29 @@ class Context:
             else:
                 dsig_arr = prep(dsig_cr, dt)
         out_dtype = np.dtype(out_dtype)
-        out_co = _host.empty_touched(shape, out_dtype) if s_co is not None else None
-        out_cr = _host.empty_touched(shape, out_dtype) if s_cr is not None else None
+        # plain np.empty: the library's worker threads write (and so first-touch) their own chunks side by side
+        for o in (out_co, out_cr):
+            if o is not None and (o.shape != tuple(shape) or o.dtype != out_dtype or not o.flags.c_contiguous):
+                raise ValueError("out_co / out_cr must be C-contiguous arrays of the broadcast shape and out_dtype")
+        if s_co is not None and out_co is None:
+            out_co = np.empty(shape, out_dtype)
+        if s_cr is not None and out_cr is None:
+            out_cr = np.empty(shape, out_dtype)
+        if s_co is None:
+            out_co = None
+        if s_cr is None:
+            out_cr = None
         idx = np.empty(shape + (3,), dtype=np.int32) if want_idx else None
+        codes = (np.empty(shape, np.uint32) if s_co is not None else None,
+                 np.empty(shape, np.uint32) if s_cr is not None else None) if want_codes else (None, None)
         if n:
             self.invert_raw(lines, samples, XSW_F32 if dt == np.float32 else XSW_F64,
-                            XSW_F32 if out_dtype == np.complex64 else XSW_F64, MEM_HOST,
+                            XSW_F32 if out_dtype == np.complex64 else XSW_F64, MEM_HOST_PINNED if pinned else MEM_HOST,
                             _ptr(inc), _ptr(s_co), _ptr(s_cr), _ptr(dsig_arr), _ptr(anc_), _ptr(out_co), _ptr(out_cr),
-                            _ptr(idx), dsig_co, dsig_scalar, sigma0_is_db, ALGOS.get(algo, algo), dual_select)
+                            _ptr(idx), dsig_co, dsig_scalar, sigma0_is_db, ALGOS.get(algo, algo), dual_select,
+                            _ptr(codes[0]), _ptr(codes[1]))
+        if want_codes:
+            return out_co, out_cr, idx, codes
         return out_co, out_cr, idx
 
     @_locked
@@ -357,13 +415,16 @@ class Context:
     @_locked
     def nesz_flatten_host(self, noise, inc):
         """xsw_nesz_flatten on host rasters of one dtype (float32 or float64) and one 2-D shape -> float64."""
-        noise = np.ascontiguousarray(noise)
-        if noise.dtype not in (np.float32, np.float64):
-            noise = noise.astype(np.float64)
-        inc = np.ascontiguousarray(inc, dtype=noise.dtype)
+        noise, inc = np.asarray(noise), np.asarray(inc)
+        # one raster dtype on the device: the wider of the two (a float64 incidence is never narrowed to a float32 noise raster)
+        dt = np.result_type(noise.dtype, inc.dtype)
+        if dt not in (np.float32, np.float64):
+            dt = np.dtype(np.float64)
+        noise = np.ascontiguousarray(noise, dtype=dt)
+        inc = np.ascontiguousarray(inc, dtype=dt)
         if noise.ndim != 2 or inc.shape != noise.shape:
             raise ValueError("noise and inc must be 2-D rasters of one shape")
-        out = _host.empty_touched(noise.shape, np.float64)
+        out = np.empty(noise.shape, np.float64)
         if noise.size:
             self.nesz_flatten_raw(noise.shape[0], noise.shape[1], XSW_F32 if noise.dtype == np.float32 else XSW_F64, MEM_HOST,
                                   noise.ctypes.data, inc.ctypes.data, out.ctypes.data)
@@ -386,7 +447,7 @@ class Context:
         lines, samples = int(np.prod(sigma0.shape[:-1])), sigma0.shape[-1]
         if ratio_row.shape != (samples,):
             raise ValueError("ratio_row must have one value per sample")
-        out = _host.empty_touched(sigma0.shape, out_dtype)
+        out = np.empty(sigma0.shape, out_dtype)
         self._check(self._lib.xsw_detrend(self._h, lines, samples, XSW_F32 if sigma0.dtype == np.float32 else XSW_F64,
                                           XSW_F32 if out.dtype == np.float32 else XSW_F64, MEM_HOST,
                                           _ptr(sigma0), _ptr(ratio_row), _ptr(out)), "xsw_detrend")
@@ -397,9 +458,22 @@ _default_ctx = {}
 _default_ctx_lock = threading.Lock()
 
 
-def default_context(device=0):
-    """Process-wide context per device (created on first use)."""
+def default_context(device=0, replica=0):
+    """Process-wide context per device (created on first use).  replica > 0: further contexts on the same device
+    (`options.devices = [0, 0]`: the single-process multi-device path rehearsed on one GPU)."""
+    key = (int(device), int(replica))
     with _default_ctx_lock:
-        if device not in _default_ctx:
-            _default_ctx[device] = Context(device)
-        return _default_ctx[device]
+        if key not in _default_ctx:
+            _default_ctx[key] = Context(device)
+        return _default_ctx[key]
+
+
+def contexts_for(devices):
+    """One context per entry of `devices` (a device listed twice gets two contexts)."""
+    seen = {}
+    out = []
+    for d in devices:
+        k = seen.get(d, 0)
+        seen[d] = k + 1
+        out.append(default_context(d, k))
+    return out

@@ -2,7 +2,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <condition_variable>
+#include <atomic>
+#include <limits>
 #include <mutex>
 #include <thread>
 #include <cmath>
@@ -37,12 +38,21 @@ struct xsw_ctx {
     bool timing_on = false;                 // xsw_timing_enable: HIP events around the kernels of every device-memory inversion
     std::vector<hipEvent_t> timing_events;  // triples (start, after the first kernel, end) on the launch stream
     unsigned *d_list = nullptr;  // hand-over k_invert_band -> k_invert_list: [0] = count, [16..] = pixel indices
-    size_t list_cap = 0;         // (context-owned, grown on demand)
+    size_t list_cap = 0;         // entries (context-owned, grown on demand: an eighth of the largest raster seen)
     double *d_ratio = nullptr;  // detrend ratio row (context-owned, grown on demand)
     size_t ratio_cap = 0;
-    hipStream_t s_in = nullptr, s_out = nullptr;  // upload / download streams of the host-memory path (lazily created)
-    char *arena = nullptr;      // device staging of the host-memory path (context-owned, grown on demand, kept between
-    size_t arena_cap = 0;       // calls up to XSW_ARENA_KEEP bytes: hipMalloc/hipFree of GBs per call cost more than the copies)
+    void *nesz_scratch = nullptr;  // xsw_nesz_flatten: column partials + means (context-owned, grown on demand)
+    size_t nesz_cap = 0;
+    // host-memory paths: worker w owns a stream, a page-locked staging buffer and a device staging buffer, all kept between calls
+    struct Worker { hipStream_t s = nullptr; char *pin = nullptr; size_t pin_cap = 0; char *dev = nullptr; size_t dev_cap = 0; };
+    std::vector<Worker> workers;
+    int host_threads = 0;  // 0: XSW_HOST_THREADS or 8
+    char *arena = nullptr;      // whole-raster device staging (xsw_nesz_flatten on host rasters; kept up to XSW_ARENA_KEEP bytes)
+    size_t arena_cap = 0;
+    std::vector<void *> host_allocs;  // xsw_host_alloc
+    // host copies of the output-forming tables (xsw_expand_codes on host memory; the expansion of the host-memory paths)
+    std::vector<double> h_sol, h_dual, h_wcr;
+    std::vector<float> h_sol32;
     std::string err;
 };
 
@@ -123,10 +133,15 @@ extern "C" int xsw_ctx_destroy(xsw_ctx *c)
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_ratio) (void)hipFree(c->d_ratio);
     if (c->d_list) (void)hipFree(c->d_list);
+    if (c->nesz_scratch) (void)hipFree(c->nesz_scratch);
     for (hipEvent_t e : c->timing_events) (void)hipEventDestroy(e);
     if (c->arena) (void)hipFree(c->arena);
-    if (c->s_in) (void)hipStreamDestroy(c->s_in);
-    if (c->s_out) (void)hipStreamDestroy(c->s_out);
+    for (auto &w : c->workers) {
+        if (w.s) { (void)hipStreamSynchronize(w.s); (void)hipStreamDestroy(w.s); }
+        if (w.pin) (void)hipHostFree(w.pin);
+        if (w.dev) (void)hipFree(w.dev);
+    }
+    for (void *p : c->host_allocs) (void)hipHostFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return XSW_OK;
@@ -135,6 +150,18 @@ extern "C" int xsw_ctx_destroy(xsw_ctx *c)
 extern "C" int xsw_set_stream(xsw_ctx *c, void *s)
 {
     if (!c) return XSW_EINVAL;
+    if ((hipStream_t)s != c->stream) {
+        // context-owned buffers (work list, nesz scratch, ratio row) are reused by the next call: what was queued on the old
+        // stream must be through with them before anything queued on the new one touches them -- ordered on the device (an
+        // event the new stream waits for), the host does not block
+        HIPCHK(c, hipSetDevice(c->device));
+        hipEvent_t ev = nullptr;
+        HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(ev, c->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)s, ev, 0);
+        (void)hipEventDestroy(ev);  // released once the wait has been satisfied
+        if (e != hipSuccess) return fail(c, XSW_EHIP, "stream hand-over failed: %s", hipGetErrorString(e));
+    }
     c->stream = (hipStream_t)s;  // NULL is a valid handle: the device's default stream
     return XSW_OK;
 }
@@ -142,7 +169,35 @@ extern "C" int xsw_set_stream(xsw_ctx *c, void *s)
 extern "C" int xsw_use_own_stream(xsw_ctx *c)
 {
     if (!c) return XSW_EINVAL;
-    c->stream = c->own_stream;
+    return xsw_set_stream(c, (void *)c->own_stream);
+}
+
+extern "C" int xsw_set_host_threads(xsw_ctx *c, int n)
+{
+    if (!c || n < 0) return XSW_EINVAL;
+    c->host_threads = n > 32 ? 32 : n;
+    return XSW_OK;
+}
+
+extern "C" int xsw_host_alloc(xsw_ctx *c, size_t bytes, void **out)
+{
+    if (!c || !out) return XSW_EINVAL;
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return fail(c, XSW_ENOMEM, "hipHostMalloc(%zu) failed", bytes);
+    c->host_allocs.push_back(p);
+    *out = p;
+    return XSW_OK;
+}
+
+extern "C" int xsw_host_free(xsw_ctx *c, void *p)
+{
+    if (!c) return XSW_EINVAL;
+    auto it = std::find(c->host_allocs.begin(), c->host_allocs.end(), p);
+    if (it == c->host_allocs.end()) return fail(c, XSW_EINVAL, "xsw_host_free: not a pointer of xsw_host_alloc on this context");
+    c->host_allocs.erase(it);
+    HIPCHK(c, hipHostFree(p));
     return XSW_OK;
 }
 
@@ -390,6 +445,22 @@ static int install_co(xsw_ctx *c, const xsw_lut *l, const double *d_dense)
         if ((rc = upload(c, c->co_allocs, od.data(), od.size(), &T.out_dir))) return rc;
         if ((rc = upload(c, c->co_allocs, ab.data(), ab.size(), &T.abs_co))) return rc;
         if ((rc = upload(c, c->co_allocs, dd.data(), dd.size(), &T.dual_dir))) return rc;
+        // the co-pol winds themselves, by the store's own operations (store_pixel: w * e.x, w * e.y + 0.0 * e.x): what a grid
+        // code expands to, on the device (k_expand) and on the host (expand_host)
+        std::vector<double> sol((size_t)4 * nW * nP);
+        for (int k = 0; k < 2; ++k)
+            for (int iw = 0; iw < nW; ++iw)
+                for (int i = 0; i < nP; ++i) {
+                    const double w = l->wspd[iw], ex = od[((size_t)k * nP + i) * 2], ey = od[((size_t)k * nP + i) * 2 + 1];
+                    const size_t o = (((size_t)k * nW + iw) * nP + i) * 2;
+                    sol[o] = w * ex;
+                    sol[o + 1] = w * ey + 0.0 * ex;
+                }
+        if ((rc = upload(c, c->co_allocs, sol.data(), sol.size(), &T.sol))) return rc;
+        c->h_sol32.resize(sol.size());
+        for (size_t k = 0; k < sol.size(); ++k) c->h_sol32[k] = (float)sol[k];
+        c->h_sol.swap(sol);
+        c->h_dual.swap(dd);
     }
     T.n_inc = nI; T.n_w = nW; T.n_phi = nP; T.phi_pad = ppad; T.w_pad = wpad;
     T.phi_180 = (180.0 - (l->phi[nP - 1] - l->phi[0])) < 2.0 ? 1 : 0;  // windspeed.py:152-156
@@ -440,6 +511,7 @@ static int upload_cr(xsw_ctx *c, const xsw_lut *l)
     if ((rc = upload(c, c->cr_allocs, l->wspd, nW, &T.wcr))) return rc;
     if ((rc = upload(c, c->cr_allocs, wh.data(), nW, &T.wcrh))) return rc;
     T.n_inc_cr = nI; T.n_wcr = nW; T.wcr_pad = wpad;
+    c->h_wcr.assign(l->wspd, l->wspd + nW);
     T.cr_finite = all_finite(l->db, (size_t)nI * nW) ? 1 : 0;
     bool mono = T.cr_finite && nW >= 2 && uniform_axis(l->wspd, nW);
     for (int r = 0; r < nI && mono; ++r)
@@ -498,75 +570,296 @@ extern "C" int xsw_lut_read(xsw_ctx *c, int32_t cross, double *out_db)
 }
 
 // ---------------------------------------------------------------------------------------- invert
+static int seterr(std::string &e, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    e = buf;
+    return code;
+}
+
+// Where an inversion launches: its stream and the work list that hands pixels from k_invert_band to k_invert_list (device
+// rasters: the context's; host rasters: the worker's own, so that the chunks of different workers run side by side).
+struct LaunchCtl {
+    hipStream_t stream;
+    unsigned *list;    // [0] = count, [16 ..] = entries; nullptr: one-kernel path
+    size_t list_cap;   // entries
+    bool timing;       // xsw_timing_enable events (context stream only)
+};
+
 template <typename T, typename TO>
-static int launch_invert(xsw_ctx *c, const KArgs &A, int algo)
+static int launch_invert(xsw_ctx *c, const KArgs &A, int algo, const LaunchCtl &lc, std::string &err)
 {
     // k_invert grid: 8 XCD lanes x ceil(columns/8) tile columns x line groups (see the kernel)
     const long long strips_per_line = (A.samples + 63) / 64, line_groups = (A.lines + 3) / 4;
     const long long nblocks = 8 * ((strips_per_line + 7) / 8) * line_groups;
-    if (nblocks > 0x7fffffffLL) return fail(c, XSW_EINVAL, "raster too large for one launch");
+    if (nblocks > 0x7fffffffLL) return seterr(err, XSW_EINVAL, "raster too large for one launch");
+    const bool mono = !A.s_cr && !A.out_cr && !A.code_cr;
     if (algo == XSW_ALGO_EXHAUSTIVE || algo == XSW_ALGO_EXHAUSTIVE_F64)
-        return launch_exhaustive<T, TO>(c->T, A, c->stream, algo == XSW_ALGO_EXHAUSTIVE) == hipSuccess
-                                                ? XSW_OK : fail(c, XSW_EHIP, "exhaustive launch failed: %s", hipGetErrorString(hipGetLastError()));
+        return launch_exhaustive<T, TO>(c->T, A, lc.stream, algo == XSW_ALGO_EXHAUSTIVE) == hipSuccess
+                   ? XSW_OK : seterr(err, XSW_EHIP, "exhaustive launch failed: %s", hipGetErrorString(hipGetLastError()));
     // Two-kernel fast path: k_invert_band finishes every pixel the band rule decides (monotone LUT rows, finite inputs,
-    // unique minimum; cross-pol by the interval rule) and appends the rest to a work list; k_invert_list inverts those.
+    // unique minimum; cross-pol by the interval rule) and appends the rest to a work list; k_invert_list inverts those
+    // (all tiles, should the list overflow).
     static const bool band_off = getenv("XSW_NO_BAND") != nullptr;  // experiments / A-B measurements only
-    if (algo == XSW_ALGO_PRUNED && !band_off && A.s_co && c->T.prunable && c->T.mono_rows && c->T.inv_rows && c->T.co_off32 &&
+    if (algo == XSW_ALGO_PRUNED && !band_off && lc.list && A.s_co && c->T.prunable && c->T.mono_rows && c->T.inv_rows && c->T.co_off32 &&
         (!A.s_cr || c->T.cr_monotone) && A.n < (1LL << 32)) {
-        if ((size_t)A.n > c->list_cap) {
-            if (c->d_list) (void)hipFree(c->d_list);
-            c->d_list = nullptr;
-            c->list_cap = 0;
-            if (hipMalloc((void **)&c->d_list, ((size_t)A.n + 16) * sizeof(unsigned)) != hipSuccess)
-                return fail(c, XSW_ENOMEM, "hipMalloc(work list, %lld) failed", A.n);
-            c->list_cap = (size_t)A.n;
-        }
         KArgs B = A;
-        B.list_count = c->d_list;
-        B.list = c->d_list + 16;
-        HIPCHK(c, hipMemsetAsync(c->d_list, 0, sizeof(unsigned), c->stream));
+        B.list_count = lc.list;
+        B.list = lc.list + 16;
+        B.list_cap = (unsigned)std::min<size_t>(lc.list_cap, 0xffffffffu);
+        if (hipMemsetAsync(lc.list, 0, sizeof(unsigned), lc.stream) != hipSuccess) return seterr(err, XSW_EHIP, "work-list reset failed");
         const unsigned list_blocks = (unsigned)std::min<long long>(nblocks, 256 * 8);  // 8 waves per SIMD
         // k_invert_band: x = XCD lane + 8 * line group, y = tile column inside the XCD's range (see the kernel)
         const long long cols_per_xcd = (strips_per_line + 7) / 8;
         const long long band_groups = (A.lines + XSW_BAND_WG_WAVES - 1) / XSW_BAND_WG_WAVES;
-        if (8 * band_groups > 0x7fffffffLL || cols_per_xcd > 65535) return fail(c, XSW_EINVAL, "raster too large for one launch");
+        if (8 * band_groups > 0x7fffffffLL || cols_per_xcd > 65535) return seterr(err, XSW_EINVAL, "raster too large for one launch");
         const dim3 band_grid((unsigned)(8 * band_groups), (unsigned)cols_per_xcd), band_block(64 * XSW_BAND_WG_WAVES);
-        timing_mark(c);
+        if (lc.timing) timing_mark(c);
         if (A.stats) {  // statistics instantiation (counts the scored candidates)
-            if (!A.s_cr && !A.out_cr) hipLaunchKernelGGL((k_invert_band<T, TO, false, true>), band_grid, band_block, 0, c->stream, c->T, B);
-            else hipLaunchKernelGGL((k_invert_band<T, TO, true, true>), band_grid, band_block, 0, c->stream, c->T, B);
-            timing_mark(c);
-            if (!A.s_cr && !A.out_cr) hipLaunchKernelGGL((k_invert_list<T, TO, false>), dim3(list_blocks), dim3(256), 0, c->stream, c->T, B);
-            else hipLaunchKernelGGL((k_invert_list<T, TO, true>), dim3(list_blocks), dim3(256), 0, c->stream, c->T, B);
-        } else if (!A.s_cr && !A.out_cr) {
-            hipLaunchKernelGGL((k_invert_band<T, TO, false, false>), band_grid, band_block, 0, c->stream, c->T, B);
-            timing_mark(c);
-            hipLaunchKernelGGL((k_invert_list<T, TO, false>), dim3(list_blocks), dim3(256), 0, c->stream, c->T, B);
+            if (mono) hipLaunchKernelGGL((k_invert_band<T, TO, false, true>), band_grid, band_block, 0, lc.stream, c->T, B);
+            else hipLaunchKernelGGL((k_invert_band<T, TO, true, true>), band_grid, band_block, 0, lc.stream, c->T, B);
+        } else if (mono) {
+            hipLaunchKernelGGL((k_invert_band<T, TO, false, false>), band_grid, band_block, 0, lc.stream, c->T, B);
         } else {
-            hipLaunchKernelGGL((k_invert_band<T, TO, true, false>), band_grid, band_block, 0, c->stream, c->T, B);
-            timing_mark(c);
-            hipLaunchKernelGGL((k_invert_list<T, TO, true>), dim3(list_blocks), dim3(256), 0, c->stream, c->T, B);
+            hipLaunchKernelGGL((k_invert_band<T, TO, true, false>), band_grid, band_block, 0, lc.stream, c->T, B);
         }
-        timing_mark(c);
-        HIPCHK(c, hipGetLastError());
+        if (lc.timing) timing_mark(c);
+        if (mono) hipLaunchKernelGGL((k_invert_list<T, TO, false>), dim3(list_blocks), dim3(256), 0, lc.stream, c->T, B);
+        else hipLaunchKernelGGL((k_invert_list<T, TO, true>), dim3(list_blocks), dim3(256), 0, lc.stream, c->T, B);
+        if (lc.timing) timing_mark(c);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return seterr(err, XSW_EHIP, "launch failed: %s", hipGetErrorString(e));
         return XSW_OK;
     }
-    if (algo == XSW_ALGO_PRUNED && !A.s_cr && !A.out_cr)
-        hipLaunchKernelGGL((k_invert<T, TO, 1, false>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, A);
+    if (algo == XSW_ALGO_PRUNED && mono)
+        hipLaunchKernelGGL((k_invert<T, TO, 1, false>), dim3((unsigned)nblocks), dim3(256), 0, lc.stream, c->T, A);
     else if (algo == XSW_ALGO_PRUNED)
-        hipLaunchKernelGGL((k_invert<T, TO, 1>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, A);
+        hipLaunchKernelGGL((k_invert<T, TO, 1>), dim3((unsigned)nblocks), dim3(256), 0, lc.stream, c->T, A);
     else
-        hipLaunchKernelGGL((k_invert<T, TO, 3>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->T, A);
-    HIPCHK(c, hipGetLastError());
+        hipLaunchKernelGGL((k_invert<T, TO, 3>), dim3((unsigned)nblocks), dim3(256), 0, lc.stream, c->T, A);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return seterr(err, XSW_EHIP, "launch failed: %s", hipGetErrorString(e));
     return XSW_OK;
 }
 
-static int dispatch_invert(xsw_ctx *c, const KArgs &A, int dtype, int out_dtype, int algo)
+static int dispatch_invert(xsw_ctx *c, const KArgs &A, int dtype, int out_dtype, int algo, const LaunchCtl &lc, std::string &err)
 {
-    if (dtype == XSW_F32 && out_dtype == XSW_F32) return launch_invert<float, float>(c, A, algo);
-    if (dtype == XSW_F32 && out_dtype == XSW_F64) return launch_invert<float, double>(c, A, algo);
-    if (dtype == XSW_F64 && out_dtype == XSW_F32) return launch_invert<double, float>(c, A, algo);
-    return launch_invert<double, double>(c, A, algo);
+    if (dtype == XSW_F32 && out_dtype == XSW_F32) return launch_invert<float, float>(c, A, algo, lc, err);
+    if (dtype == XSW_F32 && out_dtype == XSW_F64) return launch_invert<float, double>(c, A, algo, lc, err);
+    if (dtype == XSW_F64 && out_dtype == XSW_F32) return launch_invert<double, float>(c, A, algo, lc, err);
+    return launch_invert<double, double>(c, A, algo, lc, err);
+}
+
+// Work list of the device-raster path: an eighth of the raster's pixels (the benchmark scene leaves 0.06 %; a scene that
+// leaves more than an eighth overflows it, see k_invert_list).  A failed allocation selects the one-kernel path.
+static size_t list_entries_for(long long n) { return (size_t)std::max<long long>(n / 8, 1 << 16); }
+static void ensure_list(xsw_ctx *c, long long n)
+{
+    const size_t want = list_entries_for(n);
+    if (want <= c->list_cap) return;
+    (void)hipStreamSynchronize(c->stream);  // the old list may still be in use
+    if (c->d_list) (void)hipFree(c->d_list);
+    c->d_list = nullptr;
+    c->list_cap = 0;
+    static const bool no_list = getenv("XSW_FAIL_LIST_ALLOC") != nullptr;  // tests: the allocation-failure route
+    if (!no_list && hipMalloc((void **)&c->d_list, (want + 16) * sizeof(unsigned)) == hipSuccess) c->list_cap = want;
+    else { c->d_list = nullptr; (void)hipGetLastError(); }
+}
+
+// ---- grid codes -> complex winds (xsw.h: xsw_expand_codes)
+template <typename TO>
+__global__ __launch_bounds__(256) void k_expand(const double *__restrict__ sol, const double *__restrict__ dual_dir, const double *__restrict__ wcr,
+                                                long long plane, long long n, const unsigned *__restrict__ cc, const unsigned *__restrict__ cr,
+                                                typename Cx<TO>::type *__restrict__ out_co, typename Cx<TO>::type *__restrict__ out_cr)
+{
+    typedef typename Cx<TO>::type cx_t;
+    const double nan = __builtin_nan("");
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned a = cc ? cc[i] : K_CODE_NAN;
+        double co_re = nan, co_im = nan;
+        bool have_co = false;
+        long long k = 0;
+        if (a == K_CODE_NAN_RE) co_im = 0.0;
+        else if (a != K_CODE_NAN) {
+            k = (long long)(a & 0x3FFFFFFFu) + (long long)((a >> 30) & 1u) * plane;
+            const double2 z = ((const double2 *)sol)[k];
+            co_re = z.x; co_im = z.y;
+            have_co = true;
+        }
+        if (out_co) { cx_t z; z.x = (TO)co_re; z.y = (TO)co_im; out_co[i] = z; }
+        if (out_cr && cr) {
+            const unsigned b = cr[i];
+            double re = nan, im = nan;
+            if (b == K_CODE_NAN_RE) im = 0.0;
+            else if (b & K_CODE_PICK_CO) { re = co_re; im = co_im; }
+            else if ((b & K_CODE_NO_INDEX) != K_CODE_NO_INDEX) {
+                const double wd = wcr[b & K_CODE_NO_INDEX];
+                if (have_co) { const double2 u = ((const double2 *)dual_dir)[k]; re = wd * u.x; im = wd * u.y + 0.0 * u.x; }
+                else { re = wd; im = 0.0; }
+            }
+            cx_t z; z.x = (TO)re; z.y = (TO)im; out_cr[i] = z;
+        }
+    }
+}
+
+template <typename V>
+static inline void stream_store(V *p, V v)  // non-temporal when the address allows it: the output rasters are written once
+{
+    if (((uintptr_t)p & (sizeof(V) - 1)) == 0) __builtin_nontemporal_store(v, p);
+    else memcpy(p, &v, sizeof(V));
+}
+
+// Host counterpart of store_pixel / k_expand: the same table values, the same IEEE operations (this file is compiled with
+// -ffp-contract=off) -- the bits the device would have stored.  idx: optional int32[n][3] as xsw_invert's out_idx.
+template <typename TO>
+static void expand_host(const xsw_ctx *c, size_t n, const uint32_t *cc, const uint32_t *cr, TO *out_co, TO *out_cr, int32_t *idx)
+{
+    typedef TO cx_t __attribute__((ext_vector_type(2)));
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    const size_t plane = (size_t)c->T.n_w * c->T.n_phi;
+    const int nP = c->T.n_phi;
+    const double *sol = c->h_sol.data(), *dual = c->h_dual.data(), *wcr = c->h_wcr.data();
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t a = cc ? cc[i] : XSW_CODE_NAN;
+        double co_re = nan, co_im = nan;
+        bool have_co = false;
+        size_t k = 0;
+        if (a == XSW_CODE_NAN_RE) co_im = 0.0;
+        else if (a != XSW_CODE_NAN) {
+            k = (size_t)(a & 0x3FFFFFFFu) + (size_t)((a >> 30) & 1u) * plane;
+            co_re = sol[2 * k]; co_im = sol[2 * k + 1];
+            have_co = true;
+        }
+        if (out_co) { cx_t z; z.x = (TO)co_re; z.y = (TO)co_im; stream_store((cx_t *)(out_co + 2 * i), z); }
+        uint32_t b = XSW_CODE_NO_INDEX;
+        if (cr) {
+            b = cr[i];
+            if (out_cr) {
+                double re = nan, im = nan;
+                if (b == XSW_CODE_NAN_RE) im = 0.0;
+                else if (b & XSW_CODE_PICK_CO) { re = co_re; im = co_im; }
+                else if ((b & XSW_CODE_NO_INDEX) != XSW_CODE_NO_INDEX) {
+                    const double wd = wcr[b & XSW_CODE_NO_INDEX];
+                    if (have_co) { const double ux = dual[2 * k], uy = dual[2 * k + 1]; re = wd * ux; im = wd * uy + 0.0 * ux; }
+                    else { re = wd; im = 0.0; }
+                }
+                cx_t z; z.x = (TO)re; z.y = (TO)im; stream_store((cx_t *)(out_cr + 2 * i), z);
+            }
+        }
+        if (idx) {
+            const int flat = (int)(a & 0x3FFFFFFFu);
+            idx[3 * i + 0] = have_co ? flat / nP : -1;
+            idx[3 * i + 1] = have_co ? flat % nP : -1;
+            idx[3 * i + 2] = (b == XSW_CODE_NAN_RE || (b & XSW_CODE_NO_INDEX) == XSW_CODE_NO_INDEX) ? -1 : (int)(b & XSW_CODE_NO_INDEX);
+        }
+    }
+}
+
+static int check_codes_tables(xsw_ctx *c, const uint32_t *code_co, const uint32_t *code_cr)
+{
+    if (code_co && !c->have_co) return fail(c, XSW_ENOLUT, "co-pol codes given but no co-pol LUT on this context");
+    if (code_cr && !c->have_cr) return fail(c, XSW_ENOLUT, "cross-pol codes given but no cross-pol LUT on this context");
+    return XSW_OK;
+}
+
+extern "C" int xsw_expand_codes(xsw_ctx *c, int64_t n, int32_t mem, int32_t out_dtype, const uint32_t *code_co,
+                                const uint32_t *code_cr, void *out_co, void *out_cr)
+{
+    if (!c) return XSW_EINVAL;
+    if (n < 0 || (!code_co && !code_cr)) return fail(c, XSW_EINVAL, "expand_codes: no codes");
+    if (out_dtype != XSW_F32 && out_dtype != XSW_F64) return fail(c, XSW_EINVAL, "out_dtype must be XSW_F32 or XSW_F64");
+    if ((out_co && !code_co) || (out_cr && !code_cr)) return fail(c, XSW_EINVAL, "expand_codes: an output without its codes");
+    int rc = check_codes_tables(c, code_co, code_cr);
+    if (rc) return rc;
+    if (n == 0) return XSW_OK;
+    if (mem == XSW_MEM_DEVICE) {
+        HIPCHK(c, hipSetDevice(c->device));
+        const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, 256 * 16);
+        const long long plane = (long long)c->T.n_w * c->T.n_phi;
+        if (out_dtype == XSW_F32)
+            hipLaunchKernelGGL((k_expand<float>), dim3(blocks), dim3(256), 0, c->stream, c->T.sol, c->T.dual_dir, c->T.wcr, plane, (long long)n, code_co,
+                               code_cr, (Cx<float>::type *)out_co, (Cx<float>::type *)out_cr);
+        else
+            hipLaunchKernelGGL((k_expand<double>), dim3(blocks), dim3(256), 0, c->stream, c->T.sol, c->T.dual_dir, c->T.wcr, plane, (long long)n, code_co,
+                               code_cr, (Cx<double>::type *)out_co, (Cx<double>::type *)out_cr);
+        HIPCHK(c, hipGetLastError());
+        return XSW_OK;
+    }
+    if (out_dtype == XSW_F32) expand_host<float>(c, (size_t)n, code_co, code_cr, (float *)out_co, (float *)out_cr, nullptr);
+    else expand_host<double>(c, (size_t)n, code_co, code_cr, (double *)out_co, (double *)out_cr, nullptr);
+    return XSW_OK;
+}
+
+// ---- host-memory paths: chunks through a ring of workers (thread + stream + page-locked staging + device staging each)
+static int host_thread_count(const xsw_ctx *c)
+{
+    int n = c->host_threads;
+    if (n <= 0) {
+        const char *e = getenv("XSW_HOST_THREADS");
+        n = e ? atoi(e) : 8;
+    }
+    return std::max(1, std::min(n, 32));
+}
+
+static int worker_reserve(xsw_ctx::Worker &w, size_t pin_bytes, size_t dev_bytes, std::string &err)
+{
+    if (!w.s && hipStreamCreateWithFlags(&w.s, hipStreamNonBlocking) != hipSuccess) return seterr(err, XSW_EHIP, "stream create failed");
+    if (pin_bytes > w.pin_cap) {
+        if (w.pin) (void)hipHostFree(w.pin);
+        w.pin = nullptr; w.pin_cap = 0;
+        if (hipHostMalloc((void **)&w.pin, pin_bytes, hipHostMallocDefault) != hipSuccess) return seterr(err, XSW_ENOMEM, "hipHostMalloc(%zu) failed", pin_bytes);
+        w.pin_cap = pin_bytes;
+    }
+    if (dev_bytes > w.dev_cap) {
+        if (w.dev) (void)hipFree(w.dev);
+        w.dev = nullptr; w.dev_cap = 0;
+        if (hipMalloc((void **)&w.dev, dev_bytes) != hipSuccess) return seterr(err, XSW_ENOMEM, "hipMalloc(%zu) failed", dev_bytes);
+        w.dev_cap = dev_bytes;
+    }
+    return XSW_OK;
+}
+
+// body(k, worker, err) -> XSW_* runs chunk k start to finish (stage, upload, launch, download, synchronise its stream, write the
+// caller's output).  Chunks are dealt to min(threads, nchunks) workers; no exception crosses the ABI.
+template <class Body>
+static int run_chunks(xsw_ctx *c, long long nchunks, Body &&body)
+{
+    if (nchunks <= 0) return XSW_OK;
+    const int nthreads = (int)std::min<long long>(host_thread_count(c), nchunks);
+    if ((int)c->workers.size() < nthreads) c->workers.resize((size_t)nthreads);
+    std::atomic<long long> next{0};
+    std::atomic<int> rc{XSW_OK};
+    std::mutex mu;
+    std::string err;
+    auto loop = [&](int wi) {
+        std::string e;
+        int r = hipSetDevice(c->device) == hipSuccess ? XSW_OK : seterr(e, XSW_EHIP, "hipSetDevice failed in a worker thread");
+        while (!r && rc.load() == XSW_OK) {
+            const long long k = next.fetch_add(1);
+            if (k >= nchunks) break;
+            r = body(k, c->workers[(size_t)wi], e);
+        }
+        if (r) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (rc.load() == XSW_OK) { rc.store(r); err = e; }
+        }
+    };
+    std::vector<std::thread> threads;
+    int started = 0;
+    if (nthreads > 1) {
+        try {
+            for (int t = 1; t < nthreads; ++t) { threads.emplace_back(loop, t); ++started; }
+        } catch (...) { /* fewer threads than asked: the ones that started (and this one) take all the chunks */ }
+    }
+    loop(0);
+    for (auto &t : threads) t.join();
+    (void)started;
+    if (rc.load() != XSW_OK) return fail(c, rc.load(), "%s", err.c_str());
+    return XSW_OK;
 }
 
 extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
@@ -575,12 +868,12 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
     if (a->lines < 0 || a->samples < 0) return fail(c, XSW_EINVAL, "negative raster shape");
     if ((a->dtype != XSW_F32 && a->dtype != XSW_F64) || (a->out_dtype != XSW_F32 && a->out_dtype != XSW_F64))
         return fail(c, XSW_EINVAL, "dtype/out_dtype must be XSW_F32 or XSW_F64");
-    if (a->mem != XSW_MEM_HOST && a->mem != XSW_MEM_DEVICE) return fail(c, XSW_EINVAL, "bad mem kind");
+    if (a->mem != XSW_MEM_HOST && a->mem != XSW_MEM_DEVICE && a->mem != XSW_MEM_HOST_PINNED) return fail(c, XSW_EINVAL, "bad mem kind");
     if (!a->inc) return fail(c, XSW_EINVAL, "inc is NULL");
     if (!a->sigma0_co && !a->sigma0_cr) return fail(c, XSW_EINVAL, "neither sigma0_co nor sigma0_cr given");
     if (a->sigma0_co && !c->have_co) return fail(c, XSW_ENOLUT, "sigma0_co given but no co-pol LUT uploaded");
     if (a->sigma0_cr && !c->have_cr) return fail(c, XSW_ENOLUT, "sigma0_cr given but no cross-pol LUT uploaded");
-    if (a->sigma0_co && !a->out_co) return fail(c, XSW_EINVAL, "out_co is NULL");
+    if (a->sigma0_co && !a->out_co && !a->out_code_co) return fail(c, XSW_EINVAL, "out_co is NULL");
     if (a->algo < XSW_ALGO_AUTO || a->algo > XSW_ALGO_EXHAUSTIVE_F64) return fail(c, XSW_EINVAL, "unknown algo %d", a->algo);
     const long long n = (long long)a->lines * a->samples;
     if (n == 0) return XSW_OK;
@@ -608,148 +901,79 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
     if (a->mem == XSW_MEM_DEVICE) {
         A.inc = a->inc; A.s_co = a->sigma0_co; A.s_cr = a->sigma0_cr; A.dsig_cr = a->dsig_cr; A.anc = a->anc;
         A.out_co = a->out_co; A.out_cr = a->out_cr; A.out_idx = a->out_idx;
-        return dispatch_invert(c, A, a->dtype, a->out_dtype, algo);
+        A.code_co = a->out_code_co; A.code_cr = a->out_code_cr;
+        if (algo == XSW_ALGO_PRUNED) ensure_list(c, n);
+        std::string err;
+        const LaunchCtl lc{c->stream, c->d_list, c->list_cap, c->timing_on};
+        const int rc = dispatch_invert(c, A, a->dtype, a->out_dtype, algo, lc, err);
+        return rc ? fail(c, rc, "%s", err.c_str()) : XSW_OK;
     }
 
-    // Host rasters: device buffers for the whole raster, work cut into chunks of whole lines and software-
-    // pipelined so that the GPU inverts chunk k while the host side moves chunk k+1 in and chunk k-1 out
-    // (pageable hipMemcpyAsync blocks the host but not the device).  Three streams (uploads, kernels, downloads) and two
-    // events per chunk.
-    const size_t es = a->dtype == XSW_F32 ? 4 : 8, os = a->out_dtype == XSW_F32 ? 8 : 16;
-    int rc = XSW_OK;
-    // one arena for all staging rasters, 256-byte aligned slots
-    size_t need = 0;
-    auto slot = [&](bool want, size_t bytes) { const size_t o = need; if (want) need += (bytes + 255) & ~(size_t)255; return want ? o : (size_t)-1; };
-    const size_t o_inc = slot(true, n * es), o_co = slot(a->sigma0_co != nullptr, n * es), o_cr = slot(a->sigma0_cr != nullptr, n * es),
-                 o_dsig = slot(a->dsig_cr != nullptr, n * es), o_anc = slot(a->anc != nullptr, n * es * 2),
-                 o_oco = slot(a->out_co != nullptr, n * os), o_ocr = slot(a->out_cr != nullptr, n * os),
-                 o_idx = slot(a->out_idx != nullptr, n * 12);
-    if (need > c->arena_cap) {
-        if (c->arena) (void)hipFree(c->arena);
-        c->arena = nullptr;
-        c->arena_cap = 0;
-        if (hipMalloc((void **)&c->arena, need) != hipSuccess) return fail(c, XSW_ENOMEM, "hipMalloc(%zu) failed", need);
-        c->arena_cap = need;
-    }
-    auto at = [&](size_t o) -> void * { return o == (size_t)-1 ? nullptr : (void *)(c->arena + o); };
-    void *d_inc = at(o_inc), *d_co = at(o_co), *d_cr = at(o_cr), *d_dsig = at(o_dsig), *d_anc = at(o_anc), *d_oco = at(o_oco),
-         *d_ocr = at(o_ocr), *d_idx = at(o_idx);
-
-    // ~8 Mpx per chunk for large rasters; mid-size ones are still cut in ~8 chunks (>= 0.5 Mpx) so that they pipeline too
-    const long long target_px = std::min<long long>(8LL << 20, std::max<long long>(1LL << 19, (long long)(n / 8)));
+    // Host rasters.  Chunks of whole 4-line tile rows (~2 Mpx) go through the workers: stage the chunk's inputs into the
+    // worker's page-locked buffer (XSW_MEM_HOST_PINNED: skipped), ONE upload, the kernels on the worker's stream, ONE download
+    // of the grid codes, then the codes are expanded into the caller's rasters by the worker's thread while the other
+    // workers' chunks are in other phases.
+    if (c->stats_on) HIPCHK(c, hipStreamSynchronize(c->stream));  // the counters were reset on the context's stream
+    const bool pinned_in = a->mem == XSW_MEM_HOST_PINNED;
+    const size_t es = a->dtype == XSW_F32 ? 4 : 8;
+    const bool want_co = a->sigma0_co || a->out_co || a->out_code_co;
+    const bool want_cr = a->out_cr || a->out_code_cr || (a->sigma0_cr && a->out_idx);
+    const long long target_px = std::min<long long>(2LL << 20, std::max<long long>(1LL << 16, n / 16));
     long long lines_per_chunk = a->samples > 0 ? (target_px + a->samples - 1) / a->samples : a->lines;
-    if (lines_per_chunk < 4) lines_per_chunk = 4;
-    lines_per_chunk = (lines_per_chunk + 3) & ~3LL;  // whole 4-line tile rows
+    lines_per_chunk = (std::max<long long>(lines_per_chunk, 4) + 3) & ~3LL;  // whole 4-line tile rows
     const long long nchunks = (a->lines + lines_per_chunk - 1) / lines_per_chunk;
-    std::vector<hipEvent_t> done((size_t)nchunks, nullptr), ready((size_t)nchunks, nullptr);
-    if (!rc && ((!c->s_out && hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking) != hipSuccess) ||
-                (!c->s_in && hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking) != hipSuccess)))
-        rc = fail(c, XSW_EHIP, "stream create failed");
-    const hipStream_t s_out = c->s_out, s_in = c->s_in;
-    auto h2d = [&](void *d, const void *h, size_t off, size_t bytes) {
-        if (!rc && h && hipMemcpyAsync((char *)d + off, (const char *)h + off, bytes, hipMemcpyHostToDevice, s_in) != hipSuccess)
-            rc = fail(c, XSW_EHIP, "H2D copy failed");
-    };
-    // Downloads: pageable hipMemcpyAsync blocks the calling host thread for the length of the copy, so with more than
-    // two chunks they are issued by a second host thread -- uploads + launches and downloads then proceed side by side
-    // (one thread doing both is host-bound as soon as the outputs are as large as the inputs, e.g. complex128).
-    int drc = XSW_OK;          // downloader's status, merged after the join
-    std::string derr;
-    auto drain = [&](long long k) {  // outputs of chunk k -> host, once its kernel has finished
+    const size_t max_px = (size_t)std::min<long long>(lines_per_chunk, a->lines) * a->samples;
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    // staging layout of a chunk (the same offsets in the page-locked and the device buffer): inputs, then codes; list after
+    const size_t o_inc = 0, o_co = o_inc + pad(max_px * es), o_cr = o_co + (a->sigma0_co ? pad(max_px * es) : 0),
+                 o_dsig = o_cr + (a->sigma0_cr ? pad(max_px * es) : 0), o_anc = o_dsig + (a->dsig_cr ? pad(max_px * es) : 0),
+                 o_cc = o_anc + (a->anc ? pad(max_px * es * 2) : 0), o_ccr = o_cc + (want_co ? pad(max_px * 4) : 0),
+                 o_end = o_ccr + (want_cr ? pad(max_px * 4) : 0);
+    const size_t list_cap = std::max<size_t>(max_px / 4, 1 << 14), dev_bytes = o_end + (list_cap + 16) * sizeof(unsigned);
+    const int dtype = a->dtype, out_dtype = a->out_dtype;
+    return run_chunks(c, nchunks, [&](long long k, xsw_ctx::Worker &w, std::string &err) -> int {
+        int rc = worker_reserve(w, o_end, dev_bytes, err);
+        if (rc) return rc;
         const long long l0 = k * lines_per_chunk, l1 = std::min((long long)a->lines, l0 + lines_per_chunk);
         const size_t px0 = (size_t)l0 * a->samples, npx = (size_t)(l1 - l0) * a->samples;
-        auto d2h = [&](void *h, const void *d, size_t off, size_t bytes) {
-            if (!drc && h && hipMemcpyAsync((char *)h + off, (const char *)d + off, bytes, hipMemcpyDeviceToHost, s_out) != hipSuccess) {
-                drc = XSW_EHIP;
-                derr = "D2H copy failed";
-            }
+        hipError_t e = hipSuccess;
+        auto up = [&](const void *h, size_t off, size_t elem) {  // one raster of the chunk: host -> (staging ->) device
+            if (!h || e != hipSuccess) return;
+            const char *src = (const char *)h + px0 * elem;
+            if (pinned_in) e = hipMemcpyAsync(w.dev + off, src, npx * elem, hipMemcpyHostToDevice, w.s);
+            else memcpy(w.pin + off, src, npx * elem);
         };
-        if (!drc && hipStreamWaitEvent(s_out, done[(size_t)k], 0) != hipSuccess) { drc = XSW_EHIP; derr = "stream wait failed"; }
-        d2h(a->out_co, d_oco, px0 * os, npx * os);
-        d2h(a->out_cr, d_ocr, px0 * os, npx * os);
-        d2h(a->out_idx, d_idx, px0 * 12, npx * 12);
-    };
-    std::mutex mu;
-    std::condition_variable cv;
-    long long launched = 0;   // chunks whose kernel and `done` event are enqueued (guarded by mu)
-    bool stop = false;
-    bool threaded = nchunks > 2 && !rc;
-    std::thread downloader;
-    if (threaded) try {
-        downloader = std::thread([&] {
-            if (hipSetDevice(c->device) != hipSuccess) { drc = XSW_EHIP; derr = "hipSetDevice failed in the download thread"; }
-            for (long long k = 0; k < nchunks; ++k) {
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return launched > k || stop; });
-                    if (launched <= k) return;  // the launch loop gave up
-                }
-                drain(k);
-            }
-        });
-    } catch (...) {  // no exception crosses the ABI: fall back to issuing the downloads from this thread
-        threaded = false;
-    }
-    for (long long k = 0; k < nchunks && !rc; ++k) {
-        const long long l0 = k * lines_per_chunk, l1 = std::min((long long)a->lines, l0 + lines_per_chunk);
-        const size_t px0 = (size_t)l0 * a->samples, npx = (size_t)(l1 - l0) * a->samples;
-        h2d(d_inc, a->inc, px0 * es, npx * es);
-        h2d(d_co, a->sigma0_co, px0 * es, npx * es);
-        h2d(d_cr, a->sigma0_cr, px0 * es, npx * es);
-        h2d(d_dsig, a->dsig_cr, px0 * es, npx * es);
-        h2d(d_anc, a->anc, px0 * es * 2, npx * es * 2);
-        // the uploads ride their own stream (in the kernels' stream they would queue up behind the previous chunk's
-        // kernel instead of overlapping it); the kernel of chunk k waits for its inputs only
-        if (!rc && (hipEventCreateWithFlags(&ready[(size_t)k], hipEventDisableTiming) != hipSuccess ||
-                    hipEventRecord(ready[(size_t)k], s_in) != hipSuccess ||
-                    hipStreamWaitEvent(c->stream, ready[(size_t)k], 0) != hipSuccess))
-            rc = fail(c, XSW_EHIP, "event record failed");
+        up(a->inc, o_inc, es); up(a->sigma0_co, o_co, es); up(a->sigma0_cr, o_cr, es); up(a->dsig_cr, o_dsig, es); up(a->anc, o_anc, es * 2);
+        if (!pinned_in && e == hipSuccess) e = hipMemcpyAsync(w.dev, w.pin, o_cc, hipMemcpyHostToDevice, w.s);  // all inputs in one copy
+        if (e != hipSuccess) return seterr(err, XSW_EHIP, "H2D copy failed: %s", hipGetErrorString(e));
         KArgs B = A;
         B.lines = l1 - l0;
         B.n = (long long)npx;
-        B.inc = (const char *)d_inc + px0 * es;
-        B.s_co = d_co ? (const char *)d_co + px0 * es : nullptr;
-        B.s_cr = d_cr ? (const char *)d_cr + px0 * es : nullptr;
-        B.dsig_cr = d_dsig ? (const char *)d_dsig + px0 * es : nullptr;
-        B.anc = d_anc ? (const char *)d_anc + px0 * es * 2 : nullptr;
-        B.out_co = d_oco ? (char *)d_oco + px0 * os : nullptr;
-        B.out_cr = d_ocr ? (char *)d_ocr + px0 * os : nullptr;
-        B.out_idx = d_idx ? (int *)((char *)d_idx + px0 * 12) : nullptr;
-        if (!rc) rc = dispatch_invert(c, B, a->dtype, a->out_dtype, algo);
-        if (!rc && (hipEventCreateWithFlags(&done[(size_t)k], hipEventDisableTiming) != hipSuccess ||
-                    hipEventRecord(done[(size_t)k], c->stream) != hipSuccess))
-            rc = fail(c, XSW_EHIP, "event record failed");
-        if (threaded) {
-            if (!rc) {
-                std::lock_guard<std::mutex> lk(mu);
-                launched = k + 1;
-            }
-            cv.notify_one();
-        } else if (k > 0 && !rc) drain(k - 1);  // overlaps with the kernel of chunk k
-    }
-    if (threaded) {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            stop = true;
+        B.inc = w.dev + o_inc;
+        B.s_co = a->sigma0_co ? w.dev + o_co : nullptr;
+        B.s_cr = a->sigma0_cr ? w.dev + o_cr : nullptr;
+        B.dsig_cr = a->dsig_cr ? w.dev + o_dsig : nullptr;
+        B.anc = a->anc ? w.dev + o_anc : nullptr;
+        B.code_co = want_co ? (unsigned *)(w.dev + o_cc) : nullptr;
+        B.code_cr = want_cr ? (unsigned *)(w.dev + o_ccr) : nullptr;
+        const LaunchCtl lc{w.s, (unsigned *)(w.dev + o_end), list_cap, false};
+        rc = dispatch_invert(c, B, dtype, out_dtype, algo, lc, err);
+        if (rc) return rc;
+        if (o_end > o_cc) e = hipMemcpyAsync(w.pin + o_cc, w.dev + o_cc, o_end - o_cc, hipMemcpyDeviceToHost, w.s);
+        if (e == hipSuccess) e = hipStreamSynchronize(w.s);
+        if (e != hipSuccess) return seterr(err, XSW_EHIP, "kernel execution failed: %s", hipGetErrorString(e));
+        const uint32_t *cc = want_co ? (const uint32_t *)(w.pin + o_cc) : nullptr, *ccr = want_cr ? (const uint32_t *)(w.pin + o_ccr) : nullptr;
+        if (a->out_code_co && cc) memcpy(a->out_code_co + px0, cc, npx * 4);
+        if (a->out_code_cr && ccr) memcpy(a->out_code_cr + px0, ccr, npx * 4);
+        int32_t *idx = a->out_idx ? a->out_idx + 3 * px0 : nullptr;
+        if (a->out_co || a->out_cr || idx) {
+            if (out_dtype == XSW_F32)
+                expand_host<float>(c, npx, cc, ccr, a->out_co ? (float *)a->out_co + 2 * px0 : nullptr, a->out_cr ? (float *)a->out_cr + 2 * px0 : nullptr, idx);
+            else
+                expand_host<double>(c, npx, cc, ccr, a->out_co ? (double *)a->out_co + 2 * px0 : nullptr, a->out_cr ? (double *)a->out_cr + 2 * px0 : nullptr, idx);
         }
-        cv.notify_one();
-        downloader.join();
-    } else if (!rc && nchunks > 0) drain(nchunks - 1);
-    if (!rc && drc) rc = fail(c, drc, "%s", derr.c_str());
-    hipError_t se = hipStreamSynchronize(c->stream);
-    hipError_t so = s_out ? hipStreamSynchronize(s_out) : hipSuccess;
-    if (!rc && (se != hipSuccess || so != hipSuccess))
-        rc = fail(c, XSW_EHIP, "kernel execution failed: %s", hipGetErrorString(se != hipSuccess ? se : so));
-    hipError_t si = s_in ? hipStreamSynchronize(s_in) : hipSuccess;
-    if (!rc && si != hipSuccess) rc = fail(c, XSW_EHIP, "upload failed: %s", hipGetErrorString(si));
-    for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : ready) if (e) (void)hipEventDestroy(e);
-    if (c->arena_cap > XSW_ARENA_KEEP) {  // do not sit on a huge staging area
-        (void)hipFree(c->arena);
-        c->arena = nullptr;
-        c->arena_cap = 0;
-    }
-    return rc;
+        return XSW_OK;
+    });
 }
 
 // ---------------------------------------------------------------------------------------- LUT interpolation
@@ -998,6 +1222,7 @@ extern "C" int xsw_detrend(xsw_ctx *c, int64_t lines, int64_t samples, int32_t d
     const size_t es = dtype == XSW_F32 ? 4 : 8, os = out_dtype == XSW_F32 ? 4 : 8;
     // the ratio row lives in a context-owned buffer (grown on demand): no allocation on the steady-state path
     if ((size_t)samples > c->ratio_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // a previous asynchronous call may still read the old row
         if (c->d_ratio) (void)hipFree(c->d_ratio);
         c->d_ratio = nullptr;
         c->ratio_cap = 0;
@@ -1019,103 +1244,45 @@ extern "C" int xsw_detrend(xsw_ctx *c, int64_t lines, int64_t samples, int32_t d
     double *d_rinv = c->d_ratio + samples;
     hipError_t e = hipMemcpyAsync(c->d_ratio, both.data(), 2 * (size_t)samples * sizeof(double), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // `both` is a local
-    auto launch = [&](const void *din, void *dout, long long nl) {
-        if (dtype == XSW_F32 && out_dtype == XSW_F32) launch_detrend<float, float>(c->stream, din, c->d_ratio, d_rinv, fast, dout, nl, samples);
-        else if (dtype == XSW_F32) launch_detrend<float, double>(c->stream, din, c->d_ratio, d_rinv, fast, dout, nl, samples);
-        else if (out_dtype == XSW_F32) launch_detrend<double, float>(c->stream, din, c->d_ratio, d_rinv, fast, dout, nl, samples);
-        else launch_detrend<double, double>(c->stream, din, c->d_ratio, d_rinv, fast, dout, nl, samples);
+    auto launch = [&](const void *din, void *dout, long long nl, hipStream_t st) {
+        if (dtype == XSW_F32 && out_dtype == XSW_F32) launch_detrend<float, float>(st, din, c->d_ratio, d_rinv, fast, dout, nl, samples);
+        else if (dtype == XSW_F32) launch_detrend<float, double>(st, din, c->d_ratio, d_rinv, fast, dout, nl, samples);
+        else if (out_dtype == XSW_F32) launch_detrend<double, float>(st, din, c->d_ratio, d_rinv, fast, dout, nl, samples);
+        else launch_detrend<double, double>(st, din, c->d_ratio, d_rinv, fast, dout, nl, samples);
         return hipGetLastError();
     };
     if (mem == XSW_MEM_DEVICE) {  // device rasters: asynchronous on the context's stream
-        if (e == hipSuccess) e = launch(sigma0, out, lines);
+        if (e == hipSuccess) e = launch(sigma0, out, lines, c->stream);
         if (e != hipSuccess) return fail(c, XSW_EHIP, "detrend failed: %s", hipGetErrorString(e));
         return XSW_OK;
     }
-    // Host rasters (synchronous): the same three-stream pipeline as xsw_invert -- uploads, kernels and downloads of
-    // successive line chunks overlap; the downloads are issued by a second host thread (a pageable copy blocks its caller).
+    // Host rasters (synchronous): line chunks through the workers of the host-memory path (page-locked staging, one stream per
+    // worker: staging copies, uploads, kernels and downloads of different chunks overlap).
     if (e != hipSuccess) return fail(c, XSW_EHIP, "detrend failed: %s", hipGetErrorString(e));
-    const size_t in_bytes = ((size_t)n * es + 255) & ~(size_t)255, need = in_bytes + (size_t)n * os;
-    if (need > c->arena_cap) {
-        if (c->arena) (void)hipFree(c->arena);
-        c->arena = nullptr;
-        c->arena_cap = 0;
-        if (hipMalloc((void **)&c->arena, need) != hipSuccess) return fail(c, XSW_ENOMEM, "hipMalloc(%zu) failed", need);
-        c->arena_cap = need;
-    }
-    if ((!c->s_out && hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking) != hipSuccess) ||
-        (!c->s_in && hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking) != hipSuccess))
-        return fail(c, XSW_EHIP, "stream create failed");
-    char *t_in = c->arena, *t_out = c->arena + in_bytes;
-    const long long target_px = std::min<long long>(16LL << 20, std::max<long long>(1LL << 19, n / 8));
+    const bool pinned = mem == XSW_MEM_HOST_PINNED;
+    const long long target_px = std::min<long long>(4LL << 20, std::max<long long>(1LL << 16, n / 16));
     long long lpc = samples > 0 ? (target_px + samples - 1) / samples : lines;
     if (lpc < 1) lpc = 1;
     const long long nchunks = (lines + lpc - 1) / lpc;
-    std::vector<hipEvent_t> done((size_t)nchunks, nullptr), ready((size_t)nchunks, nullptr);
-    hipError_t de = hipSuccess;  // downloader's status
-    auto drain = [&](long long k) {
+    const size_t max_px = (size_t)std::min<long long>(lpc, lines) * samples;
+    const size_t o_out = ((size_t)max_px * es + 255) & ~(size_t)255, total = o_out + max_px * os;
+    return run_chunks(c, nchunks, [&](long long k, xsw_ctx::Worker &w, std::string &err) -> int {
+        int rc = worker_reserve(w, pinned ? 0 : total, total, err);
+        if (rc) return rc;
         const long long l0 = k * lpc, l1 = std::min((long long)lines, l0 + lpc);
         const size_t px0 = (size_t)l0 * samples, npx = (size_t)(l1 - l0) * samples;
-        if (de == hipSuccess) de = hipStreamWaitEvent(c->s_out, done[(size_t)k], 0);
-        if (de == hipSuccess) de = hipMemcpyAsync((char *)out + px0 * os, t_out + px0 * os, npx * os, hipMemcpyDeviceToHost, c->s_out);
-    };
-    std::mutex mu;
-    std::condition_variable cv;
-    long long launched = 0;
-    bool stop = false;
-    bool threaded = nchunks > 2;
-    std::thread downloader;
-    if (threaded) try {
-        downloader = std::thread([&] {
-            de = hipSetDevice(c->device);
-            for (long long k = 0; k < nchunks; ++k) {
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return launched > k || stop; });
-                    if (launched <= k) return;
-                }
-                drain(k);
-            }
-        });
-    } catch (...) {  // no exception crosses the ABI: fall back to issuing the downloads from this thread
-        threaded = false;
-    }
-    for (long long k = 0; k < nchunks && e == hipSuccess; ++k) {
-        const long long l0 = k * lpc, l1 = std::min((long long)lines, l0 + lpc);
-        const size_t px0 = (size_t)l0 * samples, npx = (size_t)(l1 - l0) * samples;
-        e = hipMemcpyAsync(t_in + px0 * es, (const char *)sigma0 + px0 * es, npx * es, hipMemcpyHostToDevice, c->s_in);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ready[(size_t)k], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventRecord(ready[(size_t)k], c->s_in);
-        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ready[(size_t)k], 0);
-        if (e == hipSuccess) e = launch(t_in + px0 * es, t_out + px0 * os, l1 - l0);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[(size_t)k], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventRecord(done[(size_t)k], c->stream);
-        if (threaded) {
-            if (e == hipSuccess) {
-                std::lock_guard<std::mutex> lk(mu);
-                launched = k + 1;
-            }
-            cv.notify_one();
-        } else if (e == hipSuccess && k > 0) drain(k - 1);
-    }
-    if (threaded) {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            stop = true;
-        }
-        cv.notify_one();
-        downloader.join();
-    } else if (e == hipSuccess && nchunks > 0) drain(nchunks - 1);
-    hipError_t s1 = hipStreamSynchronize(c->s_in), s2 = hipStreamSynchronize(c->stream), s3 = hipStreamSynchronize(c->s_out);
-    for (hipEvent_t ev : done) if (ev) (void)hipEventDestroy(ev);
-    for (hipEvent_t ev : ready) if (ev) (void)hipEventDestroy(ev);
-    if (c->arena_cap > XSW_ARENA_KEEP) {
-        (void)hipFree(c->arena);
-        c->arena = nullptr;
-        c->arena_cap = 0;
-    }
-    for (hipError_t x : {de, s1, s2, s3}) if (e == hipSuccess) e = x;
-    if (e != hipSuccess) return fail(c, XSW_EHIP, "detrend failed: %s", hipGetErrorString(e));
-    return XSW_OK;
+        const char *src = (const char *)sigma0 + px0 * es;
+        char *dst = (char *)out + px0 * os;
+        hipError_t ee;
+        if (pinned) ee = hipMemcpyAsync(w.dev, src, npx * es, hipMemcpyHostToDevice, w.s);
+        else { memcpy(w.pin, src, npx * es); ee = hipMemcpyAsync(w.dev, w.pin, npx * es, hipMemcpyHostToDevice, w.s); }
+        if (ee == hipSuccess) ee = launch(w.dev, w.dev + o_out, l1 - l0, w.s);
+        if (ee == hipSuccess) ee = hipMemcpyAsync(pinned ? dst : w.pin + o_out, w.dev + o_out, npx * os, hipMemcpyDeviceToHost, w.s);
+        if (ee == hipSuccess) ee = hipStreamSynchronize(w.s);
+        if (ee != hipSuccess) return seterr(err, XSW_EHIP, "detrend failed: %s", hipGetErrorString(ee));
+        if (!pinned) memcpy(dst, w.pin + o_out, npx * os);
+        return XSW_OK;
+    });
 }
 
 // ---------------------------------------------------------------------------------------- cross-pol noise flattening
@@ -1135,13 +1302,37 @@ static hipError_t launch_nesz(hipStream_t s, const void *noise, const void *inc,
     return hipGetLastError();
 }
 
+// Moves `bytes` between a host buffer and the device through the workers' page-locked staging (32 MB pieces, side by side).
+static int move_through_workers(xsw_ctx *c, void *host, void *dev, size_t bytes, bool to_device, bool pinned)
+{
+    const size_t piece = (size_t)32 << 20;
+    const long long np = (long long)((bytes + piece - 1) / piece);
+    return run_chunks(c, np, [&](long long k, xsw_ctx::Worker &w, std::string &err) -> int {
+        int rc = worker_reserve(w, pinned ? 0 : piece, 0, err);
+        if (rc) return rc;
+        const size_t off = (size_t)k * piece, nb = std::min(piece, bytes - off);
+        char *h = (char *)host + off, *d = (char *)dev + off;
+        hipError_t e;
+        if (to_device) {
+            if (pinned) e = hipMemcpyAsync(d, h, nb, hipMemcpyHostToDevice, w.s);
+            else { memcpy(w.pin, h, nb); e = hipMemcpyAsync(d, w.pin, nb, hipMemcpyHostToDevice, w.s); }
+            if (e == hipSuccess) e = hipStreamSynchronize(w.s);
+        } else {
+            e = hipMemcpyAsync(pinned ? h : w.pin, d, nb, hipMemcpyDeviceToHost, w.s);
+            if (e == hipSuccess) e = hipStreamSynchronize(w.s);
+            if (e == hipSuccess && !pinned) memcpy(h, w.pin, nb);
+        }
+        return e == hipSuccess ? XSW_OK : seterr(err, XSW_EHIP, "staged copy failed: %s", hipGetErrorString(e));
+    });
+}
+
 extern "C" int xsw_nesz_flatten(xsw_ctx *c, int64_t lines, int64_t samples, int32_t dtype, int32_t mem, const void *noise,
                                 const void *inc, double *out)
 {
     if (!c) return XSW_EINVAL;
     if (lines < 0 || samples < 0 || !noise || !inc || !out) return fail(c, XSW_EINVAL, "bad nesz_flatten argument");
     if (dtype != XSW_F32 && dtype != XSW_F64) return fail(c, XSW_EINVAL, "dtype must be XSW_F32 or XSW_F64");
-    if (mem != XSW_MEM_HOST && mem != XSW_MEM_DEVICE) return fail(c, XSW_EINVAL, "bad mem kind");
+    if (mem != XSW_MEM_HOST && mem != XSW_MEM_DEVICE && mem != XSW_MEM_HOST_PINNED) return fail(c, XSW_EINVAL, "bad mem kind");
     if (lines > 0x7fffffffLL) return fail(c, XSW_EINVAL, "raster too large for one launch");
     const long long n = (long long)lines * samples;
     if (n == 0) return XSW_OK;
@@ -1153,31 +1344,50 @@ extern "C" int xsw_nesz_flatten(xsw_ctx *c, int64_t lines, int64_t samples, int3
     nb = std::max<long long>(1, std::min<long long>(std::min<long long>(nb, (lines + 7) / 8), 65535));
     const long long lpb = (lines + nb - 1) / nb;
     nb = (lines + lpb - 1) / lpb;
+    // context-owned scratch (column partials, means, centring abscissa), grown on demand: no allocation on the steady-state path
     const size_t scratch_bytes = (size_t)nb * samples * sizeof(NeszPartial) + (2 * (size_t)samples + 8) * sizeof(double);
-    void *scratch = nullptr;
-    HIPCHK(c, hipMalloc(&scratch, scratch_bytes));
-    hipError_t e = hipSuccess;
-    const void *d_noise = noise, *d_inc = inc;
-    double *d_out = out;
-    void *stage = nullptr;
-    if (mem == XSW_MEM_HOST) {
-        const size_t in_b = ((size_t)n * es + 255) & ~(size_t)255;
-        e = hipMalloc(&stage, 2 * in_b + (size_t)n * 8);
-        if (e == hipSuccess) {
-            d_noise = stage; d_inc = (char *)stage + in_b; d_out = (double *)((char *)stage + 2 * in_b);
-            e = hipMemcpyAsync((void *)d_noise, noise, (size_t)n * es, hipMemcpyHostToDevice, c->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync((void *)d_inc, inc, (size_t)n * es, hipMemcpyHostToDevice, c->stream);
-        }
+    if (scratch_bytes > c->nesz_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // a previous call may still be using the old scratch
+        if (c->nesz_scratch) (void)hipFree(c->nesz_scratch);
+        c->nesz_scratch = nullptr;
+        c->nesz_cap = 0;
+        HIPCHK(c, hipMalloc(&c->nesz_scratch, scratch_bytes));
+        c->nesz_cap = scratch_bytes;
     }
-    if (e == hipSuccess)
-        e = dtype == XSW_F32 ? launch_nesz<float>(c->stream, d_noise, d_inc, scratch, d_out, lines, samples, (int)nb, lpb)
-                             : launch_nesz<double>(c->stream, d_noise, d_inc, scratch, d_out, lines, samples, (int)nb, lpb);
-    if (mem == XSW_MEM_HOST && e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream);
-    // the scratch (and the staging area) are call-local: wait for the stream before freeing them
-    hipError_t se = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = se;
-    (void)hipFree(scratch);
-    if (stage) (void)hipFree(stage);
-    if (e != hipSuccess) return fail(c, e == hipErrorOutOfMemory ? XSW_ENOMEM : XSW_EHIP, "nesz_flatten failed: %s", hipGetErrorString(e));
-    return XSW_OK;
+    auto launch = [&](const void *dn, const void *di, double *dout) {
+        return dtype == XSW_F32 ? launch_nesz<float>(c->stream, dn, di, c->nesz_scratch, dout, lines, samples, (int)nb, lpb)
+                                : launch_nesz<double>(c->stream, dn, di, c->nesz_scratch, dout, lines, samples, (int)nb, lpb);
+    };
+    if (mem == XSW_MEM_DEVICE) {  // asynchronous on the context's stream, like xsw_invert / xsw_detrend
+        const hipError_t e = launch(noise, inc, out);
+        if (e != hipSuccess) return fail(c, XSW_EHIP, "nesz_flatten failed: %s", hipGetErrorString(e));
+        return XSW_OK;
+    }
+    // host rasters: the column means need the whole raster before the per-line pass, so the rasters are uploaded whole (through
+    // the workers' page-locked staging), the four kernels run, and the result comes back the same way
+    const size_t in_b = ((size_t)n * es + 255) & ~(size_t)255, need = 2 * in_b + (size_t)n * 8;
+    if (need > c->arena_cap) {
+        if (c->arena) (void)hipFree(c->arena);
+        c->arena = nullptr;
+        c->arena_cap = 0;
+        if (hipMalloc((void **)&c->arena, need) != hipSuccess) return fail(c, XSW_ENOMEM, "hipMalloc(%zu) failed", need);
+        c->arena_cap = need;
+    }
+    const bool pinned = mem == XSW_MEM_HOST_PINNED;
+    char *d_noise = c->arena, *d_inc = c->arena + in_b;
+    double *d_out = (double *)(c->arena + 2 * in_b);
+    int rc = move_through_workers(c, (void *)noise, d_noise, (size_t)n * es, true, pinned);
+    if (!rc) rc = move_through_workers(c, (void *)inc, d_inc, (size_t)n * es, true, pinned);
+    if (!rc) {
+        hipError_t e = launch(d_noise, d_inc, d_out);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(c, XSW_EHIP, "nesz_flatten failed: %s", hipGetErrorString(e));
+    }
+    if (!rc) rc = move_through_workers(c, out, d_out, (size_t)n * 8, false, pinned);
+    if (c->arena_cap > XSW_ARENA_KEEP) {  // do not sit on a huge staging area
+        (void)hipFree(c->arena);
+        c->arena = nullptr;
+        c->arena_cap = 0;
+    }
+    return rc;
 }

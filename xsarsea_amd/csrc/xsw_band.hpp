@@ -342,7 +342,8 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_inve
             unsigned base = 0;
             if (lane == 0) base = atomicAdd(A.list_count, (unsigned)__popcll(um));
             base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-            if (unresolved) A.list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u))] = (unsigned)i;
+            const unsigned at = base + __builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
+            if (unresolved && at < A.list_cap) A.list[at] = (unsigned)i;  // past the capacity: k_invert_list sees count > cap and takes every tile
         }
     }
     if (in) {

@@ -41,6 +41,7 @@ struct DevTables {
     const double *out_dir;   // [2][n_phi][2]       exp(1j*deg2rad(+-phi))
     const double *abs_co;    // [n_w][n_phi]        |w*exp(1j*deg2rad(phi))|
     const double *dual_dir;  // [2][n_w][n_phi][2]  exp(1j*angle(sol / sol_2))
+    const double *sol;       // [2][n_w][n_phi][2]  w * exp(1j*deg2rad(+-phi)): the co-pol winds themselves (k_expand)
     int n_inc, n_w, n_phi, phi_pad, w_pad;
     int phi_180;   // windspeed.py:152-156
     int prunable;  // uniform axes, finite LUT: branch-and-bound allowed
@@ -72,13 +73,20 @@ struct KArgs {
     const void *inc, *s_co, *s_cr, *dsig_cr, *anc;
     void *out_co, *out_cr;
     int *out_idx;
+    unsigned *code_co, *code_cr;  // nullable: the answer as 4-byte grid codes (xsw.h: xsw_invert_args.out_code_*)
     unsigned long long *stats;  // [4]: pixels_co, cand_co, pixels_exact, pixels_cr (nullable)
     unsigned *list;             // two-kernel path (nullable): k_invert_band appends the flat index of every pixel it leaves
     unsigned *list_count;       // undecided; k_invert_list then inverts exactly those, 64 per wave
+    unsigned list_cap;          // entries the list holds; the counter runs on past it (overflow: k_invert_list takes every tile)
     long long n, lines, samples;
     double dsig_co, inv_dsig_co, dsig_cr_scalar;
     int is_db, dual_select;
 };
+
+// grid codes (xsw.h): bits 0..29 flat index (i_wspd * n_phi + i_phi; cross-pol: i_wspd_cr), bit 30 the -phi solution
+// (cross-pol: bit 30 = the dual select picked the co-pol wind, index 0x3FFFFFFF = no cross-pol search ran)
+enum : unsigned { K_CODE_NAN_RE = 0xFFFFFFFFu /* (nan, 0) */, K_CODE_NAN = 0xFFFFFFFEu /* (nan, nan) */,
+                  K_CODE_PICK_CO = 0x40000000u, K_CODE_NO_INDEX = 0x3FFFFFFFu };
 
 enum : int { F_NEED_CO = 1, F_NEED_CR = 2, F_EARLY_NAN = 4, F_CO_FINITE = 8, F_CR_RAW_NAN = 16 /* band kernel: a raw cross-pol input is NaN */ };
 
@@ -1009,10 +1017,10 @@ __device__ __forceinline__ void store_pixel(const DevTables &L, const KArgs &A, 
     const double nan = __builtin_nan("");
     double co_re, co_im, cr_re, cr_im;
     int o_iw = -1, o_ip = -1;
+    int sgn = 0;
     if (P.flags & F_EARLY_NAN) {
         co_re = nan; co_im = 0.0; cr_re = nan; cr_im = 0.0;  // out[i] = np.nan -> (nan + 0j)
     } else {
-        int sgn = 0;
         if (P.flags & F_NEED_CO) {
             // flat < 2^30, n_phi < 2^16: (flat + 0.5) / n_phi is at least 0.5 / n_phi away from an integer, the product's error ~1e-7 of that
             o_iw = (int)(((double)my_flat + 0.5) * L.inv_nphi);
@@ -1059,7 +1067,11 @@ __device__ __forceinline__ void store_pixel(const DevTables &L, const KArgs &A, 
         cx_t z; z.x = (TO)co_re; z.y = (TO)co_im;
         ((cx_t *)A.out_co)[i] = z;
     }
-    if (CR && A.out_cr) {
+    // the answer as grid codes (xsw.h): what xsw_expand_codes turns back into exactly the values formed above
+    if (A.code_co)
+        A.code_co[i] = (P.flags & F_EARLY_NAN) ? K_CODE_NAN_RE : (P.flags & F_NEED_CO) ? ((unsigned)my_flat | ((unsigned)sgn << 30)) : K_CODE_NAN;
+    if (CR && (A.out_cr || A.code_cr)) {
+        bool picked_co = false;
         if (A.dual_select) {  // xr.where((|co| < 5) | (|dual| < 5), co, dual)  (windspeed.py:426-428)
             // without a co-pol search wind_co is (nan, nan) or (nan, 0): |wind_co| is NaN, never < 5
             const double aco = (P.flags & F_NEED_CO) ? L.abs_co[(size_t)o_iw * L.n_phi + o_ip] : nan;
@@ -1069,10 +1081,15 @@ __device__ __forceinline__ void store_pixel(const DevTables &L, const KArgs &A, 
                 const double wd = L.wcr[my_icr];
                 dual_small = wd < 5.0 - 1e-9 ? true : (wd > 5.0 + 1e-9 ? false : hypot_glibc(cr_re, cr_im) < 5.0);
             }
-            if (aco < 5.0 || dual_small) { cr_re = co_re; cr_im = co_im; }
+            if (aco < 5.0 || dual_small) { cr_re = co_re; cr_im = co_im; picked_co = true; }
         }
-        cx_t z; z.x = (TO)cr_re; z.y = (TO)cr_im;
-        ((cx_t *)A.out_cr)[i] = z;
+        if (A.out_cr) {
+            cx_t z; z.x = (TO)cr_re; z.y = (TO)cr_im;
+            ((cx_t *)A.out_cr)[i] = z;
+        }
+        if (A.code_cr)
+            A.code_cr[i] = (P.flags & F_EARLY_NAN) ? K_CODE_NAN_RE
+                                                     : (((P.flags & F_NEED_CR) ? (unsigned)my_icr : K_CODE_NO_INDEX) | (picked_co ? K_CODE_PICK_CO : 0u));
     }
     if (A.out_idx) {
         A.out_idx[3 * i + 0] = o_iw;
@@ -1221,6 +1238,23 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert_list(
     const int lane = threadIdx.x & 63;
     const long long count = (long long)*A.list_count;
     const long long nwaves = (long long)gridDim.x * 4;
+    if (count > (long long)A.list_cap) {
+        // the list overflowed (k_invert_band kept counting but could not append): its pixels are unknown, so every tile of the
+        // raster is inverted by the general algorithm -- k_invert's tile walk as a grid-stride loop.  Results do not depend on
+        // which kernel wrote a pixel; only scenes that defeat the band rule wholesale come here.
+        const long long strips_per_line = (A.samples + 63) >> 6, line_groups = (A.lines + 3) >> 2;
+        const long long cols_per_xcd = (strips_per_line + 7) >> 3, nb = 8 * cols_per_xcd * line_groups;
+        for (long long b = blockIdx.x; b < nb; b += gridDim.x) {
+            const long long xcd = b & 7, j = b >> 3;
+            const long long col = xcd * cols_per_xcd + j / line_groups;
+            const long long line = (j % line_groups) * 4 + (threadIdx.x >> 6);
+            if (col >= strips_per_line || line >= A.lines) continue;  // wave-uniform
+            const long long smp = col * 64 + lane;
+            const bool in = smp < A.samples;
+            invert_strip<T, TO, 1, CR>(L, A, line * A.samples + (in ? smp : A.samples - 1), in, lane);
+        }
+        return;
+    }
     // XSW_LIST_PX pixels per wave and pass: the cooperative stage takes the pixels one after the other, so fewer pixels per
     // wave spread a short list over more SIMDs (the per-lane stage runs with idle lanes, which costs nothing here)
 #ifndef XSW_LIST_PX

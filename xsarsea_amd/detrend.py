@@ -10,7 +10,7 @@ import time
 
 import numpy as np
 
-from . import _lib, options
+from . import _device, _lib, options
 from .windspeed.lut import xr
 from .windspeed.models import get_model
 
@@ -45,7 +45,11 @@ def sigma0_detrend(sigma0, inc_angle, wind_speed_gmf=np.array([10.0]), wind_dir_
             raise ValueError("wind_speed_gmf and wind_dir_gmf size must be 1 or 0")
 
     is_xr = xr is not None and isinstance(inc_angle, xr.DataArray)
-    inc_row = np.asarray(inc_angle.isel(line=0) if is_xr else np.asarray(inc_angle)[0], dtype=np.float64)
+    on_device = _device.is_device_array(sigma0)
+    if _device.is_device_array(inc_angle):  # only the first line's incidence row is needed on the host (detrend.py:55)
+        inc_row = _device.as_tensor(inc_angle, _device.device_of(inc_angle))[0].double().cpu().numpy()
+    else:
+        inc_row = np.asarray(inc_angle.isel(line=0) if is_xr else np.asarray(inc_angle)[0], dtype=np.float64)
     if hasattr(model, "_gmf_pyfunc_scalar"):
         g = np.asarray(model(inc_row, np.broadcast_to(wind_speed_gmf.reshape(-1)[:1], inc_row.shape),
                              np.broadcast_to(wind_dir_gmf.reshape(-1)[:1], inc_row.shape), broadcast=True),
@@ -55,6 +59,21 @@ def sigma0_detrend(sigma0, inc_angle, wind_speed_gmf=np.array([10.0]), wind_dir_
                              wind_dir_gmf.reshape(-1)[:1].astype(np.float64)), dtype=np.float64).reshape(inc_row.shape)
     ratio = g / np.nanmean(g)
 
+    if on_device:  # sigma0 resident in HBM: a float64 torch tensor on the same device comes back, asynchronously
+        import torch
+        dev = _device.device_of(sigma0)
+        t = _device.as_tensor(sigma0, dev)
+        if t.dtype not in (torch.float32, torch.float64):
+            t = t.double()
+        t = t.contiguous()
+        res = torch.empty(t.shape, dtype=torch.float64, device=dev)
+        if t.numel():
+            ctx = _lib.default_context(dev.index if dev.index is not None else torch.cuda.current_device())
+            with _device.on_current_stream(ctx, dev):
+                ctx.detrend_raw(t.numel() // t.shape[-1], t.shape[-1], _device.xsw_dtype(t), _lib.XSW_F64, _lib.MEM_DEVICE,
+                                t.data_ptr(), ratio, res.data_ptr())
+                t.record_stream(torch.cuda.current_stream(dev))
+        return res
     values = np.asarray(sigma0)
     ctx = _lib.default_context(options.device)
     out = ctx.detrend_host(values.reshape(-1, values.shape[-1]), ratio).reshape(values.shape)

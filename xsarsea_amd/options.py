@@ -3,6 +3,21 @@
 #: HIP device index used by the drop-in API (one process per GPU: set it to LOCAL_RANK).
 device = 0
 
+#: Single-process multi-GPU for HOST rasters (numpy / xarray / dask blocks): None = `device` only; "all" = every visible GPU;
+#: or a list of device indices.  The raster is cut into contiguous row tiles (the reference's dask strategy,
+#: windspeed.py:356-364), one host thread and one libxsw context per GPU, every tile written in place into the one output
+#: raster -- no collective.  This is what makes `invert_from_model` a drop-in for the reference's own in-call parallelism
+#: (numba `target="parallel"` threads, windspeed.py:306-323).  Rasters below `devices_min_pixels` stay on `device`.
+devices = None
+devices_min_pixels = 1 << 22
+
+#: complex dtype of the winds returned for DEVICE-resident inputs (torch CUDA tensors): "complex128" (the reference's
+#: result dtype) or "complex64" (half the HBM bytes written).
+device_out_dtype = "complex128"
+
+#: worker threads of the host-memory paths of libxsw per context (0 = the library default: XSW_HOST_THREADS or 8)
+host_threads = 0
+
 #: sigma0 -> dB conversion (windspeed.py:126-130).
 #:   "auto"  : float64 rasters are converted on the device; float32 rasters on the host with numpy,
 #:             because numpy's float32 log10 is a platform-specific few-ulp SIMD routine and only the
@@ -24,9 +39,11 @@ lut_interp = "auto"
 gmf_on_device = "auto"
 gmf_device_min_size = 1 << 18
 
-#: cross-pol noise flattening (`windspeed.nesz_flattening`): "auto" = device (`xsw_nesz_flatten`) for rasters of
+#: cross-pol noise flattening (`windspeed.nesz_flattening`): "auto" = device (`xsw_nesz_flatten`) for FLOAT64 rasters of
 #: >= nesz_device_min_size pixels when a device is present -- float64 accumulation and closed-form least squares, within
-#: 1e-10 relative of the host route, which reproduces numpy's polyfit bit for bit -- "host", "device".
+#: 1e-10 relative of the host route, which reproduces numpy's polyfit bit for bit; float32 rasters stay on the host under
+#: "auto" (the reference accumulates them in float32: the device's float64 sums differ from that by ~1e-6) -- "host",
+#: "device" (every float raster; float32 within 1e-5).
 nesz_on_device = "auto"
 nesz_device_min_size = 1 << 20
 

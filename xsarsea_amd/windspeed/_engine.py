@@ -59,13 +59,13 @@ class DeviceLut:
         self.shape = tuple(len(a) for a in target_axes if a is not None)
 
     def build(self, ctx):
+        for ax in (self.incidence, self.wspd, self.phi) + tuple(self.raw_axes):
+            if ax is not None and np.size(ax) > 1 and not np.all(np.diff(np.asarray(ax, dtype=np.float64)) > 0):
+                raise ValueError("device LUT build needs strictly ascending axes (the host route re-orders them: lut_build='host')")
         target = dict(inc=self.incidence, wspd=self.wspd)
         if self.phi is not None:
             target.update(phi=self.phi, **host_tables(self.wspd, self.phi))
         ctx.build_lut(self.gmf_id, self.raw_axes, target)
-
-
-_device_luts = {}
 
 
 def lut_source(model, kwargs):
@@ -75,10 +75,14 @@ def lut_source(model, kwargs):
     if options.lut_build == "device" and hasattr(model, "device_lut_plan"):
         plan = model.device_lut_plan(**kwargs)
         if plan is not None:
-            key = (model.name,) + tuple(sorted(kwargs.items()))
-            hit = _device_luts.get(key)
+            # memoised on the model INSTANCE, like the host route's `Model._lut` (a model re-registered under the same name
+            # with other ranges is another instance), and keyed by the plan's own axes, so a stale grid is never reused;
+            # unhashable kwargs never reach a dict key
+            key = (plan[0],) + tuple(None if a is None else np.asarray(a, dtype=np.float64).tobytes() for a in tuple(plan[1]) + tuple(plan[2]))
+            cache = model.__dict__.setdefault("_device_luts", {})
+            hit = cache.get(key)
             if hit is None:
-                hit = _device_luts[key] = DeviceLut(model.name, plan[0], plan[1], plan[2], key)
+                hit = cache[key] = DeviceLut(model.name, plan[0], plan[1], plan[2], key)
             return hit
     return model._lut(units="dB", **kwargs)
 
@@ -169,6 +173,25 @@ def all_nan(a):
     return not any_valid(a)
 
 
+def _device_list():
+    """Devices of the single-process multi-GPU path (`options.devices`), or None for the one-device path."""
+    devs = options.devices
+    if devs is None:
+        return None
+    if isinstance(devs, str):
+        if devs != "all":
+            raise ValueError('options.devices must be None, "all" or a list of device indices')
+        devs = list(range(_lib.device_count()))
+    devs = [int(d) for d in devs]
+    return devs if len(devs) > 1 else None
+
+
+def tile_rows(lines, parts):
+    """[(l0, l1)] contiguous row tiles: `lines // parts` lines each, the last one takes the remainder (multi_gpu.tile_bounds)."""
+    base = lines // parts
+    return [(k * base, lines if k == parts - 1 else (k + 1) * base) for k in range(parts)]
+
+
 def invert_numpy(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_co=0.1):
     """(ws_co, ws_cr) complex128 for numpy rasters (None for a search that was not requested); any of
     sigma0_co / sigma0_cr / anc may be None.
@@ -177,8 +200,10 @@ def invert_numpy(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_c
     everything is handled as float64/complex128 (the gufunc signature, windspeed.py:308-318).  When
     every raster is float32/complex64 the device reads them as such (half the PCIe and HBM bytes)
     and widens in registers, which is the same arithmetic.
+
+    `options.devices`: the raster's row tiles go to several GPUs from host threads, one libxsw context each, every tile
+    written in place into the one output raster (pixels are independent: no exchange).
     """
-    ctx = _lib.default_context(options.device)
     inc = np.asarray(inc)
     rasters = [a for a in (inc, sigma0_co, sigma0_cr, None if np.isscalar(dsig_cr) else dsig_cr) if a is not None]
     # the gufunc "(n),(n),(n),(n),(n)->(n),(n)" broadcasts its loop dimensions over ALL inputs (windspeed.py:307-322):
@@ -204,15 +229,84 @@ def invert_numpy(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_c
         elif dt == np.float32:
             dsig_cr = float(np.float32(dsig_cr))
     cast = lambda a, t: None if a is None else np.ascontiguousarray(np.broadcast_to(np.asarray(a), shape), dtype=t)
-    with ctx.lock:  # LUT upload + inversion as one step: another thread may want other LUTs on the same context
-        ensure_luts(ctx, lut_co if sigma0_co is not None else None, lut_cr if sigma0_cr is not None else None)
-        out_co, out_cr, _ = _invert(ctx, cast, dt, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_co, is_db)
-    return out_co, out_cr  # None where that search did not run (the caller never reads it)
+    cdt = np.complex64 if dt == np.float32 else np.complex128
+    full = dict(inc=cast(inc, dt), sigma0_co=cast(sigma0_co, dt), sigma0_cr=cast(sigma0_cr, dt),
+                dsig_cr=dsig_cr if (dsig_cr is None or np.isscalar(dsig_cr)) else cast(dsig_cr, dt), anc=cast(anc, cdt))
+    want_co, want_cr = sigma0_co is not None, sigma0_cr is not None
+
+    def run(ctx, rows, out_co, out_cr):
+        """One context inverts rows [l0, l1) of the (lines, samples) view of every raster, into the same rows of the outputs."""
+        sl = (lambda a: a) if rows is None else (lambda a: a[rows[0]:rows[1]])
+        with ctx.lock:  # LUT upload + inversion as one step: another thread may want other LUTs on the same context
+            ensure_luts(ctx, lut_co if want_co else None, lut_cr if want_cr else None)
+            if options.host_threads:
+                ctx.set_host_threads(options.host_threads)
+            return ctx.invert_host(sl(full["inc"]), sigma0_co=None if not want_co else sl(full["sigma0_co"]),
+                                   sigma0_cr=None if not want_cr else sl(full["sigma0_cr"]),
+                                   dsig_cr=full["dsig_cr"] if (full["dsig_cr"] is None or np.isscalar(full["dsig_cr"])) else sl(full["dsig_cr"]),
+                                   anc=None if full["anc"] is None else sl(full["anc"]), dsig_co=dsig_co, sigma0_is_db=is_db,
+                                   algo=options.algo, out_dtype=np.complex128, out_co=None if out_co is None else sl(out_co),
+                                   out_cr=None if out_cr is None else sl(out_cr))
+
+    devs = _device_list()
+    n = int(np.prod(shape, dtype=np.int64)) if len(shape) else 1
+    if devs is None or len(shape) < 2 or n < options.devices_min_pixels or shape[0] < 4 * len(devs):
+        out_co, out_cr, _ = run(_lib.default_context(options.device), None, None, None)
+        return out_co, out_cr  # None where that search did not run (the caller never reads it)
+    # several GPUs: contiguous row tiles of the leading axis, one host thread and one context per GPU, results in place
+    lines = shape[0]
+    out_co = np.empty(shape, np.complex128) if want_co else None
+    out_cr = np.empty(shape, np.complex128) if want_cr else None
+    ctxs = _lib.contexts_for(devs)
+    tiles = tile_rows(lines, len(ctxs))
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(ctxs)) as ex:
+        futs = [ex.submit(run, c, t, out_co, out_cr) for c, t in zip(ctxs, tiles) if t[1] > t[0]]
+        for f in futs:
+            f.result()  # re-raises a tile's error here
+    return out_co, out_cr
 
 
-def _invert(ctx, cast, dt, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_co, is_db):
-    return ctx.invert_host(
-        cast(inc, dt), sigma0_co=cast(sigma0_co, dt), sigma0_cr=cast(sigma0_cr, dt),
-        dsig_cr=dsig_cr if (dsig_cr is None or np.isscalar(dsig_cr)) else cast(dsig_cr, dt),
-        anc=cast(anc, np.complex64 if dt == np.float32 else np.complex128), dsig_co=dsig_co, sigma0_is_db=is_db,
-        algo=options.algo, out_dtype=np.complex128)
+def invert_device(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_co=0.1, dual_select=False):
+    """(ws_co, ws_cr) torch complex tensors for rasters resident in HBM (torch CUDA tensors / `__cuda_array_interface__`
+    objects; host arrays among them are uploaded): the drop-in call without PCIe.  sigma0 -> dB is fused into the kernel
+    (float32 rasters: float32 arithmetic like the reference, the log10 correctly rounded -- numpy's float32 log10 is a few-ulp
+    SIMD routine, so ~2e-5 of the pixels of a float32 raster land one grid step from a numpy run; float64 rasters agree bit for
+    bit).  Asynchronous on torch's current stream.  dual_select: ws_cr receives the fused where(|co|<5 | |dual|<5, co, dual)."""
+    import torch
+    from .. import _device
+    arrays = [a for a in (inc, sigma0_co, sigma0_cr, None if np.isscalar(dsig_cr) else dsig_cr, anc) if a is not None]
+    dev = _device.device_of(*arrays)
+    ctx = _lib.default_context(dev.index if dev.index is not None else torch.cuda.current_device())
+    t_inc = _device.as_tensor(inc, dev)
+    t_co = None if sigma0_co is None else _device.as_tensor(sigma0_co, dev)
+    t_cr = None if sigma0_cr is None else _device.as_tensor(sigma0_cr, dev)
+    t_dsig = None if (dsig_cr is None or np.isscalar(dsig_cr)) else _device.as_tensor(dsig_cr, dev)
+    t_anc = None if anc is None else _device.as_tensor(anc, dev)
+    rasters = [t for t in (t_inc, t_co, t_cr, t_dsig) if t is not None]
+    shape = torch.broadcast_shapes(*(t.shape for t in rasters + ([] if t_anc is None else [t_anc])))
+    all_f32 = all(t.dtype == torch.float32 for t in rasters) and (t_anc is None or t_anc.dtype == torch.complex64)
+    rt, ct = (torch.float32, torch.complex64) if all_f32 else (torch.float64, torch.complex128)
+    prep = lambda t, d: None if t is None else t.to(d).expand(shape).contiguous()
+    t_inc, t_co, t_cr, t_dsig, t_anc = prep(t_inc, rt), prep(t_co, rt), prep(t_cr, rt), prep(t_dsig, rt), prep(t_anc, ct)
+    dsig_scalar = 0.1
+    if t_cr is not None and t_dsig is None and dsig_cr is not None:
+        dsig_scalar = float(np.float32(dsig_cr)) if all_f32 else float(dsig_cr)
+    odt = torch.complex64 if options.device_out_dtype == "complex64" else torch.complex128
+    out_co = torch.empty(shape, dtype=odt, device=dev) if t_co is not None else None
+    out_cr = torch.empty(shape, dtype=odt, device=dev) if t_cr is not None else None
+    n = int(np.prod(shape, dtype=np.int64)) if len(shape) else 1
+    lines, samples = (n // shape[-1], shape[-1]) if len(shape) and n else (1 if n else 0, 1 if n else 0)
+    p = lambda t: None if t is None else t.data_ptr()
+    if n:
+        with _device.on_current_stream(ctx, dev):
+            ensure_luts(ctx, lut_co if t_co is not None else None, lut_cr if t_cr is not None else None)
+            ctx.invert_raw(lines, samples, _lib.XSW_F32 if all_f32 else _lib.XSW_F64,
+                           _lib.XSW_F32 if odt == torch.complex64 else _lib.XSW_F64, _lib.MEM_DEVICE, p(t_inc), p(t_co), p(t_cr),
+                           p(t_dsig), p(t_anc), p(out_co), p(out_cr), None, dsig_co, dsig_scalar, False,
+                           _lib.ALGOS.get(options.algo, options.algo), dual_select and out_cr is not None and out_co is not None)
+            # the inputs must outlive the asynchronous launch: tie them to the stream they are read on
+            for t in (t_inc, t_co, t_cr, t_dsig, t_anc):
+                if t is not None:
+                    t.record_stream(torch.cuda.current_stream(dev))
+    return out_co, out_cr

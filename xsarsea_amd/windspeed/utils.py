@@ -78,10 +78,29 @@ def nesz_flattening(noise, inc):
     """
     if noise.ndim != 2:
         raise IndexError("Only 2D noise allowed")
-    from .. import _lib, options
+    from .. import _device, _lib, options
+    if _device.any_device_array(noise, inc):  # rasters resident in HBM: a float64 torch tensor comes back, asynchronously
+        import torch
+        dev = _device.device_of(noise, inc)
+        t_n, t_i = _device.as_tensor(noise, dev), _device.as_tensor(inc, dev)
+        dt = torch.float32 if (t_n.dtype == torch.float32 and t_i.dtype == torch.float32) else torch.float64
+        t_n, t_i = t_n.to(dt).contiguous(), t_i.to(dt).expand(t_n.shape).contiguous()
+        out = torch.empty(t_n.shape, dtype=torch.float64, device=dev)
+        if t_n.numel():
+            ctx = _lib.default_context(dev.index if dev.index is not None else torch.cuda.current_device())
+            with _device.on_current_stream(ctx, dev):
+                ctx.nesz_flatten_raw(t_n.shape[0], t_n.shape[1], _device.xsw_dtype(t_n), _lib.MEM_DEVICE, t_n.data_ptr(), t_i.data_ptr(),
+                                     out.data_ptr())
+                for t in (t_n, t_i):
+                    t.record_stream(torch.cuda.current_stream(dev))
+        return out
     values, inc_v = np.asarray(noise), np.asarray(inc)
     mode = options.nesz_on_device
+    # "auto" is parity-first like the other defaults: float64 rasters only (device == host route to ~1e-13); float32 rasters
+    # -- where the reference itself accumulates in float32 and the float64 device sums differ from it by ~1e-6 -- go to the
+    # device on request only ("device")
     on_dev = mode == "device" or (mode == "auto" and values.size >= options.nesz_device_min_size
+                                  and values.dtype == np.float64 and inc_v.dtype == np.float64
                                   and _lib.device_count_safe() > 0)
     if on_dev and values.dtype in (np.float32, np.float64) and inc_v.shape == values.shape and values.size:
         return _lib.default_context(options.device).nesz_flatten_host(values, inc_v)

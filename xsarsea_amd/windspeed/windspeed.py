@@ -7,6 +7,10 @@ routing with its pol check, warnings and assertion (:88-120), scalar `dsig_cr` b
 in -> numpy out; dask in -> lazy dask out :350-364) and the return conventions (:415-439).
 What moves to the device: the sigma0 -> dB conversion (:126-130, see `options.db_on_device`) and all
 of `_invert_from_model_numpy` (:132-331) through `xsw_invert` (include/xsw.h).
+
+Beyond the reference's containers: rasters already resident in HBM (torch CUDA tensors, `__cuda_array_interface__`
+objects) are inverted in place and torch tensors come back (`_engine.invert_device`); `options.devices` spreads the row
+tiles of a host raster over several GPUs inside the one call (the counterpart of the reference's numba thread pool).
 """
 import logging
 import time
@@ -14,7 +18,7 @@ import warnings
 
 import numpy as np
 
-from .. import options
+from .. import _device, options
 from . import _engine
 from .lut import xr
 from .models import get_model
@@ -31,6 +35,9 @@ def _valid(v):
     """np.any(~np.isnan(v)) (windspeed.py:107, :112); numpy rasters are scanned block-wise with early exit."""
     if isinstance(v, np.ndarray):
         return _engine.any_valid(v)
+    if _device.is_device_array(v):  # one reduction on the device (synchronises: the reference's assertion needs the answer)
+        import torch
+        return bool(torch.isnan(_device.as_tensor(v, _device.device_of(v))).logical_not().any().item())
     return bool(np.any(~np.isnan(v)))
 
 
@@ -100,6 +107,17 @@ def invert_from_model(inc, sigma0, sigma0_dual=None, /, ancillary_wind=None, dsi
     lut_cr = _engine.lut_source(models[1], kwargs) if (models[1] is not None and sigma0_cr is not None) else None
     if sigma0_cr is not None and lut_cr is None:
         raise ValueError("a cross-pol sigma0 was given but `model` names no cross-pol model")
+
+    if _device.any_device_array(inc, sigma0_co, sigma0_cr, None if np.isscalar(dsig_cr) else dsig_cr, ancillary_wind):
+        # rasters resident in HBM (torch CUDA tensors / __cuda_array_interface__): torch tensors on the same device come back,
+        # nothing crosses PCIe; same routing and return conventions as below (:415-439), the dual-pol select fused in the kernel
+        ws_co, ws_cr = _engine.invert_device(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr,
+                                             None if no_ancillary else ancillary_wind, dsig_co=dsig_co,
+                                             dual_select=sigma0_dual is not None)
+        logger.debug("timing invert_from_model (device rasters, asynchronous) : %.2fs.", time.time() - t0)
+        if sigma0_dual is None:
+            return ws_co if models[0] is not None else ws_cr.abs()
+        return ws_co, ws_cr
 
     def _numpy(np_inc, np_co, np_cr, np_dsig, np_anc):
         return _engine.invert_numpy(lut_co, lut_cr, np_inc, np_co, np_cr, np_dsig, np_anc, dsig_co=dsig_co)
