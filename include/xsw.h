@@ -18,7 +18,7 @@
  *     uses one context per GPU from one host thread each -- xsarsea_amd.options.devices does exactly that).
  *
  * Host rasters (XSW_MEM_HOST) travel through a context-owned ring of page-locked staging buffers filled and drained by
- * host worker threads (XSW_HOST_THREADS, default 8, at most 32), one HIP stream per worker: chunk k is staged, uploaded,
+ * host worker threads (XSW_HOST_THREADS, default 12, at most 32), one HIP stream per worker: chunk k is staged, uploaded,
  * inverted, downloaded and written to the caller's output while the other workers do the same for other chunks.  What
  * comes down the link is the answer as 4-byte GRID CODES (see xsw_invert_args.out_code_co), expanded to complex values
  * on the host from the same tables and by the same IEEE operations as on the device: bit-identical, 4 instead of 8 / 16
@@ -116,6 +116,16 @@ typedef struct {
      *            (XSW_CODE_PICK_CO) set when dual_select picked the co-pol wind; XSW_CODE_NAN_RE as above.                  */
     uint32_t *out_code_co;
     uint32_t *out_code_cr;
+    /* Optional caller-side staging (host rasters only; ignored for XSW_MEM_DEVICE).  When non-NULL, a worker thread that is
+     * about to stage pixels [px0, px0 + npx) of input raster `which` (0 inc, 1 sigma0_co, 2 sigma0_cr, 3 dsig_cr, 4 anc) calls
+     *     stage(stage_user, which, px0, npx, dst)
+     * with `dst` = the page-locked staging area for that piece (npx elements of `dtype`, complex for anc).  Return 1 when the
+     * callback has filled dst (the library then does not read the raster pointer, which must still be non-NULL to request the
+     * search), 0 to let the library copy from the raster pointer as usual, < 0 to abort the call (XSW_EINVAL is returned).
+     * Called concurrently from several threads, for disjoint pieces.  This is how the Python layer runs numpy's own float32
+     * log10 (the reference's sigma0 -> dB arithmetic, :126-130) inside the pipeline instead of in a pass of its own. */
+    int (*stage)(void *stage_user, int32_t which, int64_t px0, int64_t npx, void *dst);
+    void *stage_user;
 } xsw_invert_args;
 
 #define XSW_CODE_NAN_RE  0xFFFFFFFFu
@@ -178,7 +188,7 @@ int xsw_expand_codes(xsw_ctx *ctx, int64_t n, int32_t mem, int32_t out_dtype, co
 /* Page-locked host memory for rasters a caller fills itself (XSW_MEM_HOST_PINNED); freed by xsw_host_free or with the context. */
 int xsw_host_alloc(xsw_ctx *ctx, size_t bytes, void **out);
 int xsw_host_free(xsw_ctx *ctx, void *p);
-/* Host worker threads of the XSW_MEM_HOST paths (0 = default: XSW_HOST_THREADS or 8; at most 32). */
+/* Host worker threads of the XSW_MEM_HOST paths (0 = default: XSW_HOST_THREADS or 12; at most 32). */
 int xsw_set_host_threads(xsw_ctx *ctx, int n);
 
 /* Enable (1) / disable (0) device-side work counters; read them after synchronising. */

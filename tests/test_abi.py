@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported():
 def test_struct_layouts_match_header():
     # xsw_lut: 9 pointers + 3 int32 (padded to 8) ; xsw_invert_args: see header
     assert ctypes.sizeof(_lib.LutStruct) == 9 * 8 + 16
-    assert ctypes.sizeof(_lib.InvertArgs) == 2 * 8 + 6 * 4 + 5 * 8 + 2 * 8 + 3 * 8 + 2 * 8
+    assert ctypes.sizeof(_lib.InvertArgs) == 2 * 8 + 6 * 4 + 5 * 8 + 2 * 8 + 3 * 8 + 2 * 8 + 2 * 8
     assert ctypes.sizeof(_lib.Stats) == 32
 
 

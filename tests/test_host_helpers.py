@@ -52,3 +52,29 @@ def test_empty_touched_shape_dtype():
     out = _host.empty_touched((3000, 3000), np.complex128)  # 144 MB: above the touch threshold
     assert out.shape == (3000, 3000) and out.dtype == np.complex128 and out.flags.c_contiguous
     assert _host.empty_touched((4, 5), np.float32).shape == (4, 5)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_in_place_piecewise_db_equals_the_one_shot_expression(dtype):
+    """The staging callback of `_engine.invert_numpy` converts sigma0 -> dB piece by piece, in place, into a foreign buffer
+    at arbitrary offsets (add, log10, multiply with out=): the bits must be those of `10 * np.log10(x + 1e-15)` on the whole
+    raster whatever the piece boundaries and alignments (numpy's float32 log10 is a SIMD routine with masked tails)."""
+    rng = np.random.default_rng(8)
+    n = 300_007
+    x = rng.uniform(-0.01, 2.0, n).astype(dtype)
+    x[::997] = np.nan
+    x[3], x[4], x[5] = 0.0, np.inf, -1.0
+    with np.errstate(all="ignore"):
+        ref = 10 * np.log10(x + 1e-15)
+    u = np.uint32 if dtype == np.float32 else np.uint64
+    buf = np.empty(n + 64, dtype=dtype)
+    for shift in (0, 1, 3):  # destination alignment differs from the source's
+        got = buf[shift:shift + n]
+        edges = [0, 1, 17, 4096, 4099, 65536 + 5, 200_001, n]
+        for a, b in zip(edges[:-1], edges[1:]):
+            out = got[a:b]
+            with np.errstate(all="ignore"):
+                np.add(x[a:b], 1e-15, out=out)
+                np.log10(out, out=out)
+                np.multiply(out, 10, out=out)
+        assert np.array_equal(ref.view(u), got.view(u)), (dtype, shift)

@@ -47,7 +47,13 @@ class InvertArgs(ctypes.Structure):
                 ("dsig_cr", ctypes.c_void_p), ("anc", ctypes.c_void_p),
                 ("dsig_co", ctypes.c_double), ("dsig_cr_scalar", ctypes.c_double),
                 ("out_co", ctypes.c_void_p), ("out_cr", ctypes.c_void_p), ("out_idx", ctypes.c_void_p),
-                ("out_code_co", ctypes.c_void_p), ("out_code_cr", ctypes.c_void_p)]
+                ("out_code_co", ctypes.c_void_p), ("out_code_cr", ctypes.c_void_p),
+                ("stage", ctypes.c_void_p), ("stage_user", ctypes.c_void_p)]
+
+
+#: int stage(void *user, int32 which, int64 px0, int64 npx, void *dst)  (xsw_invert_args.stage)
+STAGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p)
+STAGE_INC, STAGE_SIGMA0_CO, STAGE_SIGMA0_CR, STAGE_DSIG_CR, STAGE_ANC = range(5)
 
 
 class Stats(ctypes.Structure):
@@ -308,12 +314,27 @@ class Context:
     @_locked
     def invert_raw(self, lines, samples, dtype, out_dtype, mem, inc, sigma0_co, sigma0_cr, dsig_cr, anc, out_co,
                    out_cr, out_idx=None, dsig_co=0.1, dsig_cr_scalar=0.1, sigma0_is_db=False, algo=ALGO_AUTO,
-                   dual_select=False, out_code_co=None, out_code_cr=None):
-        """Thin call of xsw_invert; pointer arguments are ints (device or host addresses) or None."""
+                   dual_select=False, out_code_co=None, out_code_cr=None, stage=None):
+        """Thin call of xsw_invert; pointer arguments are ints (device or host addresses) or None.
+        stage: python callable (which, px0, npx, dst_address) -> 1 filled / 0 default copy (xsw_invert_args.stage); an
+        exception inside it aborts the call and is re-raised here."""
+        cb, failure = None, []
+        if stage is not None:
+            def _cb(_user, which, px0, npx, dst):
+                try:
+                    return 1 if stage(which, px0, npx, dst) else 0
+                except BaseException as exc:  # nothing propagates through the C frames
+                    failure.append(exc)
+                    return -1
+            cb = STAGE_FN(_cb)
         a = InvertArgs(int(lines), int(samples), dtype, out_dtype, mem, int(bool(sigma0_is_db)), int(algo),
                        int(bool(dual_select)), inc, sigma0_co, sigma0_cr, dsig_cr, anc, float(dsig_co),
-                       float(dsig_cr_scalar), out_co, out_cr, out_idx, out_code_co, out_code_cr)
-        self._check(self._lib.xsw_invert(self._h, ctypes.byref(a)), "xsw_invert")
+                       float(dsig_cr_scalar), out_co, out_cr, out_idx, out_code_co, out_code_cr,
+                       ctypes.cast(cb, ctypes.c_void_p) if cb is not None else None, None)
+        rc = self._lib.xsw_invert(self._h, ctypes.byref(a))
+        if failure:
+            raise failure[0]
+        self._check(rc, "xsw_invert")
 
     @_locked
     def expand_codes_raw(self, n, mem, out_dtype, code_co, code_cr, out_co, out_cr):
@@ -322,7 +343,7 @@ class Context:
 
     @_locked
     def set_host_threads(self, n):
-        """Worker threads of the host-memory paths (0 = default: XSW_HOST_THREADS or 8)."""
+        """Worker threads of the host-memory paths (0 = default: XSW_HOST_THREADS or 12)."""
         self._check(self._lib.xsw_set_host_threads(self._h, int(n)), "xsw_set_host_threads")
 
     @_locked
@@ -348,11 +369,11 @@ class Context:
     @_locked
     def invert_host(self, inc, sigma0_co=None, sigma0_cr=None, dsig_cr=None, anc=None, dsig_co=0.1,
                     sigma0_is_db=False, algo="auto", dual_select=False, out_dtype=np.complex128, want_idx=False, want_codes=False,
-                    pinned=False, out_co=None, out_cr=None):
+                    pinned=False, out_co=None, out_cr=None, stage=None):
         """numpy-in / numpy-out wrapper of xsw_invert for host rasters of one dtype (float32 or float64).
         want_codes: also return the uint32 grid codes (co, cr) as a 4th element.  pinned: the rasters are page-locked
         (`pinned_empty`): XSW_MEM_HOST_PINNED.  out_co / out_cr: C-contiguous arrays of the broadcast shape and `out_dtype` to
-        write into (row tiles of one raster inverted by several contexts land in place)."""
+        write into (row tiles of one raster inverted by several contexts land in place).  stage: see `invert_raw`."""
         inc = np.asarray(inc)
         dt = inc.dtype
         if dt not in (np.float32, np.float64):
@@ -401,7 +422,7 @@ class Context:
                             XSW_F32 if out_dtype == np.complex64 else XSW_F64, MEM_HOST_PINNED if pinned else MEM_HOST,
                             _ptr(inc), _ptr(s_co), _ptr(s_cr), _ptr(dsig_arr), _ptr(anc_), _ptr(out_co), _ptr(out_cr),
                             _ptr(idx), dsig_co, dsig_scalar, sigma0_is_db, ALGOS.get(algo, algo), dual_select,
-                            _ptr(codes[0]), _ptr(codes[1]))
+                            _ptr(codes[0]), _ptr(codes[1]), stage)
         if want_codes:
             return out_co, out_cr, idx, codes
         return out_co, out_cr, idx

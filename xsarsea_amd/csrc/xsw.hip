@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <limits>
 #include <mutex>
 #include <thread>
@@ -46,7 +47,7 @@ struct xsw_ctx {
     // host-memory paths: worker w owns a stream, a page-locked staging buffer and a device staging buffer, all kept between calls
     struct Worker { hipStream_t s = nullptr; char *pin = nullptr; size_t pin_cap = 0; char *dev = nullptr; size_t dev_cap = 0; };
     std::vector<Worker> workers;
-    int host_threads = 0;  // 0: XSW_HOST_THREADS or 8
+    int host_threads = 0;  // 0: XSW_HOST_THREADS or 12
     char *arena = nullptr;      // whole-raster device staging (xsw_nesz_flatten on host rasters; kept up to XSW_ARENA_KEEP bytes)
     size_t arena_cap = 0;
     std::vector<void *> host_allocs;  // xsw_host_alloc
@@ -800,7 +801,7 @@ static int host_thread_count(const xsw_ctx *c)
     int n = c->host_threads;
     if (n <= 0) {
         const char *e = getenv("XSW_HOST_THREADS");
-        n = e ? atoi(e) : 8;
+        n = e ? atoi(e) : 12;
     }
     return std::max(1, std::min(n, 32));
 }
@@ -931,20 +932,37 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
                  o_end = o_ccr + (want_cr ? pad(max_px * 4) : 0);
     const size_t list_cap = std::max<size_t>(max_px / 4, 1 << 14), dev_bytes = o_end + (list_cap + 16) * sizeof(unsigned);
     const int dtype = a->dtype, out_dtype = a->out_dtype;
-    return run_chunks(c, nchunks, [&](long long k, xsw_ctx::Worker &w, std::string &err) -> int {
+    static const bool prof = getenv("XSW_HOST_PROFILE") != nullptr;  // phase times of the pipeline on stderr (experiments)
+    std::atomic<long long> t_stage{0}, t_gpu{0}, t_expand{0}, t_reserve{0};
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [](std::chrono::steady_clock::time_point a0, std::chrono::steady_clock::time_point b0) {
+        return (long long)std::chrono::duration_cast<std::chrono::microseconds>(b0 - a0).count(); };
+    const auto t_begin = now();
+    const int rc_all = run_chunks(c, nchunks, [&](long long k, xsw_ctx::Worker &w, std::string &err) -> int {
+        const auto t0 = now();
         int rc = worker_reserve(w, o_end, dev_bytes, err);
         if (rc) return rc;
+        const auto t1 = now();
         const long long l0 = k * lines_per_chunk, l1 = std::min((long long)a->lines, l0 + lines_per_chunk);
         const size_t px0 = (size_t)l0 * a->samples, npx = (size_t)(l1 - l0) * a->samples;
         hipError_t e = hipSuccess;
-        auto up = [&](const void *h, size_t off, size_t elem) {  // one raster of the chunk: host -> (staging ->) device
-            if (!h || e != hipSuccess) return;
+        // one raster of the chunk: host -> (page-locked staging ->) device.  The caller's staging callback may fill the staging
+        // area itself; page-locked caller rasters are read by the DMA engine directly
+        auto up = [&](int which, const void *h, size_t off, size_t elem) {
+            if (!h || e != hipSuccess || rc) return;
             const char *src = (const char *)h + px0 * elem;
-            if (pinned_in) e = hipMemcpyAsync(w.dev + off, src, npx * elem, hipMemcpyHostToDevice, w.s);
-            else memcpy(w.pin + off, src, npx * elem);
+            int staged = 0;
+            if (a->stage) {
+                staged = a->stage(a->stage_user, which, (int64_t)px0, (int64_t)npx, w.pin + off);
+                if (staged < 0) { rc = seterr(err, XSW_EINVAL, "the staging callback failed for raster %d, pixels [%zu, %zu)", which, px0, px0 + npx); return; }
+            }
+            if (staged > 0) src = w.pin + off;
+            else if (!pinned_in) { memcpy(w.pin + off, src, npx * elem); src = w.pin + off; }
+            e = hipMemcpyAsync(w.dev + off, src, npx * elem, hipMemcpyHostToDevice, w.s);
         };
-        up(a->inc, o_inc, es); up(a->sigma0_co, o_co, es); up(a->sigma0_cr, o_cr, es); up(a->dsig_cr, o_dsig, es); up(a->anc, o_anc, es * 2);
-        if (!pinned_in && e == hipSuccess) e = hipMemcpyAsync(w.dev, w.pin, o_cc, hipMemcpyHostToDevice, w.s);  // all inputs in one copy
+        up(0, a->inc, o_inc, es); up(1, a->sigma0_co, o_co, es); up(2, a->sigma0_cr, o_cr, es); up(3, a->dsig_cr, o_dsig, es); up(4, a->anc, o_anc, es * 2);
+        if (rc) return rc;
+        const auto t2 = now();
         if (e != hipSuccess) return seterr(err, XSW_EHIP, "H2D copy failed: %s", hipGetErrorString(e));
         KArgs B = A;
         B.lines = l1 - l0;
@@ -962,6 +980,7 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
         if (o_end > o_cc) e = hipMemcpyAsync(w.pin + o_cc, w.dev + o_cc, o_end - o_cc, hipMemcpyDeviceToHost, w.s);
         if (e == hipSuccess) e = hipStreamSynchronize(w.s);
         if (e != hipSuccess) return seterr(err, XSW_EHIP, "kernel execution failed: %s", hipGetErrorString(e));
+        const auto t3 = now();
         const uint32_t *cc = want_co ? (const uint32_t *)(w.pin + o_cc) : nullptr, *ccr = want_cr ? (const uint32_t *)(w.pin + o_ccr) : nullptr;
         if (a->out_code_co && cc) memcpy(a->out_code_co + px0, cc, npx * 4);
         if (a->out_code_cr && ccr) memcpy(a->out_code_cr + px0, ccr, npx * 4);
@@ -972,8 +991,13 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
             else
                 expand_host<double>(c, npx, cc, ccr, a->out_co ? (double *)a->out_co + 2 * px0 : nullptr, a->out_cr ? (double *)a->out_cr + 2 * px0 : nullptr, idx);
         }
+        if (prof) { const auto t4 = now(); t_reserve += us(t0, t1); t_stage += us(t1, t2); t_gpu += us(t2, t3); t_expand += us(t3, t4); }
         return XSW_OK;
     });
+    if (prof)
+        fprintf(stderr, "[xsw host] %lld px, %lld chunks, %d threads: wall %.2f ms; summed over workers: reserve %.2f, stage %.2f, upload+kernels+download %.2f, expand %.2f ms\n",
+                n, nchunks, (int)std::min<long long>(host_thread_count(c), nchunks), us(t_begin, now()) / 1e3, t_reserve / 1e3, t_stage / 1e3, t_gpu / 1e3, t_expand / 1e3);
+    return rc_all;
 }
 
 // ---------------------------------------------------------------------------------------- LUT interpolation

@@ -15,7 +15,7 @@ devices_min_pixels = 1 << 22
 #: result dtype) or "complex64" (half the HBM bytes written).
 device_out_dtype = "complex128"
 
-#: worker threads of the host-memory paths of libxsw per context (0 = the library default: XSW_HOST_THREADS or 8)
+#: worker threads of the host-memory paths of libxsw per context (0 = the library default: XSW_HOST_THREADS or 12)
 host_threads = 0
 
 #: sigma0 -> dB conversion (windspeed.py:126-130).

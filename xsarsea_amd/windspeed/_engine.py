@@ -1,5 +1,7 @@
 """Glue between the model layer and libxsw: LUT upload cache and the numpy-in/numpy-out call that
 stands where the reference's `_invert_from_model_numpy` stands (windspeed/windspeed.py:132-331)."""
+import ctypes
+
 import numpy as np
 
 from .. import _host, _lib, options
@@ -215,24 +217,63 @@ def invert_numpy(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_c
     if on_dev == "auto":
         on_dev = not any(np.asarray(a).dtype == np.float32 for a in (sigma0_co, sigma0_cr) if a is not None)
     is_db = not on_dev
-    if is_db:
-        sigma0_co = None if sigma0_co is None else _to_db(np.asarray(sigma0_co))
-        sigma0_cr_lin = sigma0_cr
-        sigma0_cr = None if sigma0_cr is None else _to_db(np.asarray(sigma0_cr))
-    else:
-        sigma0_cr_lin = sigma0_cr
     dt = np.float32 if all_f32 else np.float64
-    if sigma0_cr is not None and np.isscalar(dsig_cr):
-        if is_db:  # the kernel derives the broadcast from linear sigma0; do it here as the reference does
-            with np.errstate(all="ignore"):
-                dsig_cr = np.asarray(sigma0_cr_lin) * 0 + dsig_cr  # windspeed.py:122-123
-        elif dt == np.float32:
-            dsig_cr = float(np.float32(dsig_cr))
     cast = lambda a, t: None if a is None else np.ascontiguousarray(np.broadcast_to(np.asarray(a), shape), dtype=t)
     cdt = np.complex64 if dt == np.float32 else np.complex128
-    full = dict(inc=cast(inc, dt), sigma0_co=cast(sigma0_co, dt), sigma0_cr=cast(sigma0_cr, dt),
-                dsig_cr=dsig_cr if (dsig_cr is None or np.isscalar(dsig_cr)) else cast(dsig_cr, dt), anc=cast(anc, cdt))
     want_co, want_cr = sigma0_co is not None, sigma0_cr is not None
+    lin = {}  # host dB: the linear sigma0 rasters in their OWN dtype; converted piece by piece inside the library's pipeline
+    if is_db:
+        # numpy's own log10 in the raster's dtype is the reference's arithmetic (windspeed.py:126-130) and, for float32, the
+        # only way to its bits (a platform-specific few-ulp SIMD routine).  It runs as the STAGING step of xsw_invert's host
+        # pipeline (xsw_invert_args.stage): the worker thread that is about to upload a piece calls back, numpy converts that
+        # piece straight into the page-locked staging buffer -- no pass of its own, no dB raster in host memory.
+        as_src = lambda a: np.ascontiguousarray(np.broadcast_to(np.asarray(a), shape))
+        if want_co:
+            lin[_lib.STAGE_SIGMA0_CO] = as_src(sigma0_co)
+        if want_cr:
+            lin[_lib.STAGE_SIGMA0_CR] = as_src(sigma0_cr)
+    dsig_fill = None
+    if want_cr and np.isscalar(dsig_cr):
+        if is_db:  # the kernel derives the broadcast from linear sigma0; with dB rasters it is formed as the reference does
+            dsig_fill = dsig_cr  # sigma0_cr * 0 + dsig_cr  (windspeed.py:122-123), piece by piece in the staging callback
+        elif dt == np.float32:
+            dsig_cr = float(np.float32(dsig_cr))
+    full = dict(inc=cast(inc, dt), anc=cast(anc, cdt))
+    # rasters the staging callback fills are never read through their pointer: the incidence raster stands in (right size)
+    full["sigma0_co"] = None if not want_co else (full["inc"] if is_db else cast(sigma0_co, dt))
+    full["sigma0_cr"] = None if not want_cr else (full["inc"] if is_db else cast(sigma0_cr, dt))
+    if dsig_fill is not None:
+        full["dsig_cr"] = full["inc"]
+    else:
+        full["dsig_cr"] = dsig_cr if (dsig_cr is None or np.isscalar(dsig_cr)) else cast(dsig_cr, dt)
+
+    def stage_for(rows):
+        """The staging callback of one row tile (pixel offsets are tile-local)."""
+        if not lin:
+            return None
+        sl = (lambda a: a) if rows is None else (lambda a: a[rows[0]:rows[1]])
+        src = {k: sl(v).reshape(-1) for k, v in lin.items()}
+        item = np.dtype(dt).itemsize
+
+        def stage(which, px0, npx, dst):
+            if which == _lib.STAGE_DSIG_CR and dsig_fill is not None:
+                x = src[_lib.STAGE_SIGMA0_CR][px0:px0 + npx]
+            elif which in src:
+                x = src[which][px0:px0 + npx]
+            else:
+                return 0
+            out = np.frombuffer((ctypes.c_char * (npx * item)).from_address(dst), dtype=dt)
+            with np.errstate(all="ignore"):
+                if which == _lib.STAGE_DSIG_CR:
+                    out[...] = x * 0 + dsig_fill
+                elif x.dtype == dt:  # 10 * np.log10(x + 1e-15), the three ufunc loops writing in place
+                    np.add(x, 1e-15, out=out)
+                    np.log10(out, out=out)
+                    np.multiply(out, 10, out=out)
+                else:
+                    out[...] = 10 * np.log10(x + 1e-15)
+            return 1
+        return stage
 
     def run(ctx, rows, out_co, out_cr):
         """One context inverts rows [l0, l1) of the (lines, samples) view of every raster, into the same rows of the outputs."""
@@ -246,7 +287,7 @@ def invert_numpy(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_c
                                    dsig_cr=full["dsig_cr"] if (full["dsig_cr"] is None or np.isscalar(full["dsig_cr"])) else sl(full["dsig_cr"]),
                                    anc=None if full["anc"] is None else sl(full["anc"]), dsig_co=dsig_co, sigma0_is_db=is_db,
                                    algo=options.algo, out_dtype=np.complex128, out_co=None if out_co is None else sl(out_co),
-                                   out_cr=None if out_cr is None else sl(out_cr))
+                                   out_cr=None if out_cr is None else sl(out_cr), stage=stage_for(rows))
 
     devs = _device_list()
     n = int(np.prod(shape, dtype=np.int64)) if len(shape) else 1
