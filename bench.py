@@ -573,44 +573,71 @@ def main():
         ctx.upload_luts(cr=_engine._cr_dict(get_model("gmf_s1_v2")._lut(units="dB")))
         s_vh, dsig = make_crosspol(inc, anc, 777 + rank, device)
         out_dual = torch.empty((lines, samples), dtype=torch.complex64, device=device)
-    full = full_dual = None  # rank 0: the gathered total_lines x samples raster(s)
-    if world > 1 and rank == 0:
-        full = torch.empty((total_lines, samples), dtype=torch.complex64, device=device)
-        if mode == "dual":
-            full_dual = torch.empty((total_lines, samples), dtype=torch.complex64, device=device)
     algo = _lib.ALGOS[args.algo]
 
-    # N > 1: the tile is inverted in row chunks so that chunk k travels to rank 0 over xGMI while chunk k+1
-    # is being inverted (RCCL runs on its own stream; requests are waited for at the end of the step)
-    n_chunks = 8 if world > 1 else 1  # the last chunk's transfer is the only exposed one: 1/8 of a tile
+    # N > 1.  What travels to rank 0 is the answer as 4-byte GRID CODES (xsw_invert's out_code_*: the retrieved wind is a grid
+    # point), a quarter of the complex64 raster for mono (half for dual-pol, two codes); rank 0 expands the gathered codes
+    # to complex64 with one HBM-bound kernel (xsw_expand_codes) inside the timed step.  The tile is inverted in row chunks
+    # so that chunk k travels over xGMI while chunk k+1 is being inverted (RCCL runs on its own stream; requests are
+    # waited for at the end of the step).  Rank 0 writes its own codes straight into the gathered raster.
+    coded = world > 1
+    n_chunks = 8 if world > 1 else 1
+    codes = codes_dual = full = full_dual = full_codes = full_codes_dual = None
+    if coded:
+        if rank == 0:
+            full_codes = torch.empty((total_lines, samples), dtype=torch.int32, device=device)
+            full = torch.empty((total_lines, samples), dtype=torch.complex64, device=device)
+            codes = full_codes[l0:l1]
+            if mode == "dual":
+                full_codes_dual = torch.empty((total_lines, samples), dtype=torch.int32, device=device)
+                full_dual = torch.empty((total_lines, samples), dtype=torch.complex64, device=device)
+                codes_dual = full_codes_dual[l0:l1]
+        else:
+            codes = torch.empty((lines, samples), dtype=torch.int32, device=device)
+            codes_dual = torch.empty((lines, samples), dtype=torch.int32, device=device) if mode == "dual" else None
     pending = []
 
-    def invert_rows(r0, r1, s0_ptr=None, is_db=False):
+    def invert_rows(r0, r1, s0_ptr=None, is_db=False, as_codes=False):
         off = r0 * samples
         co_ptr = (s0_ptr if s0_ptr is not None else s_vv.data_ptr()) + off * 4
+        o_co = None if as_codes else out.data_ptr() + off * 8
+        c_co = codes.data_ptr() + off * 4 if as_codes else None
         if mode == "dual":
             ctx.invert_raw(r1 - r0, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, inc.data_ptr() + off * 4, co_ptr,
                            s_vh.data_ptr() + off * 4, dsig.data_ptr() + off * 4, anc.data_ptr() + off * 8,
-                           out.data_ptr() + off * 8, out_dual.data_ptr() + off * 8, algo=algo, dual_select=True,
-                           sigma0_is_db=is_db)
+                           o_co, None if as_codes else out_dual.data_ptr() + off * 8, algo=algo, dual_select=True,
+                           sigma0_is_db=is_db, out_code_co=c_co, out_code_cr=codes_dual.data_ptr() + off * 4 if as_codes else None)
         else:
             ctx.invert_raw(r1 - r0, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, inc.data_ptr() + off * 4, co_ptr,
-                           None, None, anc.data_ptr() + off * 8, out.data_ptr() + off * 8, None, algo=algo,
-                           sigma0_is_db=is_db)
+                           None, None, anc.data_ptr() + off * 8, o_co, None, algo=algo, sigma0_is_db=is_db, out_code_co=c_co)
 
-    def step():
+    stream_aware = backend == "nccl"  # RCCL orders a transfer after the work queued on the current stream; gloo (the one-GPU
+    # rehearsal) reads and writes the tensors' memory from the host with no regard for streams: synchronise around it
+
+    def start_gather(k):
+        if not stream_aware:
+            torch.cuda.synchronize()
+        pending.extend(multi_gpu.gather_chunk_async(codes, total_lines, k, n_chunks, dst=0, out=full_codes, self_copy=False))
+        if mode == "dual":
+            pending.extend(multi_gpu.gather_chunk_async(codes_dual, total_lines, k, n_chunks, dst=0, out=full_codes_dual, self_copy=False))
+
+    def step(gathering=True):
         for k in range(n_chunks):
             r0, r1 = multi_gpu.chunk_bounds(lines, n_chunks, k)
             if r1 > r0:
-                invert_rows(r0, r1)
-            if world > 1:
-                pending.extend(multi_gpu.gather_chunk_async(out, total_lines, k, n_chunks, dst=0, out=full))
-                if mode == "dual":
-                    pending.extend(multi_gpu.gather_chunk_async(out_dual, total_lines, k, n_chunks, dst=0, out=full_dual))
+                invert_rows(r0, r1, as_codes=coded and gathering)
+            if coded and gathering:
+                start_gather(k)
 
     def gather():
         while pending:  # the single exchange of the path, started chunk by chunk inside step()
             pending.pop().wait()
+        if not stream_aware:
+            torch.cuda.synchronize()
+        if coded and rank == 0:  # codes -> complex64, the raster a single-GPU run would have written
+            ctx.expand_codes_raw(total_lines * samples, _lib.MEM_DEVICE, _lib.XSW_F32, full_codes.data_ptr(),
+                                 full_codes_dual.data_ptr() if mode == "dual" else None, full.data_ptr(),
+                                 full_dual.data_ptr() if mode == "dual" else None)
 
     def fence():
         torch.cuda.synchronize()
@@ -627,17 +654,19 @@ def main():
         step()
         gather()
     fence()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
     ctx.timing_enable(True)  # HIP events of the library around each of the two kernels of an inversion (launch stream)
     t0 = time.perf_counter()
-    for a, b in ev:
+    for a, b, c_ in ev:
         a.record(stream)
         step()
         b.record(stream)
         gather()
+        c_.record(stream)  # N > 1: after the last transfer has landed and the codes are expanded
     fence()
     dt = time.perf_counter() - t0
-    step_kernels_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # all kernels of a step on this rank
+    step_kernels_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in ev]))  # all kernels of a step on this rank
+    step_total_ms = float(np.mean([a.elapsed_time(c_) for a, _, c_ in ev]))   # + waits for the transfers + expansion
     tm = ctx.timing()
     ctx.timing_enable(False)
     if tm["launches"]:  # two-kernel path: the dominant kernel is k_invert_band; per STEP = summed over the step's row chunks
@@ -649,6 +678,49 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    mg = None
+    if world > 1:
+        # what explains a scaling curve: every rank's kernel time, the bytes rank 0 ingests, the raw transfer time of those
+        # bytes (a gather of the already computed codes, nothing else in flight), the part of the step the transfers and the
+        # expansion are NOT hidden behind the kernels, and the same steps with the outputs left sharded (no exchange at all)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "lines": lines, "kernel_ms": round(kernel_ms + (second_ms or 0.0), 3)})
+        fence()
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tg = time.perf_counter()
+        g0.record(stream)
+        for _ in range(args.steps):
+            for k in range(n_chunks):
+                start_gather(k)
+            while pending:
+                pending.pop().wait()
+        g1.record(stream)
+        fence()
+        gather_only_ms = (time.perf_counter() - tg) / args.steps * 1e3
+        for _ in range(max(args.warmup, 1)):
+            step(gathering=False)
+        fence()
+        tn = time.perf_counter()
+        for _ in range(args.steps):
+            step(gathering=False)
+        fence()
+        t = torch.tensor([time.perf_counter() - tn], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_ng = float(t.item())
+        code_bytes = 4 if mode == "mono" else 8
+        gbytes = multi_gpu.gather_bytes_into(total_lines, samples, world, 0, code_bytes)
+        mg = {"gather": "4-byte grid codes per pixel and search (xsw_invert out_code_*), expanded to complex64 on rank 0 (xsw_expand_codes) inside the step",
+              "gather_bytes": int(gbytes), "gather_bytes_if_complex64": int(gbytes * 2),
+              "gather_only_ms": round(gather_only_ms, 3), "gather_only_GBps": round(gbytes / (gather_only_ms * 1e-3) / 1e9, 1),
+              "step_total_ms_rank0": round(step_total_ms, 3), "step_kernels_ms_rank0": round(step_kernels_ms, 3),
+              "exposed_gather_ms": round(step_total_ms - step_kernels_ms, 3),
+              "kernel_ms_per_rank": per_rank,
+              "no_gather": {"value": round(total_lines * samples * args.steps / dt_ng / 1e6, 3), "unit": "Mpixels/s",
+                            "ms_per_step": round(dt_ng / args.steps * 1e3, 3),
+                            "note": "the same steps with complex64 tiles left on their ranks (what a dask consumer of row blocks does): no exchange"},
+              "note": "gather_only_ms: the gather alone (codes already computed, nothing else in flight), wall clock between barriers; "
+                      "exposed_gather_ms: rank 0's step from first launch to the expanded raster minus its kernels' time"}
 
     # evaluated-work counters: one extra, untimed pass with the device-side statistics on
     ctx.stats_enable(True)
@@ -694,6 +766,8 @@ def main():
         px_total = total_lines * samples
         value = px_total * args.steps / dt / 1e6
         bytes_px = (BYTES_READ_PX + BYTES_WRITE_PX) if mode == "mono" else (24 + 16)  # dual: +vh, +dsig; 2 outputs
+        if coded:  # N > 1: the kernels write 4-byte codes instead of complex64
+            bytes_px = (BYTES_READ_PX + 4) if mode == "mono" else (24 + 8)
         achieved = bytes_px * lines * samples / (kernel_ms * 1e-3) / 1e9  # rank 0's tile / rank 0's kernel time
         is_metric_shape = (mode == "mono" and args.resolution == "high" and cfg["lut"] == "cmod5n" and args.algo == "pruned"
                            and (lines, samples) == (20000, 20000))
@@ -738,7 +812,8 @@ def main():
                 pass
         mode_txt = "mono-VV" if mode == "mono" else "dual-pol (VV + S1 VH GMF)"
         par = f"row tiles x{n_gpus}" + (f" ({args.scaling} scaling: {'the same raster split' if args.scaling == 'strong' else 'one full tile per rank'}), "
-                                        f"RCCL gather to rank 0 in the step, {n_chunks} chunks behind the kernel" if n_gpus > 1 else "")
+                                        f"RCCL gather of 4-byte grid codes to rank 0 in the step ({n_chunks} chunks behind the kernel), expanded to complex64 there"
+                                        if n_gpus > 1 else "")
         res = {
             "metric": "Mpixels/s wind inversion (CMOD5.N, 20k x 20k sigma0)",
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -807,6 +882,8 @@ def main():
                                  "of pixels agree with numpy's few-ulp float32 log10, the rest differ by one grid step); "
                                  "parity_config: host-converted dB, index_match_host_db")
             res["parity"] = parity
+        if mg is not None:
+            res["multi_gpu"] = mg
         if gather_ok is not None:
             res["gather_verified"] = gather_ok
         print(json.dumps(res), flush=True)

@@ -1,7 +1,7 @@
-"""Hand-run rehearsal (not collected by pytest): `multi_gpu.invert_from_model_tiled` with REAL inversions, two ranks on ONE
-MI355X (gloo gather through host memory; RCCL needs two devices), compared on rank 0 with the single-process call on the
-full raster.  The parent never touches the GPU (its children are started by spawn).
-    python tests/rehearse_tiled_two_ranks.py        -> profiles/r02_tiled_two_ranks.txt holds the output of the run kept"""
+"""`multi_gpu.invert_from_model_tiled` with REAL inversions, several ranks on ONE MI355X (gloo gather through host memory;
+RCCL needs two devices), compared on rank 0 with the single-process call on the full raster.  The parent never touches the
+GPU (its children are started by spawn).  Run by tests/test_gpu_configs.py::test_tiled_api_real_inversions (3 ranks), or by hand:
+    python tests/rehearse_tiled_two_ranks.py [ranks]"""
 import os
 import socket
 import sys
@@ -26,6 +26,7 @@ def worker(rank, world, port, ret):
         xsarsea_amd.options.device = 0
         warnings.simplefilter("ignore")
         inc, s_vv, s_vh, dsig, anc = synthetic_scene(301, 517, np.float32, 9)
+        anc[:100] = np.nan  # rank 0's whole tile (3 ranks: lines 0..99) has no ancillary wind: NaN rows, no per-tile assertion
         mono = multi_gpu.invert_from_model_tiled(inc, s_vv, ancillary_wind=anc, model="gmf_cmod5n")
         dual = multi_gpu.invert_from_model_tiled(inc, s_vv, s_vh, ancillary_wind=anc, dsig_cr=dsig, model=("gmf_cmod5n", "gmf_s1_v2"))
         if rank == 0:
@@ -35,8 +36,17 @@ def worker(rank, world, port, ret):
             ret["mono"] = eq(mono, ref_m)
             ret["dual"] = eq(dual[0], ref_d[0]) and eq(dual[1], ref_d[1])
             ret["shape"] = tuple(np.shape(mono))
+            ret["nan_tile"] = bool(np.isnan(mono[:100]).all() and not np.isnan(mono[100:]).all())
         else:
             assert mono is None and dual is None
+        # a 1-D incidence row with a SQUARE raster: passed whole to every tile
+        sq = 96
+        sq_mono = multi_gpu.invert_from_model_tiled(inc[0, :sq], s_vv[:sq, :sq], ancillary_wind=anc[150:150 + sq, :sq], model="gmf_cmod5n",
+                                                    resolution="low")
+        if rank == 0:
+            ref = windspeed.invert_from_model(inc[0, :sq], s_vv[:sq, :sq], ancillary_wind=anc[150:150 + sq, :sq], model="gmf_cmod5n",
+                                              resolution="low")
+            ret["square_1d_inc"] = eq(sq_mono, ref)
     finally:
         dist.destroy_process_group()
 
@@ -47,7 +57,9 @@ if __name__ == "__main__":
         port = s.getsockname()[1]
     with mp.Manager() as m:
         ret = m.dict()
-        mp.spawn(worker, args=(2, port, ret), nprocs=2, join=True)
-        print("invert_from_model_tiled, 2 ranks on one device (gloo): raster", ret.get("shape"), "mono bit-equal to the single-process call:",
-              ret.get("mono"), "dual:", ret.get("dual"))
-        sys.exit(0 if ret.get("mono") and ret.get("dual") else 1)
+        n = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+        mp.spawn(worker, args=(n, port, ret), nprocs=n, join=True)
+        print(f"invert_from_model_tiled, {n} ranks on one device (gloo): raster", ret.get("shape"), "mono bit-equal to the single-process call:",
+              ret.get("mono"), "dual:", ret.get("dual"), "all-NaN-ancillary tile:", ret.get("nan_tile"), "1-D incidence on a square raster:",
+              ret.get("square_1d_inc"))
+        sys.exit(0 if all(ret.get(k) for k in ("mono", "dual", "nan_tile", "square_1d_inc")) else 1)

@@ -247,3 +247,27 @@ def test_switching_streams_waits_for_the_work_in_flight(gpu_ctx, default_luts):
     a = torch.view_as_real(outs[0]).view(torch.int32)
     for o in outs[1:]:
         assert torch.equal(a, torch.view_as_real(o).view(torch.int32))
+
+
+def test_codes_that_are_not_codes_expand_to_nan(gpu_ctx, default_luts):
+    """A code whose index lies outside the context's LUT (stale memory, codes of another LUT) expands to (nan, nan) on the
+    device and on the host instead of reading outside the tables."""
+    torch = pytest.importorskip("torch")
+    from xsarsea_amd import _lib
+    lco, lcr = default_luts
+    co, cr = lut_dicts(lco, lcr)
+    gpu_ctx.upload_luts(co=co, cr=cr)
+    plane = len(lco.wspd) * len(lco.phi)
+    cc = np.array([0, plane - 1, plane, 0x3FFFFFFF, 0x40000000 | (plane - 1), 0x40000000 | plane, 0x80000000, _lib.CODE_NAN, _lib.CODE_NAN_RE], np.uint32)
+    ccr = np.array([0, len(lcr.wspd) - 1, len(lcr.wspd), 0x3FFFFFFE, _lib.CODE_NO_INDEX, _lib.CODE_PICK_CO | 5, 0x80000001, _lib.CODE_NAN, _lib.CODE_NAN_RE], np.uint32)
+    h_co, h_cr = np.empty(cc.size, np.complex128), np.empty(cc.size, np.complex128)
+    gpu_ctx.expand_codes_raw(cc.size, _lib.MEM_HOST, _lib.XSW_F64, cc.ctypes.data, ccr.ctypes.data, h_co.ctypes.data, h_cr.ctypes.data)
+    dev = torch.device("cuda", 0)
+    t_cc, t_ccr = torch.from_numpy(cc.view(np.int32)).to(dev), torch.from_numpy(ccr.view(np.int32)).to(dev)
+    d_co, d_cr = torch.empty(cc.size, dtype=torch.complex128, device=dev), torch.empty(cc.size, dtype=torch.complex128, device=dev)
+    gpu_ctx.expand_codes_raw(cc.size, _lib.MEM_DEVICE, _lib.XSW_F64, t_cc.data_ptr(), t_ccr.data_ptr(), d_co.data_ptr(), d_cr.data_ptr())
+    gpu_ctx.synchronize()
+    assert np.array_equal(_bits(h_co), _bits(d_co.cpu().numpy())) and np.array_equal(_bits(h_cr), _bits(d_cr.cpu().numpy()))
+    assert np.array_equal(np.isnan(h_co.real), [False, False, True, True, False, True, True, True, True])
+    assert np.array_equal(np.isnan(h_cr.real), [False, False, True, True, True, False, True, True, True])
+    assert h_co[8].imag == 0.0 and np.isnan(h_co[7].imag)

@@ -204,4 +204,21 @@ def test_two_rank_rehearsal_gathers_the_single_launch_raster(cfg, shape, tmp_pat
                     "--warmup", "1", "--verify-gather", "--no-extras", "--no-cpu-baseline"], tmp_path)
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["gather_verified"] is True
     assert j["config"]["lines"] == shape[0] and j["config"]["lines_rank0"] == shape[0] // 2
+    # the gather ships 4-byte grid codes (two for dual-pol) and explains itself
+    mg = j["multi_gpu"]
+    assert mg["gather_bytes"] == (shape[0] - shape[0] // 2) * shape[1] * (4 if cfg == "4" else 8)
+    assert mg["gather_only_ms"] > 0 and len(mg["kernel_ms_per_rank"]) == 2 and mg["no_gather"]["value"] > 0
+    assert "exposed_gather_ms" in mg
     assert j["roofline"]["valu"]["evaluated_candidates_per_pixel"] > 10
+
+
+def test_tiled_api_real_inversions():
+    """`multi_gpu.invert_from_model_tiled` with the real drop-in call per tile: 3 ranks on this GPU (gloo), uneven tiles, a tile
+    whose ancillary wind is all NaN, a 1-D incidence row on a square raster; rank 0's raster == the single-process call, bit
+    for bit (mono + dual).  Fresh processes: the parent makes no GPU call."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rehearse_tiled_two_ranks.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, script, "3"], env=env, capture_output=True, text=True, timeout=840)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]

@@ -674,7 +674,7 @@ static void ensure_list(xsw_ctx *c, long long n)
 // ---- grid codes -> complex winds (xsw.h: xsw_expand_codes)
 template <typename TO>
 __global__ __launch_bounds__(256) void k_expand(const double *__restrict__ sol, const double *__restrict__ dual_dir, const double *__restrict__ wcr,
-                                                long long plane, long long n, const unsigned *__restrict__ cc, const unsigned *__restrict__ cr,
+                                                long long plane, int n_wcr, long long n, const unsigned *__restrict__ cc, const unsigned *__restrict__ cr,
                                                 typename Cx<TO>::type *__restrict__ out_co, typename Cx<TO>::type *__restrict__ out_cr)
 {
     typedef typename Cx<TO>::type cx_t;
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(256) void k_expand(const double *__restrict__ sol, 
         bool have_co = false;
         long long k = 0;
         if (a == K_CODE_NAN_RE) co_im = 0.0;
-        else if (a != K_CODE_NAN) {
+        else if (!(a & 0x80000000u) && (long long)(a & 0x3FFFFFFFu) < plane) {  // anything else (XSW_CODE_NAN, or not a code of this LUT): (nan, nan)
             k = (long long)(a & 0x3FFFFFFFu) + (long long)((a >> 30) & 1u) * plane;
             const double2 z = ((const double2 *)sol)[k];
             co_re = z.x; co_im = z.y;
@@ -696,8 +696,9 @@ __global__ __launch_bounds__(256) void k_expand(const double *__restrict__ sol, 
             const unsigned b = cr[i];
             double re = nan, im = nan;
             if (b == K_CODE_NAN_RE) im = 0.0;
+            else if (b & 0x80000000u) { }
             else if (b & K_CODE_PICK_CO) { re = co_re; im = co_im; }
-            else if ((b & K_CODE_NO_INDEX) != K_CODE_NO_INDEX) {
+            else if ((int)(b & K_CODE_NO_INDEX) < n_wcr) {
                 const double wd = wcr[b & K_CODE_NO_INDEX];
                 if (have_co) { const double2 u = ((const double2 *)dual_dir)[k]; re = wd * u.x; im = wd * u.y + 0.0 * u.x; }
                 else { re = wd; im = 0.0; }
@@ -724,13 +725,14 @@ static void expand_host(const xsw_ctx *c, size_t n, const uint32_t *cc, const ui
     const size_t plane = (size_t)c->T.n_w * c->T.n_phi;
     const int nP = c->T.n_phi;
     const double *sol = c->h_sol.data(), *dual = c->h_dual.data(), *wcr = c->h_wcr.data();
+    const size_t n_wcr = c->h_wcr.size();
     for (size_t i = 0; i < n; ++i) {
         const uint32_t a = cc ? cc[i] : XSW_CODE_NAN;
         double co_re = nan, co_im = nan;
         bool have_co = false;
         size_t k = 0;
         if (a == XSW_CODE_NAN_RE) co_im = 0.0;
-        else if (a != XSW_CODE_NAN) {
+        else if (!(a & 0x80000000u) && (size_t)(a & 0x3FFFFFFFu) < plane) {  // anything else (XSW_CODE_NAN, or not a code of this LUT): (nan, nan)
             k = (size_t)(a & 0x3FFFFFFFu) + (size_t)((a >> 30) & 1u) * plane;
             co_re = sol[2 * k]; co_im = sol[2 * k + 1];
             have_co = true;
@@ -742,8 +744,9 @@ static void expand_host(const xsw_ctx *c, size_t n, const uint32_t *cc, const ui
             if (out_cr) {
                 double re = nan, im = nan;
                 if (b == XSW_CODE_NAN_RE) im = 0.0;
+                else if (b & 0x80000000u) { }
                 else if (b & XSW_CODE_PICK_CO) { re = co_re; im = co_im; }
-                else if ((b & XSW_CODE_NO_INDEX) != XSW_CODE_NO_INDEX) {
+                else if ((size_t)(b & XSW_CODE_NO_INDEX) < n_wcr) {
                     const double wd = wcr[b & XSW_CODE_NO_INDEX];
                     if (have_co) { const double ux = dual[2 * k], uy = dual[2 * k + 1]; re = wd * ux; im = wd * uy + 0.0 * ux; }
                     else { re = wd; im = 0.0; }
@@ -755,7 +758,7 @@ static void expand_host(const xsw_ctx *c, size_t n, const uint32_t *cc, const ui
             const int flat = (int)(a & 0x3FFFFFFFu);
             idx[3 * i + 0] = have_co ? flat / nP : -1;
             idx[3 * i + 1] = have_co ? flat % nP : -1;
-            idx[3 * i + 2] = (b == XSW_CODE_NAN_RE || (b & XSW_CODE_NO_INDEX) == XSW_CODE_NO_INDEX) ? -1 : (int)(b & XSW_CODE_NO_INDEX);
+            idx[3 * i + 2] = ((b & 0x80000000u) || (b & XSW_CODE_NO_INDEX) == XSW_CODE_NO_INDEX) ? -1 : (int)(b & XSW_CODE_NO_INDEX);
         }
     }
 }
@@ -782,10 +785,10 @@ extern "C" int xsw_expand_codes(xsw_ctx *c, int64_t n, int32_t mem, int32_t out_
         const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, 256 * 16);
         const long long plane = (long long)c->T.n_w * c->T.n_phi;
         if (out_dtype == XSW_F32)
-            hipLaunchKernelGGL((k_expand<float>), dim3(blocks), dim3(256), 0, c->stream, c->T.sol, c->T.dual_dir, c->T.wcr, plane, (long long)n, code_co,
+            hipLaunchKernelGGL((k_expand<float>), dim3(blocks), dim3(256), 0, c->stream, c->T.sol, c->T.dual_dir, c->T.wcr, plane, c->have_cr ? c->T.n_wcr : 0, (long long)n, code_co,
                                code_cr, (Cx<float>::type *)out_co, (Cx<float>::type *)out_cr);
         else
-            hipLaunchKernelGGL((k_expand<double>), dim3(blocks), dim3(256), 0, c->stream, c->T.sol, c->T.dual_dir, c->T.wcr, plane, (long long)n, code_co,
+            hipLaunchKernelGGL((k_expand<double>), dim3(blocks), dim3(256), 0, c->stream, c->T.sol, c->T.dual_dir, c->T.wcr, plane, c->have_cr ? c->T.n_wcr : 0, (long long)n, code_co,
                                code_cr, (Cx<double>::type *)out_co, (Cx<double>::type *)out_cr);
         HIPCHK(c, hipGetLastError());
         return XSW_OK;

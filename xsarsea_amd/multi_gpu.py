@@ -26,11 +26,13 @@ def chunk_bounds(n_rows, n_chunks, k):
     return n_rows * k // n_chunks, n_rows * (k + 1) // n_chunks
 
 
-def gather_chunk_async(tile, lines, k, n_chunks, dst=0, group=None, out=None):
+def gather_chunk_async(tile, lines, k, n_chunks, dst=0, group=None, out=None, self_copy=True):
     """Start gathering chunk k (of n_chunks, `chunk_bounds` of each rank's OWN tile height) of every rank's tile into
     `out` on `dst`; tiles may be uneven (`tile_bounds`: the last rank takes the remainder).  Returns the requests to
     `wait()` on.  Lets a caller pipeline: invert chunk k, start its gather, invert chunk k+1 while chunk k travels
-    over xGMI (RCCL orders each transfer after the work already queued on the current stream)."""
+    over xGMI (RCCL orders each transfer after the work already queued on the current stream).
+    Any dtype: complex winds, or the 4-byte grid codes of xsw_invert (`out_code_*`: a quarter / half of the bytes, expanded
+    on `dst` by xsw_expand_codes).  self_copy=False: `dst` produced its own rows directly in `out` (nothing to copy)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     ops = []
@@ -41,7 +43,8 @@ def gather_chunk_async(tile, lines, k, n_chunks, dst=0, group=None, out=None):
             if c1 <= c0:
                 continue
             if r == dst:
-                out[t0 + c0:t0 + c1].copy_(tile[c0:c1], non_blocking=True)
+                if self_copy:
+                    out[t0 + c0:t0 + c1].copy_(tile[c0:c1], non_blocking=True)
             else:
                 ops.append(dist.P2POp(dist.irecv, out[t0 + c0:t0 + c1], r, group))
     else:
@@ -50,6 +53,12 @@ def gather_chunk_async(tile, lines, k, n_chunks, dst=0, group=None, out=None):
         if c1 > c0:
             ops.append(dist.P2POp(dist.isend, tile[c0:c1], dst, group))
     return dist.batch_isend_irecv(ops) if ops else []
+
+
+def gather_bytes_into(lines, samples, world, dst, bytes_per_pixel):
+    """Bytes rank `dst` receives from its peers in one gather of a (lines, samples) raster of `bytes_per_pixel`."""
+    t0, t1 = tile_bounds(lines, world, dst)
+    return (lines - (t1 - t0)) * samples * bytes_per_pixel
 
 
 def gather_rows_async(tile, lines, row0, row1, dst=0, group=None, out=None):
@@ -105,34 +114,64 @@ def gather_rows(tile, lines, dst=0, group=None, out=None):
 
 def invert_from_model_tiled(inc, sigma0, sigma0_dual=None, /, *, dst=0, group=None, invert=None, **kwargs):
     """`windspeed.invert_from_model` on a raster tiled over the ranks of a `torch.distributed` job (one process per GPU;
-    the reference's way to parallelise the same call is dask row blocks, windspeed/windspeed.py:350-364).
+    the reference's way to parallelise the same call is dask row blocks, windspeed/windspeed.py:350-364).  (Inside ONE process,
+    `xsarsea_amd.options.devices = "all"` spreads the same row tiles over the GPUs without any exchange.)
 
     Every rank calls this with the SAME full-size array-likes (numpy or anything sliceable along axis 0: memory-mapped files,
     lazily loaded arrays -- only the rank's own lines `tile_bounds(lines, world, rank)` are touched); `ancillary_wind` and a
-    raster `dsig_cr` in `kwargs` are sliced the same way.  The rank inverts its lines on its own GPU (`options.device`, which
-    `xsarsea_amd` sets from LOCAL_RANK) and the tiles are gathered on rank `dst` (RCCL send/recv under the "nccl" backend,
-    through host memory under "gloo").  Returns what `invert_from_model` returns (an array, or a tuple of two for dual-pol)
-    for the full raster on rank `dst`, None on the other ranks.  Without an initialised process group it is the plain call.
+    raster `dsig_cr` in `kwargs` are sliced the same way (arrays of sigma0's rank whose first axis has `lines` entries: a 1-D
+    incidence row of a square raster is NOT a raster and is passed whole).  The rank inverts its lines on its own GPU
+    (`options.device`, which `xsarsea_amd` sets from LOCAL_RANK) and the tiles are gathered on rank `dst` (RCCL send/recv
+    under the "nccl" backend, through host memory under "gloo").  Returns what `invert_from_model` returns (an array, or a
+    tuple of two for dual-pol) for the full raster on rank `dst`, None on the other ranks.  Without an initialised process
+    group it is the plain call.
+
+    Whole-raster preconditions are whole-raster: the reference's "co-pol inversion needs a valid ancillary wind" assertion
+    (windspeed.py:107) holds when ANY rank's tile has a valid ancillary value (one flag all-reduced); a tile that is all NaN
+    (land) or empty (fewer lines than ranks) yields NaN / no rows instead of raising.  A rank whose inversion fails does not
+    leave the others waiting in the gather: an error flag is all-reduced first and every rank raises.
     `invert`: the per-tile callable (default `windspeed.invert_from_model`; tests on machines without a GPU pass a stand-in).
     """
     import numpy as np
 
-    if invert is None:
+    default_invert = invert is None
+    if default_invert:
         from .windspeed import invert_from_model as invert
     if not (dist.is_available() and dist.is_initialized()):
         return invert(inc, sigma0, *(() if sigma0_dual is None else (sigma0_dual,)), **kwargs)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     lines = int(np.shape(sigma0)[0])
+    ndim = np.ndim(sigma0)
     l0, l1 = tile_bounds(lines, world, rank)
 
     def cut(a):
-        return a[l0:l1] if (a is not None and np.ndim(a) >= 1 and np.shape(a)[0] == lines) else a
+        is_raster = a is not None and not np.isscalar(a) and np.ndim(a) == ndim and np.shape(a)[0] == lines
+        return a[l0:l1] if is_raster else a
 
-    kw = {k: (cut(v) if k in ("ancillary_wind", "dsig_cr") else v) for k, v in kwargs.items()}
-    res = invert(cut(inc), cut(sigma0), *(() if sigma0_dual is None else (cut(sigma0_dual),)), **kw)
-    parts = res if isinstance(res, tuple) else (res,)
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    kw = {k: (cut(v) if k in ("ancillary_wind", "dsig_cr") else v) for k, v in kwargs.items()}
+    anc_tile = kw.get("ancillary_wind")
+    # the ancillary-wind precondition, once for the whole raster: does ANY tile hold a valid value?
+    valid_here = bool(anc_tile is not None and np.size(anc_tile) and np.any(~np.isnan(np.asarray(anc_tile))))
+    flag = torch.tensor([1 if valid_here else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    any_valid_ancillary = bool(flag.item())
+    res, failure = None, None
+    try:
+        if default_invert:
+            # the per-tile call skips the per-call ancillary assertion / warning (`_xsw_tile`): the whole-raster answer is passed in
+            kw["_xsw_tile"] = any_valid_ancillary
+        res = invert(cut(inc), cut(sigma0), *(() if sigma0_dual is None else (cut(sigma0_dual),)), **kw)
+    except BaseException as exc:  # reported to every rank below, then re-raised here
+        failure = exc
+    flag = torch.tensor([1 if failure is not None else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    if failure is not None:
+        raise failure
+    if flag.item():
+        raise RuntimeError("invert_from_model_tiled: the inversion failed on another rank (see its traceback); nothing was gathered")
+    parts = res if isinstance(res, tuple) else (res,)
     outs = []
     for p in parts:
         t = torch.as_tensor(np.ascontiguousarray(np.asarray(p))).to(dev)

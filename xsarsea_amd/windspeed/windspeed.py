@@ -78,6 +78,9 @@ def invert_from_model(inc, sigma0, sigma0_dual=None, /, ancillary_wind=None, dsi
     dual-pol: `(wind_co, wind_dual)`.  The container type follows the inputs.
     """
     t0 = time.time()
+    # private: set by multi_gpu.invert_from_model_tiled, whose per-rank call sees one row tile of the raster -- the ancillary-wind
+    # precondition is a whole-raster property (windspeed.py:107, :112) and arrives as the all-reduced answer
+    tile_any_valid = kwargs.pop("_xsw_tile", None)
     models = model if isinstance(model, tuple) else (model, None)
     models = tuple(get_model(m) if m is not None else None for m in models)
     no_ancillary = ancillary_wind is None  # the reference substitutes an all-NaN array (sigma0 * nan, :71-86)
@@ -94,10 +97,11 @@ def invert_from_model(inc, sigma0, sigma0_dual=None, /, ancillary_wind=None, dsi
             raise ValueError(f"sigma0 pol is {pol}, and model {models[0].name} can only handle {model_pol}")
         if models[0].iscopol:
             sigma0_co, sigma0_cr = sigma0, None
-            assert not no_ancillary and _valid(ancillary_wind), "co-pol inversion needs a valid ancillary wind"
+            assert not no_ancillary and (_valid(ancillary_wind) if tile_any_valid is None else tile_any_valid), \
+                "co-pol inversion needs a valid ancillary wind"
         elif models[0].iscrosspol:
             sigma0_co, sigma0_cr = None, sigma0
-            if not no_ancillary and _valid(ancillary_wind):
+            if not no_ancillary and (_valid(ancillary_wind) if tile_any_valid is None else tile_any_valid):
                 warnings.warn("crosspol inversion is best without ancillary wind, but using it as requested.")
             models = (None, models[0])
     else:
