@@ -402,10 +402,12 @@ def hard_scene_figures(ctx, _lib, stream, device, samples, algo, lines_hs=4000):
         run()
         st = ctx.stats()
         ctx.stats_enable(False)
-        ms = (tm["first_kernel_ms"] + tm["second_kernel_ms"]) / max(tm["launches"], 1)
+        ms = (tm["first_kernel_ms"] + tm["second_kernel_ms"] + tm["band2_kernel_ms"]) / max(tm["launches"], 1)
         out[key] = {"scene": what, "pixels": lines_hs * samples, "value": round(lines_hs * samples / ms / 1e3, 1), "unit": "Mpixels/s",
                     "k_invert_band_ms": round(tm["first_kernel_ms"] / max(tm["launches"], 1), 2),
+                    "k_invert_band2_ms": round(tm["band2_kernel_ms"] / max(tm["launches"], 1), 2),
                     "k_invert_list_ms": round(tm["second_kernel_ms"] / max(tm["launches"], 1), 2),
+                    "pixels_to_band2_frac": round(tm["last_band2_pixels"] / (lines_hs * samples), 5),
                     "pixels_left_to_the_list_frac": round(tm["last_list_pixels"] / (lines_hs * samples), 5),
                     "evaluated_candidates_per_pixel": round(st["cand_co"] / max(st["pixels_co"], 1), 1)}
         del inc, s_vv, anc
@@ -712,7 +714,7 @@ def main():
     ctx.timing_enable(False)
     if tm["launches"]:  # two-kernel path: the dominant kernel is k_invert_band; per STEP = summed over the step's row chunks
         kernel_ms = tm["first_kernel_ms"] / args.steps
-        second_ms = tm["second_kernel_ms"] / args.steps
+        second_ms = (tm["second_kernel_ms"] + tm.get("band2_kernel_ms", 0.0)) / args.steps  # k_invert_band2 + k_invert_list
     else:
         kernel_ms, second_ms = step_kernels_ms, None
     if world > 1:
@@ -872,7 +874,9 @@ def main():
                          "kernel": {"exhaustive": "k_invert_exhaustive32", "exhaustive_f64": "k_invert_exhaustive"}.get(
                              args.algo, "k_invert_band" if second_ms is not None else "k_invert"),
                          "kernel_ms": round(kernel_ms, 3), "bytes_per_pixel": bytes_px,
-                         "second_kernel": None if second_ms is None else {"kernel": "k_invert_list", "kernel_ms": round(second_ms, 3),
+                         "second_kernel": None if second_ms is None else {"kernel": "k_invert_band2 + k_invert_list", "kernel_ms": round(second_ms, 3),
+                                                                           "k_invert_band2_ms": round(tm.get("band2_kernel_ms", 0.0) / args.steps, 3),
+                                                                           "pixels_to_band2_last_launch": tm.get("last_band2_pixels"),
                                                                            "pixels_last_launch": tm.get("last_list_pixels")},
                          "step_kernels_ms": round(step_kernels_ms, 3),
                          "note": f"algorithmic raster bytes ({bytes_px} B read+written per pixel x rank 0's {lines * samples} px) / mean "

@@ -163,17 +163,19 @@ int xsw_synchronize(xsw_ctx *ctx);
 /* Replaces Model.to_lut(...) -> closure arrays (windspeed.py:144-181).  Either may be NULL (kept).
  * Device memory held per context for the default co-pol table (501 x 499 x 181): 368 MB float64 + 184 MB float32 copies,
  * 363 MB transposed copy, 394 MB inverse-row table (first row of every direction at or above each of 2048 dB thresholds
- * per incidence slice: what the band search reads instead of bisecting), ~7 MB of small tables; all derived copies are
- * produced on the device at install (a few ms). */
+ * per incidence slice: what the band search reads instead of bisecting), ~7 MB of small tables (XSW_BAND2=1: + 755 MB for
+ * the rise-then-fall tables of k_invert_band2); all derived copies are produced on the device at install (a few ms). */
 int xsw_lut_upload(xsw_ctx *ctx, const xsw_lut *co, const xsw_lut *cr);
 
 /* Replaces _invert_from_model_numpy (windspeed.py:132-331).  Asynchronous on the context's stream
  * when mem == XSW_MEM_DEVICE; synchronous (returns with outputs filled) for host memory.
  * XSW_ALGO_PRUNED on a LUT whose columns rise monotonically with wind speed (every built-in GMF over most of its rows) runs
- * as two launches: k_invert_band decides the pixels its band rule can, k_invert_list the rest from a work list owned by
- * the context (4 bytes per EIGHTH pixel of the largest raster seen; a scene that leaves more than an eighth of its pixels
- * undecided overflows the list, which k_invert_list answers by inverting every tile itself; if the list cannot be
- * allocated the one-kernel path runs); any other LUT, and XSW_ALGO_EXACT, take the general kernel.
+ * as two launches: k_invert_band decides the pixels its band rule can, k_invert_list the rest from a work list owned by the
+ * context (4 bytes per EIGHTH pixel of the largest raster seen; a scene that leaves more than an eighth of its pixels
+ * undecided overflows the list, which k_invert_list answers by inverting every tile itself; if the list cannot be allocated
+ * the one-kernel path runs); any other LUT, and XSW_ALGO_EXACT, take the general kernel.  (Environment XSW_BAND2=1 inserts a
+ * third kernel between the two, k_invert_band2: the band rule on both branches of LUT columns that rise and then fall, for
+ * the pixels whose search window leaves the monotone rows; exact, tested, off by default -- it does not pay on CMOD5.N.)
  * Results do not depend on the route (environment variable XSW_NO_BAND=1 forces the general kernel: A/B measurements). */
 int xsw_invert(xsw_ctx *ctx, const xsw_invert_args *args);
 
@@ -203,6 +205,8 @@ typedef struct {
     double first_kernel_ms;  /* k_invert_band, summed over the launches                               */
     double second_kernel_ms; /* k_invert_list, summed over the launches                               */
     int64_t last_list_pixels;/* pixels the most recent launch left to k_invert_list                   */
+    double band2_kernel_ms;  /* k_invert_band2 (the band rule on rise-then-fall columns, between the two), summed */
+    int64_t last_band2_pixels;/* pixels the most recent launch handed to k_invert_band2              */
 } xsw_timing;
 int xsw_timing_enable(xsw_ctx *ctx, int on);
 int xsw_timing_read(xsw_ctx *ctx, xsw_timing *out);

@@ -630,3 +630,61 @@ def test_random_configurations_large_axes(gpu_ctx):
         o = cport.invert_numpy(p, inc, sco, nan, nan, anc, return_idx=True, reference_layout=False)
         got = gpu_ctx.invert_host(inc, sigma0_co=sco, anc=anc, dsig_co=dsig_co, sigma0_is_db=True, algo="pruned", want_idx=True)
         assert np.array_equal(got[2][..., :2], o[2][..., :2]), (case, co.shape, shape, dsig_co)
+
+
+_BAND2_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {repo!r}); sys.path.insert(0, {repo!r} + "/tests")
+import torch
+from oracle import gmf, lut as olut
+from util import lut_dicts
+from test_gpu_kernel import synthetic_scene
+from xsarsea_amd import _lib
+lco = olut.to_lut("gmf_cmod5n")
+co, _ = lut_dicts(lco, None)
+ctx = _lib.Context(0)
+ctx.upload_luts(co=co)
+dev = torch.device("cuda", 0)
+for scale, inc_lo, inc_hi in ((1.0, 17.0, 25.0), (1.6, 20.0, 36.0), (2.5, 30.0, 46.0), (0.5, 17.0, 30.0)):
+    inc, s_vv, _, _, anc = synthetic_scene(160, 900, np.float32, 61)
+    inc = np.where(np.isnan(inc), np.nan, inc_lo + (inc - 30.0) * (inc_hi - inc_lo) / 16.0).astype(np.float32)
+    w_t, d_t = np.abs(anc), np.degrees(np.angle(anc))
+    rng = np.random.default_rng(5)
+    s_vv = (gmf.gmf_cmod5n(np.nan_to_num(inc, nan=30.0).astype(np.float64), np.maximum(w_t, 1.0).astype(np.float64) * 1.3, d_t.astype(np.float64))
+            * rng.gamma(100, 0.01, inc.shape)).astype(np.float32)
+    anc = (anc * scale).astype(np.complex64)
+    t = [torch.from_numpy(a).to(dev) for a in (inc, s_vv, anc)]
+    out = torch.empty(inc.shape, dtype=torch.complex64, device=dev)
+    torch.cuda.synchronize()
+    ctx.timing_enable(True)
+    ctx.invert_raw(inc.shape[0], inc.shape[1], _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, t[0].data_ptr(), t[1].data_ptr(), None, None,
+                   t[2].data_ptr(), out.data_ptr(), None, algo=_lib.ALGO_PRUNED)
+    tm = ctx.timing()
+    ctx.timing_enable(False)
+    ex = ctx.invert_host(inc, sigma0_co=s_vv, anc=anc, algo="exhaustive", out_dtype=np.complex64)
+    got = out.cpu().numpy()
+    diff = int(np.sum(got.view(np.int32) != ex[0].view(np.int32)))
+    print("RESULT", scale, diff, tm["launches"], tm["last_band2_pixels"], tm["last_list_pixels"])
+"""
+
+
+@pytest.mark.parametrize("list_cap", [None, "300"])
+def test_band2_rise_then_fall_columns(list_cap):
+    """XSW_BAND2=1 (opt-in, fresh process: read at LUT install): windows that leave the monotone rows of the LUT (high winds at
+    near-range incidences, where CMOD5.N saturates and turns over; a-priori winds far above the truth) are handed to
+    k_invert_band2, which applies the band rule to both branches of the rise-then-fall columns.  The three-kernel chain returns
+    the bits of the LDS-tiled exhaustive sweep (an independent kernel) on every pixel, k_invert_band2 really takes pixels, and
+    with list capacities of 300 pixels both overflow routes run (k_invert_band2 walks every strip, k_invert_list every tile)."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, XSW_BAND2="1")
+    if list_cap:
+        env["XSW_LIST_CAP_TEST"] = list_cap
+    r = subprocess.run([sys.executable, "-c", _BAND2_SCRIPT.format(repo=REPO)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [l.split() for l in r.stdout.splitlines() if l.startswith("RESULT")]
+    assert len(rows) == 4
+    for _, scale, diff, launches, b2, _listed in rows:
+        assert int(diff) == 0, f"scale {scale}: {diff} values differ from the exhaustive sweep"
+        assert int(launches) == 1 and (float(scale) < 1.0 or int(b2) > 0)

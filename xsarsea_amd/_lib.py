@@ -63,7 +63,7 @@ class Stats(ctypes.Structure):
 
 class Timing(ctypes.Structure):
     _fields_ = [("launches", ctypes.c_int64), ("first_kernel_ms", ctypes.c_double), ("second_kernel_ms", ctypes.c_double),
-                ("last_list_pixels", ctypes.c_int64)]
+                ("last_list_pixels", ctypes.c_int64), ("band2_kernel_ms", ctypes.c_double), ("last_band2_pixels", ctypes.c_int64)]
 
 
 _cdll = None

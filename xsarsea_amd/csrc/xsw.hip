@@ -37,7 +37,7 @@ struct xsw_ctx {
     unsigned long long *d_stats = nullptr;
     bool stats_on = false;
     bool timing_on = false;                 // xsw_timing_enable: HIP events around the kernels of every device-memory inversion
-    std::vector<hipEvent_t> timing_events;  // triples (start, after the first kernel, end) on the launch stream
+    std::vector<hipEvent_t> timing_events;  // quadruples (start, after k_invert_band, after k_invert_band2, end) on the launch stream
     unsigned *d_list = nullptr;  // hand-over k_invert_band -> k_invert_list: [0] = count, [16..] = pixel indices
     size_t list_cap = 0;         // entries (context-owned, grown on demand: an eighth of the largest raster seen)
     double *d_ratio = nullptr;  // detrend ratio row (context-owned, grown on demand)
@@ -232,19 +232,23 @@ extern "C" int xsw_timing_read(xsw_ctx *c, xsw_timing *out)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     out->launches = 0;
-    out->first_kernel_ms = out->second_kernel_ms = 0.0;
+    out->first_kernel_ms = out->second_kernel_ms = out->band2_kernel_ms = 0.0;
+    out->last_band2_pixels = 0;
     out->last_list_pixels = 0;
     if (c->d_list) {
-        unsigned cnt = 0;
-        HIPCHK(c, hipMemcpy(&cnt, c->d_list, sizeof cnt, hipMemcpyDeviceToHost));
-        out->last_list_pixels = (int64_t)cnt;
+        unsigned cnt[2] = {0, 0};
+        HIPCHK(c, hipMemcpy(cnt, c->d_list, sizeof cnt, hipMemcpyDeviceToHost));
+        out->last_list_pixels = (int64_t)cnt[0];
+        out->last_band2_pixels = (int64_t)cnt[1];
     }
-    for (size_t k = 0; k + 3 <= c->timing_events.size(); k += 3) {
-        float a = 0.f, b = 0.f;
+    for (size_t k = 0; k + 4 <= c->timing_events.size(); k += 4) {
+        float a = 0.f, b = 0.f, d = 0.f;
         HIPCHK(c, hipEventElapsedTime(&a, c->timing_events[k], c->timing_events[k + 1]));
         HIPCHK(c, hipEventElapsedTime(&b, c->timing_events[k + 1], c->timing_events[k + 2]));
+        HIPCHK(c, hipEventElapsedTime(&d, c->timing_events[k + 2], c->timing_events[k + 3]));
         out->first_kernel_ms += a;
-        out->second_kernel_ms += b;
+        out->band2_kernel_ms += b;
+        out->second_kernel_ms += d;
         out->launches += 1;
     }
     for (hipEvent_t e : c->timing_events) (void)hipEventDestroy(e);
@@ -257,7 +261,7 @@ static void timing_mark(xsw_ctx *c)
     if (!c->timing_on) return;
     hipEvent_t e = nullptr;
     if (hipEventCreate(&e) == hipSuccess && hipEventRecord(e, c->stream) == hipSuccess) c->timing_events.push_back(e);
-    else c->timing_on = false;  // never half a triple
+    else c->timing_on = false;  // never half a quadruple
 }
 
 extern "C" int xsw_stats_read(xsw_ctx *c, xsw_stats *out)
@@ -385,6 +389,37 @@ static int install_co(xsw_ctx *c, const xsw_lut *l, const double *d_dense)
                 e = hipGetLastError();
             }
             if (e == hipSuccess) { T.inv_rows = d_inv; T.inv_grid = d_grid; }
+        }
+        // the same for columns that rise and then fall (k_invert_band2; 755 MB at the default size).  OFF unless XSW_BAND2=1:
+        // measured in round 3, the windows that leave the monotone rows sit on the flat top of the saturating GMF, where a
+        // band of +-d dB is tens of rows long -- the rule prunes little there and k_invert_band2 hands most of its pixels on
+        // to the general kernel anyway.  Kept as a tested, exact route for LUTs with steep falling branches.
+        T.inv2 = nullptr; T.inv_grid2 = nullptr; T.bitonic_ok = nullptr;
+        static const bool band2_on = getenv("XSW_BAND2") != nullptr && atoi(getenv("XSW_BAND2")) != 0;
+        const size_t inv2_n = (size_t)nI * 2 * (XSW_INV_BINS + 1) * ppad;
+        if (e == hipSuccess && T.inv_rows && band2_on && inv2_n * sizeof(unsigned short) < ((size_t)1 << 32)) {
+            unsigned short *d_inv2 = nullptr, *d_peak = nullptr;
+            double *d_grid2 = nullptr;
+            int *d_ok = nullptr;
+            hipError_t e2 = hipMalloc((void **)&d_inv2, inv2_n * sizeof(unsigned short) + 64);
+            if (e2 == hipSuccess) { c->co_allocs.push_back(d_inv2); e2 = hipMalloc((void **)&d_grid2, (size_t)3 * nI * sizeof(double) + 64); }
+            if (e2 == hipSuccess) { c->co_allocs.push_back(d_grid2); e2 = hipMalloc((void **)&d_ok, (size_t)nI * sizeof(int) + 64); }
+            if (e2 == hipSuccess) { c->co_allocs.push_back(d_ok); e2 = hipMalloc((void **)&d_peak, (size_t)nI * nP * sizeof(unsigned short) + 64); }
+            if (e2 == hipSuccess) {
+                c->co_allocs.push_back(d_peak);
+                std::vector<int> ones((size_t)nI, 1);
+                e2 = hipMemcpy(d_ok, ones.data(), (size_t)nI * sizeof(int), hipMemcpyHostToDevice);
+            }
+            if (e2 == hipSuccess) e2 = hipMemsetAsync(d_inv2, 0, inv2_n * sizeof(unsigned short), c->stream);
+            if (e2 == hipSuccess) {
+                const unsigned nb = (unsigned)(((long long)nI * nP + 255) / 256);
+                hipLaunchKernelGGL(k_peak_rows, dim3(nb), dim3(256), 0, c->stream, d_dense, nI, nW, nP, d_peak, d_ok);
+                hipLaunchKernelGGL(k_inv_range2, dim3((unsigned)nI), dim3(256), 0, c->stream, d_dense, nW, nP, d_grid2);
+                hipLaunchKernelGGL(k_inv_rows2, dim3(nb), dim3(256), 0, c->stream, d_dense, nI, nW, nP, ppad, d_peak, d_grid2, d_inv2);
+                e2 = hipGetLastError();
+            }
+            if (e2 == hipSuccess) { T.inv2 = d_inv2; T.inv_grid2 = d_grid2; T.bitonic_ok = d_ok; }
+            else (void)hipGetLastError();  // feature off, nothing else depends on it
         }
         if (e == hipSuccess) e = hipMemcpyAsync(h_flags, d_flags, sizeof h_flags, hipMemcpyDeviceToHost, c->stream);
         hipError_t se = hipStreamSynchronize(c->stream);
@@ -611,8 +646,11 @@ static int launch_invert(xsw_ctx *c, const KArgs &A, int algo, const LaunchCtl &
         KArgs B = A;
         B.list_count = lc.list;
         B.list = lc.list + 16;
-        B.list_cap = (unsigned)std::min<size_t>(lc.list_cap, 0xffffffffu);
-        if (hipMemsetAsync(lc.list, 0, sizeof(unsigned), lc.stream) != hipSuccess) return seterr(err, XSW_EHIP, "work-list reset failed");
+        B.list_cap = (unsigned)std::min<size_t>(lc.list_cap, 0xfffffff0u);
+        // list B (k_invert_band -> k_invert_band2: windows that leave the monotone rows of a rise-then-fall slice) follows list G
+        const bool band2 = c->T.inv2 != nullptr && !A.stats;  // (the statistics instantiation keeps the two-kernel chain)
+        if (band2) { B.list_b_count = lc.list + 1; B.list_b = lc.list + 16 + lc.list_cap; B.list_b_cap = B.list_cap; }
+        if (hipMemsetAsync(lc.list, 0, 2 * sizeof(unsigned), lc.stream) != hipSuccess) return seterr(err, XSW_EHIP, "work-list reset failed");
         const unsigned list_blocks = (unsigned)std::min<long long>(nblocks, 256 * 8);  // 8 waves per SIMD
         // k_invert_band: x = XCD lane + 8 * line group, y = tile column inside the XCD's range (see the kernel)
         const long long cols_per_xcd = (strips_per_line + 7) / 8;
@@ -627,6 +665,12 @@ static int launch_invert(xsw_ctx *c, const KArgs &A, int algo, const LaunchCtl &
             hipLaunchKernelGGL((k_invert_band<T, TO, false, false>), band_grid, band_block, 0, lc.stream, c->T, B);
         } else {
             hipLaunchKernelGGL((k_invert_band<T, TO, true, false>), band_grid, band_block, 0, lc.stream, c->T, B);
+        }
+        if (lc.timing) timing_mark(c);
+        if (band2) {
+            const dim3 b2_grid((unsigned)std::min<long long>(nblocks, 256 * XSW_BAND2_WAVES));  // XSW_BAND2_WAVES waves per SIMD, 4-wave workgroups
+            if (mono) hipLaunchKernelGGL((k_invert_band2<T, TO, false>), b2_grid, band_block, 0, lc.stream, c->T, B);
+            else hipLaunchKernelGGL((k_invert_band2<T, TO, true>), b2_grid, band_block, 0, lc.stream, c->T, B);
         }
         if (lc.timing) timing_mark(c);
         if (mono) hipLaunchKernelGGL((k_invert_list<T, TO, false>), dim3(list_blocks), dim3(256), 0, lc.stream, c->T, B);
@@ -657,7 +701,12 @@ static int dispatch_invert(xsw_ctx *c, const KArgs &A, int dtype, int out_dtype,
 
 // Work list of the device-raster path: an eighth of the raster's pixels (the benchmark scene leaves 0.06 %; a scene that
 // leaves more than an eighth overflows it, see k_invert_list).  A failed allocation selects the one-kernel path.
-static size_t list_entries_for(long long n) { return (size_t)std::max<long long>(n / 8, 1 << 16); }
+static size_t list_entries_for(long long n)
+{
+    static const char *test_cap = getenv("XSW_LIST_CAP_TEST");  // tests: a tiny capacity, so that the overflow route runs
+    if (test_cap) return (size_t)std::max(atoll(test_cap), 16LL);
+    return (size_t)std::max<long long>(n / 8, 1 << 16);
+}
 static void ensure_list(xsw_ctx *c, long long n)
 {
     const size_t want = list_entries_for(n);
@@ -667,7 +716,7 @@ static void ensure_list(xsw_ctx *c, long long n)
     c->d_list = nullptr;
     c->list_cap = 0;
     static const bool no_list = getenv("XSW_FAIL_LIST_ALLOC") != nullptr;  // tests: the allocation-failure route
-    if (!no_list && hipMalloc((void **)&c->d_list, (want + 16) * sizeof(unsigned)) == hipSuccess) c->list_cap = want;
+    if (!no_list && hipMalloc((void **)&c->d_list, (2 * want + 16) * sizeof(unsigned)) == hipSuccess) c->list_cap = want;  // lists G and B
     else { c->d_list = nullptr; (void)hipGetLastError(); }
 }
 
@@ -933,7 +982,7 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
                  o_dsig = o_cr + (a->sigma0_cr ? pad(max_px * es) : 0), o_anc = o_dsig + (a->dsig_cr ? pad(max_px * es) : 0),
                  o_cc = o_anc + (a->anc ? pad(max_px * es * 2) : 0), o_ccr = o_cc + (want_co ? pad(max_px * 4) : 0),
                  o_end = o_ccr + (want_cr ? pad(max_px * 4) : 0);
-    const size_t list_cap = std::max<size_t>(max_px / 4, 1 << 14), dev_bytes = o_end + (list_cap + 16) * sizeof(unsigned);
+    const size_t list_cap = std::max<size_t>(max_px / 4, 1 << 14), dev_bytes = o_end + (2 * list_cap + 16) * sizeof(unsigned);  // lists G and B
     const int dtype = a->dtype, out_dtype = a->out_dtype;
     static const bool prof = getenv("XSW_HOST_PROFILE") != nullptr;  // phase times of the pipeline on stderr (experiments)
     std::atomic<long long> t_stage{0}, t_gpu{0}, t_expand{0}, t_reserve{0};

@@ -64,6 +64,12 @@ namespace xsw {
 #ifndef XSW_BAND_WAVES
 #define XSW_BAND_WAVES 8
 #endif
+#ifndef XSW_BAND2_MAX
+#define XSW_BAND2_MAX 24  // k_invert_band2: rows a direction may hold before the pixel is left to the general kernel
+#endif
+#ifndef XSW_BAND2_WAVES
+#define XSW_BAND2_WAVES 5  // k_invert_band2 (two column branches per direction: more live state; at 8 waves it spills 0.5 KB per lane)
+#endif
 
 struct BandSlot {  // 64 bytes per pixel, read by every lane of its segment (same address: LDS broadcast)
     double sn, thr_lo, thr_hi, ah, bh, m2;
@@ -77,7 +83,11 @@ __device__ __forceinline__ double ld_co(const char *__restrict__ base, unsigned 
     return *(const double *)(base + (off0 + __umul24((unsigned)row, rowB)));
 }
 
-template <int S, int K, bool COUNT>
+// BITONIC (k_invert_band2): the columns may rise and then fall.  A window of n directions is laid out as 2n virtual columns --
+// column c < n is the RISING part of direction c (rows below the column's first decreasing step), column n + c its FALLING part
+// -- so a lane still owns one run of rows per column: only the table (L.inv2: rising and falling inverse tables side by side,
+// XSW_INV_BINS + 1 thresholds, the last one +inf) and the order of the two threshold bins differ between the two halves.
+template <int S, int K, bool COUNT, bool BITONIC>
 __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig, int lane,
                                              const BandSlot *slots /* this wave's [64], sorted by class */, int *res /* [64], by slot */,
                                              int first, int count /* slots [first, first + count) -> segments 0 .. count-1 */, unsigned &cand)
@@ -89,6 +99,7 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
     BandSlot B = slots[owner];
     if (!valid) { B.inc_bin = 0; B.rows = 0; B.ipn = 0; B.bin_hi = -1; }  // idle segment: harmless addresses, nothing scored
     const int B_ip_lo = B.ipn & 0xffff, B_ncols = (int)((unsigned)B.ipn >> 16);
+    const int B_vcols = BITONIC ? 2 * B_ncols : B_ncols;  // virtual columns
     const int w_lo = B.rows & 0xffff, w_hi = B.rows >> 16;
     const double thr_lo = B.thr_lo, thr_hi = B.thr_hi, sn = B.sn;
     const double wh0 = 0.5 * L.w0, whs = L.wstep_half;
@@ -98,23 +109,28 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
     const unsigned slice0 = (unsigned)(i_inc * L.n_w) * rowB;
     // rows of the inverse table (2-byte entries, one per direction, < 4 GB: xsw.hip): the largest threshold <= s - d gives a
     // row at or below the band's first, the smallest threshold > s + d one past a row at or above its last
-    const unsigned inv0 = (unsigned)(i_inc * XSW_INV_BINS + ((unsigned)B.inc_bin >> 16)) * (unsigned)L.phi_pad * 2u;
-    const unsigned inv1 = (unsigned)(i_inc * XSW_INV_BINS + max(B.bin_hi, 0)) * (unsigned)L.phi_pad * 2u;
+    constexpr int NB = BITONIC ? XSW_INV_BINS + 1 : XSW_INV_BINS;  // thresholds per column table
+    const unsigned short *__restrict__ inv_tab = BITONIC ? L.inv2 : L.inv_rows;
+    const unsigned inv0 = (unsigned)(i_inc * (BITONIC ? 2 : 1) * NB + ((unsigned)B.inc_bin >> 16)) * (unsigned)L.phi_pad * 2u;
+    const unsigned inv1 = (unsigned)(i_inc * (BITONIC ? 2 : 1) * NB + max(B.bin_hi, 0)) * (unsigned)L.phi_pad * 2u;
+    const unsigned inv_fall = (unsigned)NB * (unsigned)L.phi_pad * 2u;  // BITONIC: the falling table follows the rising one
     double best = inf, second = inf;
     int brow = 0, bip = 0;
     unsigned ncand = 0;
     bool overflow = false;
-    const int nchunks = S == 64 ? (__builtin_amdgcn_readfirstlane(B_ncols) + 64 * K - 1) / (64 * K) : 1;  // S == 64: one pixel, wave-uniform
+    const int nchunks = S == 64 ? (__builtin_amdgcn_readfirstlane(B_vcols) + 64 * K - 1) / (64 * K) : 1;  // S == 64: one pixel, wave-uniform
 #pragma unroll 1
     for (int ch = 0; ch < nchunks; ++ch) {
-        bool act[K];
+        bool act[K], fall[K];
         int ip[K], r[K], nrow[K];
         unsigned off0[K];
         double U[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const int col = sl + S * j + S * K * ch;  // blocked: the lanes of a segment read contiguous directions in every load
-            act[j] = valid && col < B_ncols;
+            const int vcol = sl + S * j + S * K * ch;  // blocked: the lanes of a segment read contiguous directions in every load
+            act[j] = valid && vcol < B_vcols;
+            fall[j] = BITONIC && vcol >= B_ncols;
+            const int col = fall[j] ? vcol - B_ncols : vcol;
             ip[j] = B_ip_lo + (act[j] ? col : 0);
             const unsigned ipB = (unsigned)ip[j] * 8u;
             const double2 cs = *(const double2 *)((const char *)L.csphi + 2u * ipB);
@@ -125,12 +141,22 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
         int nmax = 0;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const int ra = (int)*(const unsigned short *)((const char *)L.inv_rows + (inv0 + (unsigned)ip[j] * 2u));
-            const int rb = (int)*(const unsigned short *)((const char *)L.inv_rows + (inv1 + (unsigned)ip[j] * 2u));
+            // rising part: rows [table(bin <= s - d), table(bin > s + d)); falling part: [table'(bin > s + d), table'(bin <= s - d))
+            const unsigned o_first = (fall[j] ? inv1 + inv_fall : inv0) + (unsigned)ip[j] * 2u;
+            const unsigned o_last = (fall[j] ? inv0 + inv_fall : inv1) + (unsigned)ip[j] * 2u;
+            const int ra = (int)*(const unsigned short *)((const char *)inv_tab + o_first);
+            const int rb = (int)*(const unsigned short *)((const char *)inv_tab + o_last);
             r[j] = max(ra, w_lo);
-            const int last = B.bin_hi >= 0 ? min(rb - 1, w_hi) : w_hi;
+            const int last = (BITONIC || B.bin_hi >= 0) ? min(rb - 1, w_hi) : w_hi;  // BITONIC: the "no threshold above" bin is tabulated
             nrow[j] = act[j] ? last - r[j] + 1 : 0;
             nmax = max(nmax, nrow[j]);
+        }
+        if (BITONIC && nmax > XSW_BAND2_MAX) {
+            // a long run (the flat top of a saturating column): the band rule prunes little there and a lane walks its run row
+            // by row, whereas the general kernel sweeps such a window 64 candidates per trip -- leave the pixel to it, unswept
+            overflow = true;
+#pragma unroll
+            for (int j = 0; j < K; ++j) nrow[j] = 0;
         }
 #pragma unroll 1
         for (int t = 0; t < XSW_BAND_MAX; ++t) {  // scalar trip counter; the loop leaves as soon as no lane has rows left
@@ -156,7 +182,7 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
                 if (COUNT) ncand += inb ? 1u : 0u;
             }
         }
-        const bool any = nmax > XSW_BAND_MAX;
+        const bool any = nmax > (BITONIC ? XSW_BAND2_MAX : XSW_BAND_MAX);
         overflow = overflow || any;  // rows left after XSW_BAND_MAX trips
         if (K == 1 && S != 64) bip = ip[0];
     }
@@ -174,32 +200,33 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
     }
 }
 
+// Compact append of the wave's flagged pixels to a work list: one atomicAdd per wave.  Past the capacity the counter keeps
+// running (the consumer sees count > cap and falls back to inverting every tile: k_invert_list).
+__device__ __forceinline__ void list_append(unsigned *__restrict__ count, unsigned *__restrict__ list, unsigned cap, bool flag, long long i, int lane)
+{
+    const unsigned long long um = __ballot(flag);
+    if (!um) return;
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(count, (unsigned)__popcll(um));
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    const unsigned at = base + __builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
+    if (flag && at < cap) list[at] = (unsigned)i;
+}
+
+// One wave's 64 pixels (lane l: pixel i, `in` = the lane has one) through stage 1, the band passes, the cross-pol phase and the
+// store.  Body of k_invert_band (tiles of the raster) and k_invert_band2 (pixels of a work list, BITONIC rule).
 // COUNT = true: the statistics instantiation (xsw_stats_enable): candidates are counted per pass; its own kernel so that the
 // production kernel carries one copy of each pass (half the code).
-template <typename T, typename TO, bool CR, bool COUNT>
-__global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_invert_band(DevTables L, KArgs A)
+template <typename T, typename TO, bool CR, bool COUNT, bool BITONIC>
+__device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, long long i, bool in, int lane, BandSlot *__restrict__ slots,
+                                          int *__restrict__ res_)
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __shared__ BandSlot slots[XSW_BAND_WG_WAVES][64];  // search parameters of the wave's eligible pixels, sorted by window class
-    __shared__ int res_[XSW_BAND_WG_WAVES][64];        // slot -> winning flat index (or -1)
-    // same tile walk as k_invert (XCD x owns a contiguous range of tile columns, line groups fastest), as a 2-D grid so that
-    // no division is needed: blockIdx.x = xcd + 8 * line group, blockIdx.y = tile column inside the XCD's range (workgroups
-    // are dealt to the XCDs round-robin in linear order, x fastest: the XCD of a workgroup is still blockIdx.x & 7)
-    const long long strips_per_line = (A.samples + 63) >> 6;
-    const long long cols_per_xcd = (strips_per_line + 7) >> 3;
-    const long long xcd = blockIdx.x & 7;
-    const long long col = xcd * cols_per_xcd + blockIdx.y;
-    const long long line = (long long)(blockIdx.x >> 3) * XSW_BAND_WG_WAVES + wv;
-    if (col >= strips_per_line || line >= A.lines) return;  // wave-uniform
-    const long long smp = col * 64 + lane;
-    const bool in = smp < A.samples;
-    const long long i = line * A.samples + (in ? smp : A.samples - 1);
     const double nan = __builtin_nan("");
-
     int flags, my_flat = -1, my_icr = -1;
     unsigned cand = 0;
     constexpr int NC = 11;  // window classes: S lanes x K directions = 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128 (and wider: chunks)
     int pos = -1, first[NC] = {}, ncls[NC] = {};  // slot of this lane's pixel; slot range of each class
+    bool to_bitonic = false;  // not eligible here only because its window leaves the monotone rows of a rise-then-fall slice
     {
         // ---- stage 1, one pixel per lane: classify, incidence bin, upper bound along the a-priori direction, window
         Pixel P;
@@ -219,17 +246,23 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_inve
             const int nrows_p = W.w_hi - W.w_lo + 1;
             ncols_p = W.ip_hi - W.ip_lo + 1;
             const bool need = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0 && !loose && ncols_p >= 1 && nrows_p >= 1;
-            eligb = need && W.w_hi < L.mono_rows[need ? P.i_inc : 0];  // the window stays inside the monotone rows
+            if (BITONIC) {
+                eligb = need && L.bitonic_ok[need ? P.i_inc : 0] != 0;  // every column of the slice rises, then falls
+            } else {
+                eligb = need && W.w_hi < L.mono_rows[need ? P.i_inc : 0];  // the window stays inside the monotone rows
+                to_bitonic = need && !eligb && L.inv2 != nullptr && L.bitonic_ok[P.i_inc] != 0;
+            }
             if (COUNT) cand += (unsigned)__popcll(__ballot(eligb)) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)) + (XSW_BAND_RAYS - 1) * 2 * XSW_RAY_SIDE_STEPS);
-            // class of a window by its number of directions n: the smallest of 4, 6, 8, 12, ..., 96, 128 that holds it, i.e. S lanes
+            // class of a window by its number of (virtual) columns n: the smallest of 4, 6, 8, 12, ..., 96, 128 that holds it, i.e. S lanes
             // x K directions per lane with K = 2 (capacity 2S) or 3 (capacity 3S, S half as large: twice the pixels per pass of
             // the next power of two).  The slots are written SORTED by class (slot = pixels of narrower classes + rank inside the
             // class): a pass takes the next 64/S slots of its class, no per-pass ranking, and a lane picks its result up from its
             // slot once, after the last pass
             int myc = NC;
             if (eligb) {
-                const int p2 = 31 - __clz(max(ncols_p, 2) - 1);  // 2^p2 < n <= 2^(p2 + 1)
-                myc = ncols_p <= 4 ? 0 : min(2 * p2 - 3 + (ncols_p > (3 << (p2 - 1)) ? 1 : 0), NC - 1);
+                const int nv = BITONIC ? 2 * ncols_p : ncols_p;
+                const int p2 = 31 - __clz(max(nv, 2) - 1);  // 2^p2 < n <= 2^(p2 + 1)
+                myc = nv <= 4 ? 0 : min(2 * p2 - 3 + (nv > (3 << (p2 - 1)) ? 1 : 0), NC - 1);
             }
             int base = 0;
 #pragma unroll
@@ -260,7 +293,7 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_inve
                 b.ah = ah; b.bh = bh; b.m2 = ah * ah + bh * bh;
                 // threshold bin of the slice's inverse table: the largest grid threshold <= s - d (bin 0 also stands for
                 // anything below the grid); the check repeats the builder's own expression (k_inv_rows)
-                const double *g = L.inv_grid + 3 * P.i_inc;
+                const double *g = (BITONIC ? L.inv_grid2 : L.inv_grid) + 3 * P.i_inc;
                 const double t0 = g[0], width = g[1];
                 int bin = (int)fmin(fmax((b.thr_lo - t0) * g[2], 0.0), (double)(XSW_INV_BINS - 1));
                 if (bin > 0 && fma((double)bin, width, t0) > b.thr_lo) --bin;
@@ -270,9 +303,9 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_inve
                 if (bhi < XSW_INV_BINS && !(fma((double)bhi, width, t0) > b.thr_hi)) ++bhi;
                 if (bhi < XSW_INV_BINS && !(fma((double)bhi, width, t0) > b.thr_hi)) bhi = XSW_INV_BINS;
                 b.inc_bin = P.i_inc | (bin << 16); b.rows = W.w_lo | (W.w_hi << 16); b.ipn = W.ip_lo | (ncols_p << 16);
-                b.bin_hi = bhi < XSW_INV_BINS ? bhi : -1;
-                slots[wv][pos] = b;
-                res_[wv][pos] = -1;
+                b.bin_hi = bhi < XSW_INV_BINS ? bhi : (BITONIC ? XSW_INV_BINS /* the tabulated +inf threshold */ : -1);
+                slots[pos] = b;
+                res_[pos] = -1;
             }
         }
     }
@@ -284,7 +317,7 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_inve
         auto run = [&](auto seg, auto kk, int c) {
             constexpr int S = decltype(seg)::value, K = decltype(kk)::value;
             for (int p = 0; p < ncls[c]; p += 64 / S)
-                co_band_pass<S, K, COUNT>(L, A.inv_dsig_co, lane, slots[wv], res_[wv], first[c] + p, min(64 / S, ncls[c] - p), cand);
+                co_band_pass<S, K, COUNT, BITONIC>(L, A.inv_dsig_co, lane, slots, res_, first[c] + p, min(64 / S, ncls[c] - p), cand);
         };
         using two = std::integral_constant<int, 2>;
         using three = std::integral_constant<int, 3>;
@@ -303,7 +336,7 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_inve
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (pos >= 0) my_flat = res_[wv][pos];  // -1: undecided by its pass
+    if (pos >= 0) my_flat = res_[pos];  // -1: undecided by its pass
     const bool need_co = (flags & F_NEED_CO) != 0;
     bool unresolved = in && need_co && my_flat < 0;  // not eligible, or undecided by its pass
 
@@ -336,16 +369,10 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_inve
             atomicAdd(&A.stats[3], (unsigned long long)__popcll(done_cr));
         }
     }
-    {   // hand the undecided pixels over to k_invert_list: one atomic per wave, then a compact append
-        const unsigned long long um = __ballot(unresolved);
-        if (um) {
-            unsigned base = 0;
-            if (lane == 0) base = atomicAdd(A.list_count, (unsigned)__popcll(um));
-            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-            const unsigned at = base + __builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
-            if (unresolved && at < A.list_cap) A.list[at] = (unsigned)i;  // past the capacity: k_invert_list sees count > cap and takes every tile
-        }
-    }
+    // hand the undecided pixels over: a window that left the monotone rows of a rise-then-fall slice goes to k_invert_band2 (list
+    // B, the band rule on both branches of the columns), everything else -- and what k_invert_band2 cannot decide -- to k_invert_list
+    if (!BITONIC && A.list_b) list_append(A.list_b_count, A.list_b, A.list_b_cap, unresolved && to_bitonic, i, lane);
+    list_append(A.list_count, A.list, A.list_cap, unresolved && !(!BITONIC && A.list_b && to_bitonic), i, lane);
     if (in) {
         if (!unresolved) {
             Pixel Q;  // what store_pixel reads: flags and the ancillary wind (reloaded: not kept live through the passes)
@@ -358,6 +385,62 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_inve
             }
             store_pixel<TO, CR>(L, A, i, Q, my_flat, my_icr);
         }
+    }
+}
+
+template <typename T, typename TO, bool CR, bool COUNT>
+__global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_invert_band(DevTables L, KArgs A)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ BandSlot slots[XSW_BAND_WG_WAVES][64];  // search parameters of the wave's eligible pixels, sorted by window class
+    __shared__ int res_[XSW_BAND_WG_WAVES][64];        // slot -> winning flat index (or -1)
+    // same tile walk as k_invert (XCD x owns a contiguous range of tile columns, line groups fastest), as a 2-D grid so that
+    // no division is needed: blockIdx.x = xcd + 8 * line group, blockIdx.y = tile column inside the XCD's range (workgroups
+    // are dealt to the XCDs round-robin in linear order, x fastest: the XCD of a workgroup is still blockIdx.x & 7)
+    const long long strips_per_line = (A.samples + 63) >> 6;
+    const long long cols_per_xcd = (strips_per_line + 7) >> 3;
+    const long long xcd = blockIdx.x & 7;
+    const long long col = xcd * cols_per_xcd + blockIdx.y;
+    const long long line = (long long)(blockIdx.x >> 3) * XSW_BAND_WG_WAVES + wv;
+    if (col >= strips_per_line || line >= A.lines) return;  // wave-uniform
+    const long long smp = col * 64 + lane;
+    const bool in = smp < A.samples;
+    const long long i = line * A.samples + (in ? smp : A.samples - 1);
+    band_wave<T, TO, CR, COUNT, false>(L, A, i, in, lane, slots[wv], res_[wv]);
+}
+
+// Second kernel of the three-kernel chain: the pixels k_invert_band left on list B (their window leaves the monotone rows of a
+// slice whose columns rise and then fall: high winds at near-range incidences, where CMOD5.N saturates and turns over) with the
+// band rule applied to BOTH branches of every column.  64 listed pixels per wave (gathered rasters), fixed grid, every wave
+// strides over the list; a list that overflowed is left to k_invert_list (which then inverts every tile).
+template <typename T, typename TO, bool CR>
+__global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND2_WAVES) void k_invert_band2(DevTables L, KArgs A)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ BandSlot slots[XSW_BAND_WG_WAVES][64];
+    __shared__ int res_[XSW_BAND_WG_WAVES][64];
+    const long long count = (long long)*A.list_b_count;
+    const long long nwaves = (long long)gridDim.x * XSW_BAND_WG_WAVES;
+    if (count > (long long)A.list_b_cap) {
+        // list B overflowed (k_invert_band kept counting but could not append): which pixels it meant is unknown, so EVERY strip
+        // of the raster goes through the rise-then-fall rule -- it holds for monotone windows as well (their falling runs are
+        // empty), and results do not depend on which kernel wrote a pixel.  Only scenes whose windows leave the monotone rows
+        // wholesale (an a-priori wind far above the truth) come here.
+        const long long strips_per_line = (A.samples + 63) >> 6, nstrips = strips_per_line * A.lines;
+        for (long long c = (long long)blockIdx.x * XSW_BAND_WG_WAVES + wv; c < nstrips; c += nwaves) {  // wave-uniform
+            const long long line = c / strips_per_line, smp = (c - line * strips_per_line) * 64 + lane;
+            const bool in = smp < A.samples;
+            band_wave<T, TO, CR, false, true>(L, A, line * A.samples + (in ? smp : A.samples - 1), in, lane, slots[wv], res_[wv]);
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+    for (long long c = (long long)blockIdx.x * XSW_BAND_WG_WAVES + wv; c * 64 < count; c += nwaves) {  // wave-uniform
+        const long long k = c * 64 + lane;
+        const bool in = k < count;
+        const long long i = (long long)A.list_b[in ? k : count - 1];
+        band_wave<T, TO, CR, false, true>(L, A, i, in, lane, slots[wv], res_[wv]);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

@@ -51,6 +51,14 @@ struct DevTables {
     // LUT >= fma(b, inv_grid[3i+1], inv_grid[3i]) (a uniform dB grid per slice, XSW_INV_BINS bins), else mono_rows[i]
     const unsigned short *inv_rows;  // [n_inc][XSW_INV_BINS][phi_pad]
     const double *inv_grid;          // [n_inc][3]: t0, bin width, 1 / bin width
+    // the same for columns that rise and then fall (k_invert_band2): per slice and direction the rising part is rows [0, P), P the
+    // first row lower than its predecessor, the falling part rows [P, n_w).  inv2[i][0][b][p] = first row r < P with LUT >= t_b
+    // (else P), inv2[i][1][b][p] = first row r >= P with LUT < t_b (else n_w); thresholds t_b = fma(b, inv_grid2[3i+1], inv_grid2[3i])
+    // over the dB range of the WHOLE slice, b = 0 .. XSW_INV_BINS - 1, plus row b = XSW_INV_BINS for "+inf" (P in both tables);
+    // falling table: bin 0 = n_w (nothing lies below the slice's minimum).  bitonic_ok[i]: every column of slice i has that shape.
+    const unsigned short *inv2;      // [n_inc][2][XSW_INV_BINS + 1][phi_pad]   (null: not built)
+    const double *inv_grid2;         // [n_inc][3]
+    const int *bitonic_ok;           // [n_inc]
     double w0, inv_wstep, phi0, phi_last, inv_dphi;
     double wstep_half;  // 0.5 / inv_wstep (host: one IEEE division instead of one per wave and pass)
     double inv_nphi;    // 1 / n_phi: flat index -> (row, direction) without an integer division
@@ -78,6 +86,8 @@ struct KArgs {
     unsigned *list;             // two-kernel path (nullable): k_invert_band appends the flat index of every pixel it leaves
     unsigned *list_count;       // undecided; k_invert_list then inverts exactly those, 64 per wave
     unsigned list_cap;          // entries the list holds; the counter runs on past it (overflow: k_invert_list takes every tile)
+    unsigned *list_b, *list_b_count;  // list B (nullable): pixels k_invert_band hands to k_invert_band2 (rise-then-fall columns)
+    unsigned list_b_cap;
     long long n, lines, samples;
     double dsig_co, inv_dsig_co, dsig_cr_scalar;
     int is_db, dual_select;
