@@ -164,9 +164,15 @@ __global__ __launch_bounds__(256) void k_nesz_rows(const T *__restrict__ noise, 
     double n[R], sx[R], sy[R], sxx[R], sxy[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) n[j] = sx[j] = sy[j] = sxx[j] = sxy[j] = 0.0;
+    // float32 rasters: the reference takes log10 and 10** in float32 (numpy keeps the raster's dtype, utils.py:133-152), so the
+    // hardware's float32 log2 / exp2 (v_log_f32 / v_exp_f32, ~1 ulp) are the matching precision -- one instruction each instead
+    // of ~50 float64 instructions for the series pair, which is what bounded this kernel (0.38 of the HBM rate in round 2).
+    // The moments and the fit stay float64.  float64 rasters keep the float64 series (1e-13 vs numpy).
+    constexpr bool F32 = sizeof(T) == 4;
     auto take = [&](int j, double v, double m, double x) {
         if (v != v) v = m;
-        const double y = 10.0 * nesz_log10(v);  // NaN for v < 0 or NaN, -inf for 0: dropped like the reference's isfinite mask
+        // NaN for v < 0 or NaN, -inf for 0: dropped like the reference's isfinite mask
+        const double y = F32 ? (double)(3.0102999566398120f * __builtin_amdgcn_logf((float)v)) : 10.0 * nesz_log10(v);
         // polyfit sees x[ok]: a NaN abscissa (column without valid incidence) poisons the fit there; here too
         if (isfinite(y)) { n[j] += 1.0; sx[j] += x; sy[j] += y; sxx[j] += x * x; sxy[j] += x * y; }
     };
@@ -227,7 +233,9 @@ __global__ __launch_bounds__(256) void k_nesz_rows(const T *__restrict__ noise, 
         for (int j = 0; j < R; ++j) {
             if (!live[j]) continue;
             double *o = out + (l0 + j) * samples + s;
-            const double ra = nesz_exp10((xa * slope[j] + icpt[j] - 1.0) * 0.1), rb = nesz_exp10((xb * slope[j] + icpt[j] - 1.0) * 0.1);
+            const double ta = (xa * slope[j] + icpt[j] - 1.0) * 0.1, tb = (xb * slope[j] + icpt[j] - 1.0) * 0.1;
+            const double ra = F32 ? (double)__builtin_amdgcn_exp2f((float)(ta * 3.321928094887362)) : nesz_exp10(ta);
+            const double rb = F32 ? (double)__builtin_amdgcn_exp2f((float)(tb * 3.321928094887362)) : nesz_exp10(tb);
             if ((((size_t)o) & 15) == 0) { double2 t; t.x = ra; t.y = rb; *(double2 *)o = t; }
             else { o[0] = ra; o[1] = rb; }
         }
@@ -235,7 +243,10 @@ __global__ __launch_bounds__(256) void k_nesz_rows(const T *__restrict__ noise, 
     for (long long s = pairs * 2 + threadIdx.x; s < samples; s += blockDim.x)
 #pragma unroll
         for (int j = 0; j < R; ++j)
-            if (live[j]) out[(l0 + j) * samples + s] = nesz_exp10((xs[s] * slope[j] + icpt[j] - 1.0) * 0.1);
+            if (live[j]) {
+                const double tt = (xs[s] * slope[j] + icpt[j] - 1.0) * 0.1;
+                out[(l0 + j) * samples + s] = F32 ? (double)__builtin_amdgcn_exp2f((float)(tt * 3.321928094887362)) : nesz_exp10(tt);
+            }
 }
 
 }  // namespace xsw
