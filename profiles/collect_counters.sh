@@ -16,7 +16,7 @@ for set in \
  "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
  "SQ_INST_CYCLES_VMEM_RD SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_WAVES SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU" ; do
   i=$((i+1))
-  XSW_TRAFFIC_ONLY_INVERT=1 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/profiles/traffic_driver.py > $OUT/p$i.log 2>&1 || echo "pass $i failed"
+  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/profiles/traffic_driver.py > $OUT/p$i.log 2>&1 || echo "pass $i failed"
 done
 python3 - <<PY
 import csv, glob, json, collections

@@ -64,6 +64,9 @@ namespace xsw {
 #ifndef XSW_BAND_WAVES
 #define XSW_BAND_WAVES 8
 #endif
+#ifndef XSW_BAND_WAVES_CR
+#define XSW_BAND_WAVES_CR 7  // the dual-pol instantiation: 8 / 7 / 6 waves per SIMD measured 59.8 / 58.3 / 58.8 ms at 20000^2 (8 spills 12-20 B per lane)
+#endif
 #ifndef XSW_BAND2_MAX
 #define XSW_BAND2_MAX 24  // k_invert_band2: rows a direction may hold before the pixel is left to the general kernel
 #endif
@@ -389,7 +392,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
 }
 
 template <typename T, typename TO, bool CR, bool COUNT>
-__global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND_WAVES) void k_invert_band(DevTables L, KArgs A)
+__global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, CR ? XSW_BAND_WAVES_CR : XSW_BAND_WAVES) void k_invert_band(DevTables L, KArgs A)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ BandSlot slots[XSW_BAND_WG_WAVES][64];  // search parameters of the wave's eligible pixels, sorted by window class

@@ -1078,8 +1078,10 @@ __device__ __forceinline__ void store_pixel(const DevTables &L, const KArgs &A, 
         ((cx_t *)A.out_co)[i] = z;
     }
     // the answer as grid codes (xsw.h): what xsw_expand_codes turns back into exactly the values formed above
+#ifndef XSW_NO_CODES
     if (A.code_co)
         A.code_co[i] = (P.flags & F_EARLY_NAN) ? K_CODE_NAN_RE : (P.flags & F_NEED_CO) ? ((unsigned)my_flat | ((unsigned)sgn << 30)) : K_CODE_NAN;
+#endif
     if (CR && (A.out_cr || A.code_cr)) {
         bool picked_co = false;
         if (A.dual_select) {  // xr.where((|co| < 5) | (|dual| < 5), co, dual)  (windspeed.py:426-428)
@@ -1097,9 +1099,11 @@ __device__ __forceinline__ void store_pixel(const DevTables &L, const KArgs &A, 
             cx_t z; z.x = (TO)cr_re; z.y = (TO)cr_im;
             ((cx_t *)A.out_cr)[i] = z;
         }
+#ifndef XSW_NO_CODES
         if (A.code_cr)
             A.code_cr[i] = (P.flags & F_EARLY_NAN) ? K_CODE_NAN_RE
                                                      : (((P.flags & F_NEED_CR) ? (unsigned)my_icr : K_CODE_NO_INDEX) | (picked_co ? K_CODE_PICK_CO : 0u));
+#endif
     }
     if (A.out_idx) {
         A.out_idx[3 * i + 0] = o_iw;
