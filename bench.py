@@ -874,10 +874,10 @@ def main():
                          "kernel": {"exhaustive": "k_invert_exhaustive32", "exhaustive_f64": "k_invert_exhaustive"}.get(
                              args.algo, "k_invert_band" if second_ms is not None else "k_invert"),
                          "kernel_ms": round(kernel_ms, 3), "bytes_per_pixel": bytes_px,
-                         "second_kernel": None if second_ms is None else {"kernel": "k_invert_band2 + k_invert_list", "kernel_ms": round(second_ms, 3),
-                                                                           "k_invert_band2_ms": round(tm.get("band2_kernel_ms", 0.0) / args.steps, 3),
-                                                                           "pixels_to_band2_last_launch": tm.get("last_band2_pixels"),
-                                                                           "pixels_last_launch": tm.get("last_list_pixels")},
+                         "second_kernel": None if second_ms is None else dict(
+                             {"kernel": "k_invert_list", "kernel_ms": round(second_ms, 3), "pixels_last_launch": tm.get("last_list_pixels")},
+                             **({"kernel": "k_invert_band2 + k_invert_list", "k_invert_band2_ms": round(tm.get("band2_kernel_ms", 0.0) / args.steps, 3),
+                                 "pixels_to_band2_last_launch": tm.get("last_band2_pixels")} if os.environ.get("XSW_BAND2", "0") not in ("", "0") else {})),
                          "step_kernels_ms": round(step_kernels_ms, 3),
                          "note": f"algorithmic raster bytes ({bytes_px} B read+written per pixel x rank 0's {lines * samples} px) / mean "
                                  "duration of the dominant kernel per step (HIP events on the launch stream, recorded by the library around each kernel); "

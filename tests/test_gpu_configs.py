@@ -193,6 +193,17 @@ def test_bench_line_contract(tmp_path):
     p = j["parity"]
     assert p["nan_mask_equal"] is True and p["index_match_host_db"] == 1.0 and p["index_match_device_db"] > 0.999
     assert j["detrend"]["roofline"]["bound"] == "hbm" and j["nesz_flatten"]["roofline"]["bound"] == "hbm" and j["lut"]["lut_device_build_ms"] > 0
+    # round 3: the line states the error of the path it times, times the bit-parity route end to end, and carries the host path
+    for k in ("max_rel_err_uv_c64_device_db", "pixels_outside_1e-4_device_db", "pixels_outside_1e-4_host_db"):
+        assert k in p, k
+    assert p["pixels_outside_1e-4_host_db"] == 0 and p["frac_outside_1e-4_device_db"] < 1e-3
+    e2e = j["parity_config_end_to_end"]
+    assert e2e["value"] > 0 and abs(e2e["host_log10_ms"] + e2e["upload_ms"] + e2e["kernels_ms"] - e2e["ms"]) < 0.5
+    hp = j["host_path"]
+    assert hp["value"] > 0 and hp["roofline"]["bound"] == "pcie" and hp["bytes_over_pcie"] == 20 * 768 * 2048
+    assert "numpy_restatement" in cb and cb["numpy_restatement"]["equals_c_port"] is True
+    # counter-derived fields are either fresh (stamped with the loaded library's device-code hash) or null with a reason
+    assert rf["traffic"] is None or "measured_on" in rf["traffic_provenance"]
 
 
 @pytest.mark.parametrize("cfg,shape", [("4", (2503, 1700)), ("3", (1001, 1030))])
