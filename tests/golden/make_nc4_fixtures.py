@@ -35,7 +35,7 @@ def table(n_inc, n_w, n_phi, seed):
     return inc, w, None, v
 
 
-def write(name, style, n_phi=5, chunked=False, fletcher=False, libver=None, dtype="<f8", seed=0, pol="VV"):
+def write(name, style, n_phi=5, chunked=False, fletcher=False, libver=None, dtype="<f8", seed=0, pol="VV", extra_attrs=0):
     inc, w, phi, v = table(6, 7, n_phi, seed)
     path = os.path.join(HERE, name)
     nc4 = style == "netcdf4"
@@ -62,6 +62,8 @@ def write(name, style, n_phi=5, chunked=False, fletcher=False, libver=None, dtyp
         text = dict(units="dB", resolution="low", model="cmod_fixture", pol=pol)
         if nc4:
             f.attrs.create("_NCProperties", np.bytes_("version=2,netcdf=4.7.4,hdf5=1.10.6"))
+            for k in range(extra_attrs):  # a file with a long history: the attribute heap outgrows its first direct block
+                f.attrs.create(f"history_{k:02d}", np.bytes_(f"step {k}: " + "processing note " * (3 + k % 5)))
             for k, val in text.items():
                 f.attrs.create(k, np.bytes_(val))                       # NC_CHAR: fixed-length string, scalar dataspace
             for k, val in {**ranges, **steps}.items():
@@ -91,3 +93,5 @@ if __name__ == "__main__":
     write("nc_lut_h5netcdf_deflate.nc", "h5netcdf", chunked=True, seed=6)
     write("nc_lut_h5netcdf_latest.nc", "h5netcdf", libver="latest", seed=7)
     write("nc_lut_netcdf4_v18.nc", "netcdf4", libver=("v108", "latest"), seed=8)
+    write("nc_lut_netcdf4_many_attrs.nc", "netcdf4", seed=9, extra_attrs=18)
+    write("nc_lut_h5py_latest_chunked.nc", "h5netcdf", chunked=True, libver="latest", seed=10)  # layout v4 chunk index: refused

@@ -2,6 +2,8 @@
 and the golden vectors.  (No device compute here.)"""
 import warnings
 
+import os
+
 import numpy as np
 import pytest
 
@@ -263,10 +265,70 @@ def test_netcdf_lut_roundtrip(tmp_path):
     assert hi.shape == (501, 499, 181) and hi.attrs["units"] == "dB"
     assert np.allclose(hi.values[::10, ::2, ::5], raw.values[:, :, ::2], rtol=0, atol=1e-9)  # the shared grid nodes are kept
     assert m_cr._lut(units="dB").shape == (501, 771)
-    # an HDF5-based file is refused with a clear message when xarray is absent
+    # a truncated HDF5 file, and a file that is neither container, fail with a clear message
     bad = tmp_path / "nc_lut_hdf5.nc"
     bad.write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
-    with pytest.raises(ImportError, match="classic netCDF-3"):
+    with pytest.raises((ValueError, NotImplementedError)):
         models.NcLutModel(str(bad))
+    junk = tmp_path / "nc_lut_junk.nc"
+    junk.write_bytes(b"not a netcdf file at all")
+    with pytest.raises(ImportError, match="neither"):
+        models.NcLutModel(str(junk))
     for n in ("nc_lut_rt_cmod5n", "nc_lut_rt_s1_v2"):
         models.Model._available_models.pop(n, None)
+
+
+NC4 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nc4")
+NC4_FILES = ["nc_lut_netcdf4_contiguous.nc", "nc_lut_netcdf4_deflate.nc", "nc_lut_netcdf4_deflate_fletcher_f32.nc", "nc_lut_netcdf4_crosspol.nc",
+             "nc_lut_netcdf4_v18.nc", "nc_lut_netcdf4_many_attrs.nc", "nc_lut_h5netcdf_earliest.nc", "nc_lut_h5netcdf_deflate.nc",
+             "nc_lut_h5netcdf_latest.nc"]
+
+
+@pytest.mark.parametrize("fname", NC4_FILES)
+def test_netcdf4_hdf5_lut_files(fname):
+    """netCDF-4 (HDF5) LUT files in the layouts of both xarray backends -- netCDF4-python (creation order tracked: dense
+    attribute storage in a fractal heap + v2 B-tree, fixed-length text attributes, 1-element numeric attributes, `_NCProperties`,
+    `_FillValue`) and h5netcdf (variable-length strings in the global heap, old-style groups or the latest file format) --
+    contiguous or chunked + shuffle + deflate (+ fletcher32), float64 or float32: the package's own HDF5 reader returns the
+    table, the axes (in DIMENSION_LIST order) and the global attributes the fixture generator wrote (tests/golden/make_nc4_fixtures.py,
+    h5py in the build container's conda), and `NcLutModel` builds the model from them like from a classic file."""
+    from xsarsea_amd.windspeed import hdf5_min, models, nc_io
+    path = os.path.join(NC4, fname)
+    exp = np.load(path + ".expected.npz")
+    assert hdf5_min.is_hdf5(path) and not nc_io.is_classic_netcdf(path)
+    f = hdf5_min.File(path)
+    has_phi = "phi" in exp
+    assert f.names() == sorted(["incidence", "wspd", "sigma0_model"] + (["phi"] if has_phi else []))
+    assert f.dims("sigma0_model") == (("incidence", "wspd", "phi") if has_phi else ("incidence", "wspd"))
+    assert np.array_equal(np.asarray(f.read("sigma0_model"), np.float64), exp["values"])
+    lut = nc_io.read_lut(path)
+    assert np.array_equal(lut.values, exp["values"]) and lut.values.dtype == np.float64
+    assert np.array_equal(lut.incidence, exp["incidence"]) and np.array_equal(lut.wspd, exp["wspd"])
+    assert (lut.phi is None) == (not has_phi) and (not has_phi or np.array_equal(lut.phi, exp["phi"]))
+    attrs = nc_io.read_attrs(path)
+    for k in ("units", "resolution", "model", "pol"):
+        assert attrs[k] == str(exp[k]), (k, attrs[k])
+    for k in ("inc_range", "wspd_range") + (("phi_range",) if has_phi else ()):
+        assert np.array_equal(np.asarray(attrs[k], np.float64), exp[k])
+    for k in ("inc_step", "wspd_step") + (("phi_step",) if has_phi else ()):
+        assert float(attrs[k]) == float(exp[k])
+    assert not any(k.startswith("_NC") for k in attrs)
+    if fname == "nc_lut_netcdf4_many_attrs.nc":  # 29 attributes: indirect root block of the heap, B-tree of depth 1
+        assert sum(k.startswith("history_") for k in attrs) == 18 and attrs["history_03"].startswith("step 3: processing note")
+    m = models.NcLutModel(path)
+    try:
+        assert m.pol == str(exp["pol"]) and m.short_name == "cmod_fixture" and m.iscopol == has_phi
+        raw = m._raw_lut()
+        assert np.array_equal(raw.values, exp["values"]) and raw.attrs["units"] == "dB" and raw.attrs["resolution"] == "low"
+    finally:
+        models.Model._available_models.pop(m.name, None)
+
+
+def test_netcdf4_layout_v4_chunk_index_is_refused_clearly():
+    """A chunked variable written with libver >= 1.10 bounds (HDF5 'version 4' data layout: fixed-array chunk index) is outside
+    the reader's subset -- netCDF-4 writers keep the 1.8-compatible layout -- and says so; its attributes still read."""
+    from xsarsea_amd.windspeed import nc_io
+    path = os.path.join(NC4, "nc_lut_h5py_latest_chunked.nc")
+    assert nc_io.read_attrs(path)["units"] == "dB"
+    with pytest.raises(NotImplementedError, match="layout version 4"):
+        nc_io.read_lut(path)

@@ -1,0 +1,587 @@
+"""Minimal pure-Python reader of the HDF5 container of netCDF-4 files -- just enough to open the xsarsea LUT files that
+`Model.to_netcdf` (reference: windspeed/models.py:232-262) produces when xarray writes through a netCDF-4 backend
+(netCDF4-python or h5netcdf) and that `NcLutModel` (:350-410) reads back: a root group with a handful of float datasets
+(`sigma0_model` over the dimension scales `incidence`, `wspd` [, `phi`]) and about ten global attributes.
+
+Neither the build image nor the GPU image has an HDF5 library for the product's interpreter, hence this module
+(numpy + zlib only).  Implemented from the HDF5 File Format Specification (version 3.0):
+  superblock versions 0-3; object headers version 1 and 2 (continuation blocks); old-style groups (symbol-table B-tree +
+  local heap) and new-style groups with compact links or dense links (fractal heap + version-2 B-tree); compact and
+  dense attribute storage (netCDF-4 tracks creation order, so a root group with more than 8 attributes -- the LUT schema has
+  11 -- stores them in a fractal heap); datatypes: fixed point, floating point, fixed-length and variable-length strings
+  (global heap), object references, variable-length sequences of references (DIMENSION_LIST); dataspaces version 1 and 2; data layout
+  version 3 (compact, contiguous, chunked through a version-1 B-tree) and version 4 contiguous / compact / single-chunk /
+  implicit / fixed-array indexed chunks are NOT needed by netCDF-4 writers (they keep the 1.8-compatible layout) and are refused;
+  filters: deflate, shuffle, fletcher32.
+Anything outside that subset raises `NotImplementedError` with the structure's name.  Fixtures: tests/golden/nc4/ (written by
+h5py in the layouts of both backends, tests/golden/make_nc4_fixtures.py).
+"""
+import struct
+import zlib
+
+import numpy as np
+
+SIGNATURE = b"\x89HDF\r\n\x1a\n"
+UNDEF = 0xFFFFFFFFFFFFFFFF
+
+
+def is_hdf5(path):
+    with open(path, "rb") as f:
+        return f.read(8) == SIGNATURE
+
+
+class _Buf:
+    """Random-access little-endian reader over the whole file (LUT files are a few MB to a few hundred MB)."""
+
+    def __init__(self, data):
+        self.d = data
+
+    def u(self, off, n):
+        return int.from_bytes(self.d[off:off + n], "little")
+
+    def bytes(self, off, n):
+        if off + n > len(self.d) or off < 0:
+            raise ValueError("HDF5: read past the end of the file (truncated or corrupt)")
+        return self.d[off:off + n]
+
+
+class Datatype:
+    """What is needed of a datatype message: numpy dtype for atomic types, or the kind of string / reference / vlen."""
+
+    def __init__(self, buf, off):
+        b = buf.d
+        cv = b[off]
+        self.cls, self.version = cv & 0x0F, cv >> 4
+        bits = b[off + 1] | (b[off + 2] << 8) | (b[off + 3] << 16)
+        self.size = buf.u(off + 4, 4)
+        self.kind = None       # "num" | "str" | "vstr" | "ref" | "vlen"
+        self.dtype = None
+        self.base = None
+        props = off + 8
+        if self.cls == 0:      # fixed point
+            order = ">" if bits & 1 else "<"
+            self.kind, self.dtype = "num", np.dtype(f"{order}{'i' if bits & 8 else 'u'}{self.size}")
+            self.msg_size = 8 + 4
+        elif self.cls == 1:    # floating point
+            order = ">" if bits & 1 else "<"
+            if bits & 0x40:
+                raise NotImplementedError("HDF5 datatype: VAX byte order")
+            self.kind, self.dtype = "num", np.dtype(f"{order}f{self.size}")
+            self.msg_size = 8 + 12
+        elif self.cls == 3:    # fixed-length string
+            self.kind, self.dtype = "str", np.dtype(f"S{self.size}")
+            self.pad = bits & 0x0F
+            self.msg_size = 8
+        elif self.cls == 7:    # reference
+            if bits & 0x0F:
+                raise NotImplementedError("HDF5 datatype: region references")
+            self.kind, self.dtype = "ref", np.dtype("<u8")
+            self.msg_size = 8
+        elif self.cls == 9:    # variable length
+            self.base = Datatype(buf, props)
+            self.kind = "vstr" if (bits & 0x0F) == 1 else "vlen"
+            self.msg_size = 8 + self.base.msg_size
+        else:
+            raise NotImplementedError(f"HDF5 datatype class {self.cls} (compound / enum / array / opaque / bitfield / time)")
+
+
+def _dataspace(buf, off):
+    """-> (shape tuple, message size).  Scalar: (); null: None."""
+    ver, rank, flags = buf.d[off], buf.d[off + 1], buf.d[off + 2]
+    if ver == 1:
+        p = off + 8
+    elif ver == 2:
+        if buf.d[off + 3] == 2:
+            return None, 4
+        p = off + 4
+    else:
+        raise NotImplementedError(f"HDF5 dataspace message version {ver}")
+    shape = tuple(buf.u(p + 8 * k, 8) for k in range(rank))
+    size = (p - off) + 8 * rank * (2 if flags & 1 else 1)
+    return shape, size
+
+
+class _FractalHeap:
+    def __init__(self, buf, addr, O, L):
+        if buf.bytes(addr, 4) != b"FRHP":
+            raise ValueError("HDF5: bad fractal heap signature")
+        p = addr + 5
+        self.id_len = buf.u(p, 2); p += 2
+        self.filter_len = buf.u(p, 2); p += 2
+        self.flags = buf.d[p]; p += 1
+        self.max_managed = buf.u(p, 4); p += 4
+        p += L + O + L + O          # next huge id, huge b-tree, free space, free-space manager
+        p += L * 4                  # managed space, allocated, iterator offset, number of managed objects
+        p += L * 4                  # huge size / count, tiny size / count
+        self.width = buf.u(p, 2); p += 2
+        self.start_size = buf.u(p, L); p += L
+        self.max_direct = buf.u(p, L); p += L
+        self.max_heap_bits = buf.u(p, 2); p += 2
+        p += 2                      # starting rows in root indirect block
+        self.root = buf.u(p, O); p += O
+        self.cur_rows = buf.u(p, 2); p += 2
+        if self.filter_len:
+            raise NotImplementedError("HDF5 fractal heap with I/O filters")
+        self.buf, self.O, self.addr = buf, O, addr
+        self.off_size = (self.max_heap_bits + 7) // 8
+        self.len_size = (min(self.max_direct, self.max_managed).bit_length() + 7) // 8
+        self.blocks = []            # (heap offset, size, file address)
+        if self.root != UNDEF:
+            if self.cur_rows == 0:
+                self.blocks.append((0, self.start_size, self.root))
+            else:
+                self._indirect(self.root, self.cur_rows)
+
+    def _row_size(self, row):
+        return self.start_size if row < 2 else self.start_size << (row - 1)
+
+    def _indirect(self, addr, nrows):
+        buf, O = self.buf, self.O
+        if buf.bytes(addr, 4) != b"FHIB":
+            raise ValueError("HDF5: bad fractal heap indirect block signature")
+        p = addr + 5 + O
+        block_off = buf.u(p, self.off_size); p += self.off_size
+        max_direct_rows = (self.max_direct.bit_length() - 1) - (self.start_size.bit_length() - 1) + 2
+        off = block_off
+        for row in range(nrows):
+            size = self._row_size(row)
+            for _ in range(self.width):
+                child = buf.u(p, O); p += O
+                if row < max_direct_rows:
+                    if child != UNDEF:
+                        self.blocks.append((off, size, child))
+                elif child != UNDEF:
+                    raise NotImplementedError("HDF5 fractal heap with nested indirect blocks")
+                off += size
+
+    def get(self, heap_id):
+        kind = (heap_id[0] >> 4) & 3
+        if kind == 2:  # tiny object: the data is in the ID itself
+            n = (heap_id[0] & 0x0F) + 1
+            return bytes(heap_id[1:1 + n])
+        if kind != 0:
+            raise NotImplementedError("HDF5 fractal heap huge objects")
+        off = int.from_bytes(heap_id[1:1 + self.off_size], "little")
+        n = int.from_bytes(heap_id[1 + self.off_size:1 + self.off_size + self.len_size], "little")
+        for boff, size, addr in self.blocks:
+            if boff <= off < boff + size:
+                return self.buf.bytes(addr + (off - boff), n)
+        raise ValueError("HDF5: fractal heap object outside every direct block")
+
+
+def _btree2_records(buf, addr, O, L):
+    """Every record of a version-2 B-tree (leaf and internal nodes both hold records), in tree order."""
+    if addr == UNDEF:
+        return 0, []
+    if buf.bytes(addr, 4) != b"BTHD":
+        raise ValueError("HDF5: bad v2 B-tree header signature")
+    rtype = buf.d[addr + 5]
+    node_size = buf.u(addr + 6, 4)
+    rec_size = buf.u(addr + 10, 2)
+    depth = buf.u(addr + 12, 2)
+    root = buf.u(addr + 16, O)
+    nroot = buf.u(addr + 16 + O, 2)
+    if nroot == 0 or root == UNDEF:
+        return rtype, []
+    nbytes = lambda x: (int(x).bit_length() + 7) // 8
+    # per level: the most records a node can hold, and the most its whole subtree can hold (they size the pointer fields)
+    max_nrec, cum_max = [(node_size - 10) // rec_size], [(node_size - 10) // rec_size]
+    for lvl in range(1, depth + 1):
+        ptr = O + nbytes(max_nrec[lvl - 1]) + (nbytes(cum_max[lvl - 1]) if lvl - 1 > 0 else 0)
+        max_nrec.append((node_size - 10 - ptr) // (rec_size + ptr))
+        cum_max.append((max_nrec[lvl] + 1) * cum_max[lvl - 1] + max_nrec[lvl])
+    out = []
+
+    def walk(node, nrec, lvl):
+        sig = b"BTLF" if lvl == 0 else b"BTIN"
+        if buf.bytes(node, 4) != sig:
+            raise ValueError("HDF5: bad v2 B-tree node signature")
+        p = node + 6
+        recs = [buf.bytes(p + k * rec_size, rec_size) for k in range(nrec)]
+        if lvl == 0:
+            out.extend(recs)
+            return
+        p += nrec * rec_size
+        n1, n2 = nbytes(max_nrec[lvl - 1]), (nbytes(cum_max[lvl - 1]) if lvl - 1 > 0 else 0)
+        for k in range(nrec + 1):
+            child, cn = buf.u(p, O), buf.u(p + O, n1)
+            p += O + n1 + n2
+            walk(child, cn, lvl - 1)
+            if k < nrec:
+                out.append(recs[k])
+
+    walk(root, nroot, depth)
+    return rtype, out
+
+
+class File:
+    """`File(path)`: `.attrs` (global attributes), `.names()` (datasets of the root group), `.read(name)` -> ndarray,
+    `.dataset_attrs(name)`, `.dims(name)` -> names of the dimension scales attached to each axis (or None)."""
+
+    def __init__(self, path):
+        with open(path, "rb") as f:
+            self.buf = _Buf(f.read())
+        b = self.buf
+        base = 0
+        while b.d[base:base + 8] != SIGNATURE:
+            base = 512 if base == 0 else base * 2
+            if base >= len(b.d):
+                raise ValueError(f"{path}: not an HDF5 file")
+        ver = b.d[base + 8]
+        if ver in (0, 1):
+            self.O, self.L = b.d[base + 13], b.d[base + 14]
+            p = base + 24 + (4 if ver == 1 else 0)
+            self.base = b.u(p, self.O)
+            p += 4 * self.O            # base, free-space, end of file, driver info
+            root = b.u(p + self.O, self.O)  # root symbol table entry: link name offset, object header address
+        elif ver in (2, 3):
+            self.O, self.L = b.d[base + 9], b.d[base + 10]
+            p = base + 12
+            self.base = b.u(p, self.O)
+            root = b.u(p + 3 * self.O, self.O)
+        else:
+            raise NotImplementedError(f"HDF5 superblock version {ver}")
+        if self.O != 8 or self.L != 8:
+            raise NotImplementedError("HDF5 files with offsets / lengths other than 8 bytes")
+        if self.base not in (0, base):
+            raise NotImplementedError("HDF5 file with a relocated base address")
+        self._gcol = {}
+        self.root = self._object(root)
+        self._links = self._group_links(self.root)
+        self.attrs = self._attributes(self.root)
+
+    # ------------------------------------------------------------------ object headers
+    def _object(self, addr):
+        """-> list of (type, flags, data offset, size) of every header message of the object at `addr`."""
+        b, O, L = self.buf, self.O, self.L
+        msgs = []
+        if b.d[addr:addr + 4] == b"OHDR":
+            if b.d[addr + 4] != 2:
+                raise NotImplementedError("HDF5 object header version")
+            hflags = b.d[addr + 5]
+            p = addr + 6
+            if hflags & 0x20:
+                p += 16
+            if hflags & 0x10:
+                p += 4
+            nsz = 1 << (hflags & 3)
+            size0 = b.u(p, nsz); p += nsz
+            blocks = [(p, size0)]
+            track = bool(hflags & 4)
+            while blocks:
+                start, size = blocks.pop(0)
+                q, end = start, start + size
+                while q + 4 + (2 if track else 0) <= end:
+                    mtype, msize, mflags = b.d[q], b.u(q + 1, 2), b.d[q + 3]
+                    q += 4 + (2 if track else 0)
+                    if mtype == 0x10:
+                        caddr, clen = b.u(q, O), b.u(q + O, L)
+                        if b.bytes(caddr, 4) != b"OCHK":
+                            raise ValueError("HDF5: bad object header continuation signature")
+                        blocks.append((caddr + 4, clen - 8))  # minus signature and checksum
+                    elif mtype != 0:
+                        msgs.append((mtype, mflags, q, msize))
+                    q += msize
+            return {"addr": addr, "msgs": msgs, "v2": True}
+        if b.d[addr] != 1:
+            raise ValueError(f"HDF5: no object header at {addr}")
+        nmsgs = b.u(addr + 2, 2)
+        size0 = b.u(addr + 8, 4)
+        blocks = [(addr + 16, size0)]
+        while blocks and len(msgs) < nmsgs + 64:
+            start, size = blocks.pop(0)
+            q, end = start, start + size
+            while q + 8 <= end:
+                mtype, msize, mflags = b.u(q, 2), b.u(q + 2, 2), b.d[q + 4]
+                q += 8
+                if mtype == 0x10:
+                    blocks.append((b.u(q, O), b.u(q + O, L)))
+                elif mtype != 0:
+                    msgs.append((mtype, mflags, q, msize))
+                q += msize
+        return {"addr": addr, "msgs": msgs, "v2": False}
+
+    def _msg(self, obj, mtype):
+        for t, flags, off, size in obj["msgs"]:
+            if t == mtype:
+                if flags & 2:
+                    raise NotImplementedError("HDF5 shared header messages")
+                return off, size
+        return None
+
+    # ------------------------------------------------------------------ groups
+    def _group_links(self, obj):
+        b, O, L = self.buf, self.O, self.L
+        links = {}
+        st = self._msg(obj, 0x11)
+        if st:  # old-style group: B-tree of symbol-table nodes + local heap of names
+            btree, heap = b.u(st[0], O), b.u(st[0] + O, O)
+            if b.bytes(heap, 4) != b"HEAP":
+                raise ValueError("HDF5: bad local heap signature")
+            data = b.u(heap + 8 + 2 * L, O)
+
+            def name_at(off):
+                end = b.d.index(b"\x00", data + off)
+                return b.d[data + off:end].decode("utf-8")
+
+            def walk(node):
+                if b.bytes(node, 4) == b"SNOD":
+                    n = b.u(node + 6, 2)
+                    for k in range(n):
+                        e = node + 8 + k * (2 * O + 24)
+                        links[name_at(b.u(e, O))] = b.u(e + O, O)
+                    return
+                if b.bytes(node, 4) != b"TREE":
+                    raise ValueError("HDF5: bad group B-tree node signature")
+                used = b.u(node + 6, 2)
+                p = node + 8 + 2 * O
+                for k in range(used):
+                    walk(b.u(p + L + k * (L + O), O))
+
+            if btree != UNDEF:
+                walk(btree)
+            return links
+        for t, flags, off, size in obj["msgs"]:  # new-style group, compact storage: Link messages in the header
+            if t == 0x06:
+                name, target = self._link(off)
+                if target is not None:
+                    links[name] = target
+        li = self._msg(obj, 0x02)
+        if li:  # dense storage: links in a fractal heap, indexed by name in a v2 B-tree
+            lflags = b.d[li[0] + 1]
+            p = li[0] + 2 + (8 if lflags & 1 else 0)
+            heap_addr, bt = b.u(p, O), b.u(p + O, O)
+            if heap_addr != UNDEF:
+                heap = _FractalHeap(b, heap_addr, O, L)
+                rtype, recs = _btree2_records(b, bt, O, L)
+                for r in recs:
+                    hid = r[4:4 + heap.id_len] if rtype == 5 else r[8:8 + heap.id_len]
+                    blob = heap.get(hid)
+                    name, target = self._link(0, _Buf(blob))
+                    if target is not None:
+                        links[name] = target
+        return links
+
+    def _link(self, off, buf=None):
+        b = buf or self.buf
+        if b.d[off] != 1:
+            raise NotImplementedError("HDF5 link message version")
+        flags = b.d[off + 1]
+        p = off + 2
+        ltype = 0
+        if flags & 8:
+            ltype = b.d[p]; p += 1
+        if flags & 4:
+            p += 8
+        if flags & 16:
+            p += 1
+        nsz = 1 << (flags & 3)
+        n = b.u(p, nsz); p += nsz
+        name = bytes(b.d[p:p + n]).decode("utf-8"); p += n
+        return name, (b.u(p, self.O) if ltype == 0 else None)  # soft / external links are ignored
+
+    # ------------------------------------------------------------------ attributes
+    def _attributes(self, obj):
+        b, O, L = self.buf, self.O, self.L
+        out = {}
+        for t, flags, off, size in obj["msgs"]:
+            if t == 0x0C:
+                if flags & 2:
+                    raise NotImplementedError("HDF5 shared attribute messages")
+                k, v = self._attribute(self.buf, off)
+                out[k] = v
+        ai = self._msg(obj, 0x15)
+        if ai:  # dense attribute storage
+            aflags = b.d[ai[0] + 1]
+            p = ai[0] + 2 + (2 if aflags & 1 else 0)
+            heap_addr, bt = b.u(p, O), b.u(p + O, O)
+            if heap_addr != UNDEF:
+                heap = _FractalHeap(b, heap_addr, O, L)
+                _, recs = _btree2_records(b, bt, O, L)
+                for r in recs:  # record type 8: heap ID, message flags, creation order, hash
+                    blob = heap.get(r[:heap.id_len])
+                    k, v = self._attribute(_Buf(blob), 0)
+                    out[k] = v
+        return out
+
+    def _attribute(self, b, off):
+        ver = b.d[off]
+        nsz, tsz, ssz = b.u(off + 2, 2), b.u(off + 4, 2), b.u(off + 6, 2)
+        if ver == 1:
+            pad = lambda n: (n + 7) & ~7
+            p = off + 8
+        elif ver in (2, 3):
+            if b.d[off + 1] & 3:
+                raise NotImplementedError("HDF5 attribute with a shared datatype / dataspace")
+            pad = lambda n: n
+            p = off + 8 + (1 if ver == 3 else 0)
+        else:
+            raise NotImplementedError(f"HDF5 attribute message version {ver}")
+        name = bytes(b.d[p:p + nsz]).split(b"\x00")[0].decode("utf-8"); p += pad(nsz)
+        dt = Datatype(b, p); p += pad(tsz)
+        shape, _ = _dataspace(b, p); p += pad(ssz)
+        if shape is None:
+            return name, None
+        n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        return name, self._decode(dt, b.d[p:p + n * dt.size], shape)
+
+    def _decode(self, dt, raw, shape):
+        """Raw element bytes -> numpy array (numbers, references), str (scalar strings) or list (string arrays, vlen)."""
+        n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        if dt.kind in ("num", "ref"):
+            a = np.frombuffer(bytes(raw), dtype=dt.dtype, count=n).astype(dt.dtype.newbyteorder("="))
+            return a.reshape(shape) if shape else a.reshape(())[()]
+        if dt.kind == "str":
+            items = [bytes(raw[k * dt.size:(k + 1) * dt.size]).split(b"\x00")[0].rstrip(b" " if dt.pad == 2 else b"").decode("utf-8")
+                     for k in range(n)]
+            return items[0] if not shape else items
+        items = []
+        for k in range(n):  # variable length: (length, global heap collection address, object index)
+            e = bytes(raw[k * 16:(k + 1) * 16])
+            count, gaddr, gidx = struct.unpack("<IQI", e)
+            blob = self._global_heap_object(gaddr, gidx) if count else b""
+            if dt.kind == "vstr":
+                items.append(blob[:count].decode("utf-8"))
+            else:
+                items.append(self._decode(dt.base, blob[:count * dt.base.size], (count,)))
+        return items[0] if not shape else items
+
+    def _global_heap_object(self, addr, index):
+        if addr not in self._gcol:
+            b, L = self.buf, self.L
+            if b.bytes(addr, 4) != b"GCOL":
+                raise ValueError("HDF5: bad global heap collection signature")
+            size = b.u(addr + 8, L)
+            objs, p, end = {}, addr + 8 + L, addr + size
+            while p + 8 + L <= end:
+                idx = b.u(p, 2)
+                osize = b.u(p + 8, L)
+                if idx == 0:
+                    break
+                objs[idx] = bytes(b.d[p + 8 + L:p + 8 + L + osize])
+                p += 8 + L + ((osize + 7) & ~7)
+            self._gcol[addr] = objs
+        return self._gcol[addr][index]
+
+    # ------------------------------------------------------------------ datasets
+    def names(self):
+        return sorted(self._links)
+
+    def _dataset(self, name):
+        if name not in self._links:
+            raise KeyError(f"no dataset {name!r} in the HDF5 file (root group holds {self.names()})")
+        return self._object(self._links[name])
+
+    def dataset_attrs(self, name):
+        return self._attributes(self._dataset(name))
+
+    def dims(self, name):
+        """Names of the dimension scales attached to the axes of dataset `name` (netCDF-4 / h5py DIMENSION_LIST), else None."""
+        dl = self.dataset_attrs(name).get("DIMENSION_LIST")
+        if dl is None:
+            return None
+        by_addr = {addr: n for n, addr in self._links.items()}
+        out = []
+        for refs in dl:
+            refs = np.atleast_1d(refs)
+            out.append(by_addr.get(int(refs[0])) if len(refs) else None)
+        return tuple(out)
+
+    def read(self, name):
+        b, O, L = self.buf, self.O, self.L
+        obj = self._dataset(name)
+        dt = Datatype(b, self._msg(obj, 0x03)[0])
+        if dt.kind != "num":
+            raise NotImplementedError("HDF5: only numeric datasets are read")
+        shape, _ = _dataspace(b, self._msg(obj, 0x01)[0])
+        if shape is None:
+            return np.zeros((0,), dt.dtype)
+        n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        lo, _ = self._msg(obj, 0x08)
+        ver, cls = b.d[lo], b.d[lo + 1]
+        native = dt.dtype.newbyteorder("=")
+        if ver == 3 or (ver == 4 and cls in (0, 1)):
+            if cls == 0:
+                size = b.u(lo + 2, 2)
+                return np.frombuffer(bytes(b.d[lo + 4:lo + 4 + size]), dt.dtype, n).astype(native).reshape(shape)
+            if cls == 1:
+                addr = b.u(lo + 2, O)
+                if addr == UNDEF:
+                    return np.zeros(shape, native)
+                return np.frombuffer(b.bytes(addr, n * dt.size), dt.dtype, n).astype(native).reshape(shape)
+            if cls == 2:
+                rank1 = b.d[lo + 2]
+                btree = b.u(lo + 3, O)
+                chunk = tuple(b.u(lo + 3 + O + 4 * k, 4) for k in range(rank1 - 1))
+                return self._read_chunked(obj, dt, shape, chunk, btree).astype(native)
+        if ver == 4:
+            raise NotImplementedError("HDF5 data layout version 4 chunk indexes (file written with libver >= 1.10 bounds): "
+                                      "netCDF-4 writers keep the 1.8-compatible layout; rewrite the file or use the netCDF-3 form")
+        raise NotImplementedError(f"HDF5 data layout message version {ver}")
+
+    def _filters(self, obj):
+        m = self._msg(obj, 0x0B)
+        if not m:
+            return []
+        b, p = self.buf, m[0]
+        ver, nf = b.d[p], b.d[p + 1]
+        p += 8 if ver == 1 else 2
+        out = []
+        for _ in range(nf):
+            fid = b.u(p, 2)
+            if ver == 1 or fid >= 256:
+                nlen = b.u(p + 2, 2); p += 4
+            else:
+                nlen = 0; p += 2
+            p += 2  # flags
+            ncd = b.u(p, 2); p += 2
+            p += (nlen + 7) & ~7 if ver == 1 else nlen
+            cd = [b.u(p + 4 * k, 4) for k in range(ncd)]
+            p += 4 * ncd + (4 if (ver == 1 and ncd % 2) else 0)
+            out.append((fid, cd))
+        return out
+
+    def _read_chunked(self, obj, dt, shape, chunk, btree):
+        b, O = self.buf, self.O
+        filters = self._filters(obj)
+        out = np.zeros(shape, dt.dtype)
+        rank = len(shape)
+        csize = int(np.prod(chunk, dtype=np.int64)) * dt.size
+
+        def leafs(node):
+            if b.bytes(node, 4) != b"TREE":
+                raise ValueError("HDF5: bad chunk B-tree node signature")
+            level, used = b.d[node + 5], b.u(node + 6, 2)
+            p = node + 8 + 2 * O
+            ksize = 8 + 8 * (rank + 1)
+            for k in range(used):
+                key = p + k * (ksize + O)
+                child = b.u(key + ksize, O)
+                if level > 0:
+                    yield from leafs(child)
+                else:
+                    yield (b.u(key, 4), b.u(key + 4, 4), tuple(b.u(key + 8 + 8 * d, 8) for d in range(rank)), child)
+
+        if btree == UNDEF:
+            return out
+        for nbytes, mask, offs, addr in leafs(btree):
+            raw = bytes(b.bytes(addr, nbytes))
+            for k in range(len(filters) - 1, -1, -1):
+                if mask & (1 << k):
+                    continue
+                fid, cd = filters[k]
+                if fid == 3:      # fletcher32: checksum appended
+                    raw = raw[:-4]
+                elif fid == 1:    # deflate
+                    raw = zlib.decompress(raw)
+                elif fid == 2:    # shuffle
+                    es = cd[0] if cd else dt.size
+                    raw = np.frombuffer(raw, np.uint8).reshape(es, -1).T.tobytes()
+                else:
+                    raise NotImplementedError(f"HDF5 filter {fid} (only deflate, shuffle and fletcher32 are read)")
+            if len(raw) != csize:
+                raise ValueError("HDF5: chunk of unexpected size")
+            block = np.frombuffer(raw, dt.dtype).reshape(chunk)
+            sl = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, chunk, shape))
+            out[sl] = block[tuple(slice(0, s.stop - s.start) for s in sl)]
+        return out

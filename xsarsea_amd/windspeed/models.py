@@ -236,8 +236,8 @@ class ArrayLutModel(LutModel):
 
 class NcLutModel(LutModel):
     """LUT stored in the xsarsea netCDF format (variable `sigma0_model`, global attrs units / pol /
-    model / resolution / *_range / *_step; models.py:361-410).  Read through xarray when it is installed, else classic
-    netCDF-3 files through scipy (`nc_io`)."""
+    model / resolution / *_range / *_step; models.py:361-410).  Read through xarray when it is installed, else through
+    `nc_io`: classic netCDF-3 files with scipy, netCDF-4 / HDF5 files with the package's own minimal HDF5 reader."""
 
     _priority = 10
 
@@ -247,7 +247,7 @@ class NcLutModel(LutModel):
 
     def __init__(self, path, **kwargs):
         name = os.path.splitext(os.path.basename(path))[0]
-        if xr is None:  # classic netCDF-3 files through scipy (nc_io); HDF5-based netCDF-4 needs xarray
+        if xr is None:  # nc_io: classic netCDF-3 through scipy, netCDF-4 / HDF5 through hdf5_min
             from . import nc_io
             file_attrs = nc_io.read_attrs(path)
         else:
