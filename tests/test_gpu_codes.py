@@ -275,3 +275,22 @@ def test_codes_that_are_not_codes_expand_to_nan(gpu_ctx, default_luts):
     assert np.array_equal(np.isnan(h_cr.real), [False, False, True, True, True, True, True, True, True])
     assert h_cr[0] == 3.0 * np.exp(1j * 0.0) or np.isclose(abs(h_cr[0]), 3.0)
     assert h_co[8].imag == 0.0 and np.isnan(h_co[7].imag)
+
+
+def test_flat_raster_is_recut_into_tiles(gpu_ctx, default_luts):
+    """A 1-D vector of pixels (lines = 1: what stacked / flattened inputs give) is re-cut by the host path into lines of 4096
+    samples + a tail, so that the workgroups stay full and the chunks pipeline: same bits as the one-line raster inverted in HBM."""
+    torch = pytest.importorskip("torch")
+    from xsarsea_amd import _lib
+    lco, lcr = default_luts
+    co, cr = lut_dicts(lco, lcr)
+    gpu_ctx.upload_luts(co=co, cr=cr)
+    inc, s_vv, s_vh, dsig, anc = (a.reshape(-1)[:200_003] for a in synthetic_scene(300, 700, np.float32, 29))  # 48 lines of 4096 + 3395
+    ref = _device_run(gpu_ctx, torch, _lib, tuple(a.reshape(1, -1) for a in (inc, s_vv, s_vh, dsig, anc)), np.complex128, {"complex", "codes"},
+                      dual_select=True)
+    g = gpu_ctx.invert_host(inc, sigma0_co=s_vv, sigma0_cr=s_vh, dsig_cr=dsig, anc=anc, dual_select=True, want_idx=True, want_codes=True,
+                            algo="pruned")
+    assert g[0].shape == inc.shape
+    assert np.array_equal(_bits(g[0]), _bits(ref["co"].cpu().numpy().reshape(-1)))
+    assert np.array_equal(_bits(g[1]), _bits(ref["cr"].cpu().numpy().reshape(-1)))
+    assert np.array_equal(g[3][0], ref["cc"].cpu().numpy().reshape(-1).view(np.uint32))

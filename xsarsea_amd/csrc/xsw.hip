@@ -971,11 +971,17 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
     const size_t es = a->dtype == XSW_F32 ? 4 : 8;
     const bool want_co = a->sigma0_co || a->out_co || a->out_code_co;
     const bool want_cr = a->out_cr || a->out_code_cr || (a->sigma0_cr && a->out_idx);
+    // A flat raster (a long vector of pixels -- the core dimension is only a loop, windspeed.py:190; 1-D inputs arrive as one
+    // line) is re-cut into lines of 4096 samples + a tail: pixels are independent, and whole 4-line tiles keep the workgroups
+    // full (a one-line raster leaves three of a workgroup's four waves idle) and let the chunks pipeline.
+    long long lines = a->lines, samples = a->samples, tail_px = 0;
+    if (lines < 16 && n >= (1LL << 16)) { samples = 4096; lines = n / samples; tail_px = n - lines * samples; }
+    A.samples = samples;
     const long long target_px = std::min<long long>(2LL << 20, std::max<long long>(1LL << 16, n / 16));
-    long long lines_per_chunk = a->samples > 0 ? (target_px + a->samples - 1) / a->samples : a->lines;
+    long long lines_per_chunk = samples > 0 ? (target_px + samples - 1) / samples : lines;
     lines_per_chunk = (std::max<long long>(lines_per_chunk, 4) + 3) & ~3LL;  // whole 4-line tile rows
-    const long long nchunks = (a->lines + lines_per_chunk - 1) / lines_per_chunk;
-    const size_t max_px = (size_t)std::min<long long>(lines_per_chunk, a->lines) * a->samples;
+    const long long nmain = (lines + lines_per_chunk - 1) / lines_per_chunk, nchunks = nmain + (tail_px ? 1 : 0);
+    const size_t max_px = (size_t)std::max<long long>(std::min<long long>(lines_per_chunk, lines) * samples, tail_px);
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
     // staging layout of a chunk (the same offsets in the page-locked and the device buffer): inputs, then codes; list after
     const size_t o_inc = 0, o_co = o_inc + pad(max_px * es), o_cr = o_co + (a->sigma0_co ? pad(max_px * es) : 0),
@@ -995,8 +1001,9 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
         int rc = worker_reserve(w, o_end, dev_bytes, err);
         if (rc) return rc;
         const auto t1 = now();
-        const long long l0 = k * lines_per_chunk, l1 = std::min((long long)a->lines, l0 + lines_per_chunk);
-        const size_t px0 = (size_t)l0 * a->samples, npx = (size_t)(l1 - l0) * a->samples;
+        const bool is_tail = k >= nmain;  // the last pixels of a re-cut flat raster, as one short line
+        const long long l0 = is_tail ? lines : k * lines_per_chunk, l1 = is_tail ? lines + 1 : std::min(lines, l0 + lines_per_chunk);
+        const size_t px0 = (size_t)l0 * samples, npx = is_tail ? (size_t)tail_px : (size_t)(l1 - l0) * samples;
         hipError_t e = hipSuccess;
         // one raster of the chunk: host -> (page-locked staging ->) device.  The caller's staging callback may fill the staging
         // area itself; page-locked caller rasters are read by the DMA engine directly
@@ -1019,6 +1026,7 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
         KArgs B = A;
         B.lines = l1 - l0;
         B.n = (long long)npx;
+        if (is_tail) B.samples = tail_px;
         B.inc = w.dev + o_inc;
         B.s_co = a->sigma0_co ? w.dev + o_co : nullptr;
         B.s_cr = a->sigma0_cr ? w.dev + o_cr : nullptr;
