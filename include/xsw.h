@@ -175,7 +175,10 @@ int xsw_lut_upload(xsw_ctx *ctx, const xsw_lut *co, const xsw_lut *cr);
  * undecided overflows the list, which k_invert_list answers by inverting every tile itself; if the list cannot be allocated
  * the one-kernel path runs); any other LUT, and XSW_ALGO_EXACT, take the general kernel.  (Environment XSW_BAND2=1 inserts a
  * third kernel between the two, k_invert_band2: the band rule on both branches of LUT columns that rise and then fall, for
- * the pixels whose search window leaves the monotone rows; exact, tested, off by default -- it does not pay on CMOD5.N.)
+ * the pixels whose search window leaves the monotone rows; exact, tested, off by default -- it does not pay on CMOD5.N.
+ * XSW_WIDE=1 gives the same third kernel its other role: k_invert_band then keeps the search windows of <= 48 directions and
+ * hands the wider ones over to be swept in batches at lower occupancy: 1.5x on scenes whose a-priori wind is far from the
+ * sigma0 contour, 4 % slower on the benchmark scene, hence off by default too.)
  * Results do not depend on the route (environment variable XSW_NO_BAND=1 forces the general kernel: A/B measurements). */
 int xsw_invert(xsw_ctx *ctx, const xsw_invert_args *args);
 

@@ -669,6 +669,28 @@ for scale, inc_lo, inc_hi in ((1.0, 17.0, 25.0), (1.6, 20.0, 36.0), (2.5, 30.0, 
 
 
 @pytest.mark.parametrize("list_cap", [None, "300"])
+def test_wide_window_kernel(list_cap):
+    """XSW_WIDE=1 (opt-in, fresh process): k_invert_band keeps the windows of <= 48 directions and hands the wider ones to
+    k_invert_band2 in its WIDE role (batched sweeps); four scenes from friendly to far-off a-priori winds == the exhaustive sweep on
+    every pixel, and with list capacities of 300 pixels the strip-walk (only the wide pixels are searched again) and the
+    every-tile route of k_invert_list run."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, XSW_WIDE="1")
+    if list_cap:
+        env["XSW_LIST_CAP_TEST"] = list_cap
+    r = subprocess.run([sys.executable, "-c", _BAND2_SCRIPT.format(repo=REPO)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [l.split() for l in r.stdout.splitlines() if l.startswith("RESULT")]
+    assert len(rows) == 4
+    for _, scale, diff, launches, b2, _listed in rows:
+        assert int(diff) == 0, f"scale {scale}: {diff} values differ from the exhaustive sweep"
+        assert int(launches) == 1
+    assert any(int(r_[4]) > 0 for r_ in rows), "no pixel was handed to the wide kernel"
+
+
+@pytest.mark.parametrize("list_cap", [None, "300"])
 def test_band2_rise_then_fall_columns(list_cap):
     """XSW_BAND2=1 (opt-in, fresh process: read at LUT install): windows that leave the monotone rows of the LUT (high winds at
     near-range incidences, where CMOD5.N saturates and turns over; a-priori winds far above the truth) are handed to

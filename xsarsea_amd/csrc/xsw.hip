@@ -647,8 +647,14 @@ static int launch_invert(xsw_ctx *c, const KArgs &A, int algo, const LaunchCtl &
         B.list_count = lc.list;
         B.list = lc.list + 16;
         B.list_cap = (unsigned)std::min<size_t>(lc.list_cap, 0xfffffff0u);
-        // list B (k_invert_band -> k_invert_band2: windows that leave the monotone rows of a rise-then-fall slice) follows list G
-        const bool band2 = c->T.inv2 != nullptr && !A.stats;  // (the statistics instantiation keeps the two-kernel chain)
+        // list B (k_invert_band -> k_invert_band2) follows list G.  Both roles of k_invert_band2 are opt-in:
+        // XSW_WIDE=1: k_invert_band keeps the window classes of <= 48 directions and hands the wider ones over to a kernel that
+        // sweeps their rows in batches at lower occupancy (1.5x on scenes whose a-priori wind is far off, -4 % on the benchmark
+        // scene); XSW_BAND2=1: the rise-then-fall rule, k_invert_band carries every class.  The statistics instantiation keeps
+        // the two-kernel chain.
+        static const bool wide_on = getenv("XSW_WIDE") != nullptr && atoi(getenv("XSW_WIDE")) != 0;
+        const bool bitonic2 = c->T.inv2 != nullptr && !A.stats, wide2 = !bitonic2 && wide_on && !A.stats;
+        const bool band2 = bitonic2 || wide2;
         if (band2) { B.list_b_count = lc.list + 1; B.list_b = lc.list + 16 + lc.list_cap; B.list_b_cap = B.list_cap; }
         if (hipMemsetAsync(lc.list, 0, 2 * sizeof(unsigned), lc.stream) != hipSuccess) return seterr(err, XSW_EHIP, "work-list reset failed");
         const unsigned list_blocks = (unsigned)std::min<long long>(nblocks, 256 * 8);  // 8 waves per SIMD
@@ -661,6 +667,9 @@ static int launch_invert(xsw_ctx *c, const KArgs &A, int algo, const LaunchCtl &
         if (A.stats) {  // statistics instantiation (counts the scored candidates)
             if (mono) hipLaunchKernelGGL((k_invert_band<T, TO, false, true>), band_grid, band_block, 0, lc.stream, c->T, B);
             else hipLaunchKernelGGL((k_invert_band<T, TO, true, true>), band_grid, band_block, 0, lc.stream, c->T, B);
+        } else if (wide2) {
+            if (mono) hipLaunchKernelGGL((k_invert_band<T, TO, false, false, 1>), band_grid, band_block, 0, lc.stream, c->T, B);
+            else hipLaunchKernelGGL((k_invert_band<T, TO, true, false, 1>), band_grid, band_block, 0, lc.stream, c->T, B);
         } else if (mono) {
             hipLaunchKernelGGL((k_invert_band<T, TO, false, false>), band_grid, band_block, 0, lc.stream, c->T, B);
         } else {
@@ -669,8 +678,13 @@ static int launch_invert(xsw_ctx *c, const KArgs &A, int algo, const LaunchCtl &
         if (lc.timing) timing_mark(c);
         if (band2) {
             const dim3 b2_grid((unsigned)std::min<long long>(nblocks, 256 * XSW_BAND2_WAVES));  // XSW_BAND2_WAVES waves per SIMD, 4-wave workgroups
-            if (mono) hipLaunchKernelGGL((k_invert_band2<T, TO, false>), b2_grid, band_block, 0, lc.stream, c->T, B);
-            else hipLaunchKernelGGL((k_invert_band2<T, TO, true>), b2_grid, band_block, 0, lc.stream, c->T, B);
+            if (bitonic2) {
+                if (mono) hipLaunchKernelGGL((k_invert_band2<T, TO, false, true>), b2_grid, band_block, 0, lc.stream, c->T, B);
+                else hipLaunchKernelGGL((k_invert_band2<T, TO, true, true>), b2_grid, band_block, 0, lc.stream, c->T, B);
+            } else {
+                if (mono) hipLaunchKernelGGL((k_invert_band2<T, TO, false, false>), b2_grid, band_block, 0, lc.stream, c->T, B);
+                else hipLaunchKernelGGL((k_invert_band2<T, TO, true, false>), b2_grid, band_block, 0, lc.stream, c->T, B);
+            }
         }
         if (lc.timing) timing_mark(c);
         if (mono) hipLaunchKernelGGL((k_invert_list<T, TO, false>), dim3(list_blocks), dim3(256), 0, lc.stream, c->T, B);

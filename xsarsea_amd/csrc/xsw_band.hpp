@@ -64,6 +64,15 @@ namespace xsw {
 #ifndef XSW_BAND_WAVES
 #define XSW_BAND_WAVES 8
 #endif
+#ifndef XSW_BAND_NARROW_CLASSES
+#define XSW_BAND_NARROW_CLASSES 8  // k_invert_band keeps window classes 0 .. 7 (<= 48 directions); wider ones go to k_invert_band2
+#endif
+#ifndef XSW_BAND_BATCH_S
+#define XSW_BAND_BATCH_S 32  // window classes of S >= this many lanes per pixel sweep their rows in batches (co_band_pass)
+#endif
+#ifndef XSW_BAND_BATCH
+#define XSW_BAND_BATCH 4
+#endif
 #ifndef XSW_BAND_WAVES_CR
 #define XSW_BAND_WAVES_CR 7  // the dual-pol instantiation: 8 / 7 / 6 waves per SIMD measured 59.8 / 58.3 / 58.8 ms at 20000^2 (8 spills 12-20 B per lane)
 #endif
@@ -71,7 +80,7 @@ namespace xsw {
 #define XSW_BAND2_MAX 24  // k_invert_band2: rows a direction may hold before the pixel is left to the general kernel
 #endif
 #ifndef XSW_BAND2_WAVES
-#define XSW_BAND2_WAVES 5  // k_invert_band2 (two column branches per direction: more live state; at 8 waves it spills 0.5 KB per lane)
+#define XSW_BAND2_WAVES 4  // k_invert_band2 (two column branches per direction: more live state; at 8 waves it spills 0.5 KB per lane)
 #endif
 
 struct BandSlot {  // 64 bytes per pixel, read by every lane of its segment (same address: LDS broadcast)
@@ -90,7 +99,7 @@ __device__ __forceinline__ double ld_co(const char *__restrict__ base, unsigned 
 // column c < n is the RISING part of direction c (rows below the column's first decreasing step), column n + c its FALLING part
 // -- so a lane still owns one run of rows per column: only the table (L.inv2: rising and falling inverse tables side by side,
 // XSW_INV_BINS + 1 thresholds, the last one +inf) and the order of the two threshold bins differ between the two halves.
-template <int S, int K, bool COUNT, bool BITONIC>
+template <int S, int K, bool COUNT, bool BITONIC, bool BATCH = false>
 __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig, int lane,
                                              const BandSlot *slots /* this wave's [64], sorted by class */, int *res /* [64], by slot */,
                                              int first, int count /* slots [first, first + count) -> segments 0 .. count-1 */, unsigned &cand)
@@ -161,6 +170,40 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
 #pragma unroll
             for (int j = 0; j < K; ++j) nrow[j] = 0;
         }
+        if (BATCH && S >= XSW_BAND_BATCH_S) {
+            // wide windows (one or two pixels per pass: an a-priori wind far from the sigma0 contour): their runs are several rows
+            // long and the sweep is a chain of dependent load round trips -- take the rows XSW_BAND_BATCH at a time, all loads of
+            // a batch in flight before the first is scored.  (Narrow windows have 1-3 rows per direction: batching costs there.)
+#pragma unroll 1
+            for (int t0 = 0; t0 < XSW_BAND_MAX; t0 += XSW_BAND_BATCH) {
+                unsigned long long left[K], any_left = 0ULL;
+#pragma unroll
+                for (int j = 0; j < K; ++j) { left[j] = ballot64(t0 < nrow[j]); any_left |= left[j]; }
+                if (any_left == 0ULL) break;
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    if (left[j] == 0ULL) continue;
+                    double v[XSW_BAND_BATCH];
+                    int rc[XSW_BAND_BATCH];
+#pragma unroll
+                    for (int u = 0; u < XSW_BAND_BATCH; ++u) { rc[u] = min(r[j] + t0 + u, w_hi); v[u] = ld_co(base, off0[j], rc[u], rowB); }
+#pragma unroll
+                    for (int u = 0; u < XSW_BAND_BATCH; ++u) {
+                        const bool inb = t0 + u < nrow[j] && v[u] >= thr_lo && v[u] <= thr_hi;
+                        const double wh = fma((double)rc[u], whs, wh0);
+                        const double dd = fma(v[u], inv_dsig, sn);
+                        double J = fma(dd, dd, wh * (wh - U[j]));
+                        J = inb ? J : inf;
+                        second = vmin(second, vmax(J, best));
+                        const bool lt = J < best;
+                        brow = lt ? rc[u] : brow;
+                        bip = lt ? ip[j] : bip;
+                        best = vmin(best, J);
+                        if (COUNT) ncand += inb ? 1u : 0u;
+                    }
+                }
+            }
+        } else {
 #pragma unroll 1
         for (int t = 0; t < XSW_BAND_MAX; ++t) {  // scalar trip counter; the loop leaves as soon as no lane has rows left
             unsigned long long left[K], any_left = 0ULL;
@@ -184,6 +227,7 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
                 best = vmin(best, J);
                 if (COUNT) ncand += inb ? 1u : 0u;
             }
+        }
         }
         const bool any = nmax > (BITONIC ? XSW_BAND2_MAX : XSW_BAND_MAX);
         overflow = overflow || any;  // rows left after XSW_BAND_MAX trips
@@ -220,16 +264,21 @@ __device__ __forceinline__ void list_append(unsigned *__restrict__ count, unsign
 // store.  Body of k_invert_band (tiles of the raster) and k_invert_band2 (pixels of a work list, BITONIC rule).
 // COUNT = true: the statistics instantiation (xsw_stats_enable): candidates are counted per pass; its own kernel so that the
 // production kernel carries one copy of each pass (half the code).
-template <typename T, typename TO, bool CR, bool COUNT, bool BITONIC>
+// ROLE: 0 = every window class (the statistics instantiation; the rise-then-fall rule; no second kernel available);
+//       1 = the NARROW classes only, windows of more than XSW_BAND_NARROW_MAX directions are left to the second band kernel (list B);
+//       2 = every class, the wide ones sweeping their rows in batches (k_invert_band2 in its default, WIDE role).
+template <typename T, typename TO, bool CR, bool COUNT, bool BITONIC, int ROLE = 0>
 __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, long long i, bool in, int lane, BandSlot *__restrict__ slots,
-                                          int *__restrict__ res_)
+                                          int *__restrict__ res_, bool wide_only = false /* ROLE 2, strip walk: the narrow pixels are k_invert_band's */)
 {
     const double nan = __builtin_nan("");
     int flags, my_flat = -1, my_icr = -1;
     unsigned cand = 0;
     constexpr int NC = 11;  // window classes: S lanes x K directions = 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128 (and wider: chunks)
     int pos = -1, first[NC] = {}, ncls[NC] = {};  // slot of this lane's pixel; slot range of each class
-    bool to_bitonic = false;  // not eligible here only because its window leaves the monotone rows of a rise-then-fall slice
+    bool skip = false;        // ROLE 2 walking every strip (list B overflowed): not one of the wide pixels this kernel is for
+    bool to_bitonic = false;  // left to the second band kernel: its window leaves the monotone rows of a rise-then-fall slice
+                              // (XSW_BAND2=1), or -- ROLE 1 -- it is wider than the classes this kernel carries
     {
         // ---- stage 1, one pixel per lane: classify, incidence bin, upper bound along the a-priori direction, window
         Pixel P;
@@ -249,6 +298,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
             const int nrows_p = W.w_hi - W.w_lo + 1;
             ncols_p = W.ip_hi - W.ip_lo + 1;
             const bool need = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0 && !loose && ncols_p >= 1 && nrows_p >= 1;
+            if (ROLE == 2 && wide_only) skip = !need || !(W.w_hi < L.mono_rows[need ? P.i_inc : 0]);  // everything k_invert_band did not hand over
             if (BITONIC) {
                 eligb = need && L.bitonic_ok[need ? P.i_inc : 0] != 0;  // every column of the slice rises, then falls
             } else {
@@ -266,6 +316,16 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                 const int nv = BITONIC ? 2 * ncols_p : ncols_p;
                 const int p2 = 31 - __clz(max(nv, 2) - 1);  // 2^p2 < n <= 2^(p2 + 1)
                 myc = nv <= 4 ? 0 : min(2 * p2 - 3 + (nv > (3 << (p2 - 1)) ? 1 : 0), NC - 1);
+                if (ROLE == 1 && myc >= XSW_BAND_NARROW_CLASSES) {  // a wide window: the second band kernel's
+                    myc = NC;
+                    eligb = false;
+                    to_bitonic = true;
+                }
+                if (ROLE == 2 && wide_only && myc < XSW_BAND_NARROW_CLASSES) {  // k_invert_band has dealt with it (decided, or listed)
+                    myc = NC;
+                    eligb = false;
+                    skip = true;
+                }
             }
             int base = 0;
 #pragma unroll
@@ -282,7 +342,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
             // ITS part-filled last pass (their slots lie right before that class's: only the boundary moves; a narrow window in
             // a wide segment merely leaves lanes idle): one pass less each time
 #pragma unroll
-            for (int c = 0; c + 1 < NC; ++c) {
+            for (int c = 0; c + 1 < (ROLE == 1 ? XSW_BAND_NARROW_CLASSES : NC); ++c) {
                 const int np = 64 / (2 << (c >> 1)), npn = 64 / (2 << ((c + 1) >> 1));  // pixels per pass of this class / of the next
                 const int rem = ncls[c] % np;
                 const int added = (ncls[c + 1] + rem + npn - 1) / npn - (ncls[c + 1] + npn - 1) / npn;
@@ -320,7 +380,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
         auto run = [&](auto seg, auto kk, int c) {
             constexpr int S = decltype(seg)::value, K = decltype(kk)::value;
             for (int p = 0; p < ncls[c]; p += 64 / S)
-                co_band_pass<S, K, COUNT, BITONIC>(L, A.inv_dsig_co, lane, slots, res_, first[c] + p, min(64 / S, ncls[c] - p), cand);
+                co_band_pass<S, K, COUNT, BITONIC, ROLE == 2>(L, A.inv_dsig_co, lane, slots, res_, first[c] + p, min(64 / S, ncls[c] - p), cand);
         };
         using two = std::integral_constant<int, 2>;
         using three = std::integral_constant<int, 3>;
@@ -332,14 +392,20 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
         run(std::integral_constant<int, 8>{}, three{}, 5);
         run(std::integral_constant<int, 16>{}, two{}, 6);
         run(std::integral_constant<int, 16>{}, three{}, 7);
-        run(std::integral_constant<int, 32>{}, two{}, 8);
-        run(std::integral_constant<int, 32>{}, three{}, 9);
-        run(std::integral_constant<int, 64>{}, two{}, 10);
+        if (ROLE != 1) {  // (ROLE 1 carries no pass for the wide classes)
+            run(std::integral_constant<int, 32>{}, two{}, 8);
+            run(std::integral_constant<int, 32>{}, three{}, 9);
+            run(std::integral_constant<int, 64>{}, two{}, 10);
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (pos >= 0) my_flat = res_[pos];  // -1: undecided by its pass
+    if (ROLE == 2 && wide_only) {  // strip walk: lanes without a co-pol search, and the pixels k_invert_band kept, are not this kernel's
+        skip = skip || (flags & F_NEED_CO) == 0;
+        in = in && !skip;
+    }
     const bool need_co = (flags & F_NEED_CO) != 0;
     bool unresolved = in && need_co && my_flat < 0;  // not eligible, or undecided by its pass
 
@@ -391,7 +457,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
     }
 }
 
-template <typename T, typename TO, bool CR, bool COUNT>
+template <typename T, typename TO, bool CR, bool COUNT, int ROLE = 0>
 __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, CR ? XSW_BAND_WAVES_CR : XSW_BAND_WAVES) void k_invert_band(DevTables L, KArgs A)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -409,14 +475,14 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, CR ? XSW_BAND_WAVES_CR : XS
     const long long smp = col * 64 + lane;
     const bool in = smp < A.samples;
     const long long i = line * A.samples + (in ? smp : A.samples - 1);
-    band_wave<T, TO, CR, COUNT, false>(L, A, i, in, lane, slots[wv], res_[wv]);
+    band_wave<T, TO, CR, COUNT, false, ROLE>(L, A, i, in, lane, slots[wv], res_[wv]);
 }
 
 // Second kernel of the three-kernel chain: the pixels k_invert_band left on list B (their window leaves the monotone rows of a
 // slice whose columns rise and then fall: high winds at near-range incidences, where CMOD5.N saturates and turns over) with the
 // band rule applied to BOTH branches of every column.  64 listed pixels per wave (gathered rasters), fixed grid, every wave
 // strides over the list; a list that overflowed is left to k_invert_list (which then inverts every tile).
-template <typename T, typename TO, bool CR>
+template <typename T, typename TO, bool CR, bool BITONIC>
 __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND2_WAVES) void k_invert_band2(DevTables L, KArgs A)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -425,15 +491,17 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND2_WAVES) void k_inv
     const long long count = (long long)*A.list_b_count;
     const long long nwaves = (long long)gridDim.x * XSW_BAND_WG_WAVES;
     if (count > (long long)A.list_b_cap) {
-        // list B overflowed (k_invert_band kept counting but could not append): which pixels it meant is unknown, so EVERY strip
-        // of the raster goes through the rise-then-fall rule -- it holds for monotone windows as well (their falling runs are
-        // empty), and results do not depend on which kernel wrote a pixel.  Only scenes whose windows leave the monotone rows
-        // wholesale (an a-priori wind far above the truth) come here.
+        // list B overflowed (k_invert_band kept counting but could not append): which pixels it meant is unknown, so this kernel
+        // walks EVERY strip of the raster.  Rise-then-fall role: every pixel goes through the rule (it holds for monotone windows
+        // as well: their falling runs are empty; results do not depend on which kernel wrote a pixel).  Wide role: stage 1 is
+        // redone for every pixel and only the wide windows -- what k_invert_band did not keep -- are searched.
+        // (strips in linear order, one per wave: measured 2x faster for this kernel than k_invert_band's XCD-aware tile walk as a
+        // grid-stride loop -- the heavy pixels of a scene cluster, and the linear order spreads them over all the waves)
         const long long strips_per_line = (A.samples + 63) >> 6, nstrips = strips_per_line * A.lines;
         for (long long c = (long long)blockIdx.x * XSW_BAND_WG_WAVES + wv; c < nstrips; c += nwaves) {  // wave-uniform
             const long long line = c / strips_per_line, smp = (c - line * strips_per_line) * 64 + lane;
             const bool in = smp < A.samples;
-            band_wave<T, TO, CR, false, true>(L, A, line * A.samples + (in ? smp : A.samples - 1), in, lane, slots[wv], res_[wv]);
+            band_wave<T, TO, CR, false, BITONIC, BITONIC ? 0 : 2>(L, A, line * A.samples + (in ? smp : A.samples - 1), in, lane, slots[wv], res_[wv], !BITONIC);
             __builtin_amdgcn_wave_barrier();
         }
         return;
@@ -442,7 +510,7 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND2_WAVES) void k_inv
         const long long k = c * 64 + lane;
         const bool in = k < count;
         const long long i = (long long)A.list_b[in ? k : count - 1];
-        band_wave<T, TO, CR, false, true>(L, A, i, in, lane, slots[wv], res_[wv]);
+        band_wave<T, TO, CR, false, BITONIC, BITONIC ? 0 : 2>(L, A, i, in, lane, slots[wv], res_[wv]);
         __builtin_amdgcn_wave_barrier();
     }
 }
