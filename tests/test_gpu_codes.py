@@ -288,6 +288,11 @@ def test_flat_raster_is_recut_into_tiles(gpu_ctx, default_luts):
     inc, s_vv, s_vh, dsig, anc = (a.reshape(-1)[:200_003] for a in synthetic_scene(300, 700, np.float32, 29))  # 48 lines of 4096 + 3395
     ref = _device_run(gpu_ctx, torch, _lib, tuple(a.reshape(1, -1) for a in (inc, s_vv, s_vh, dsig, anc)), np.complex128, {"complex", "codes"},
                       dual_select=True)
+    # (the device-raster path re-cuts the one-line raster too: compare with 49 separately inverted lines of 4096)
+    lines49 = tuple(np.pad(a, (0, 49 * 4096 - a.size), constant_values=np.nan).reshape(49, 4096) for a in (inc, s_vv, s_vh, dsig, anc))
+    sep = _device_run(gpu_ctx, torch, _lib, lines49, np.complex128, {"complex"}, dual_select=True)
+    assert np.array_equal(_bits(sep["co"].cpu().numpy().reshape(-1)[:inc.size]), _bits(ref["co"].cpu().numpy().reshape(-1)))
+    assert np.array_equal(_bits(sep["cr"].cpu().numpy().reshape(-1)[:inc.size]), _bits(ref["cr"].cpu().numpy().reshape(-1)))
     g = gpu_ctx.invert_host(inc, sigma0_co=s_vv, sigma0_cr=s_vh, dsig_cr=dsig, anc=anc, dual_select=True, want_idx=True, want_codes=True,
                             algo="pruned")
     assert g[0].shape == inc.shape

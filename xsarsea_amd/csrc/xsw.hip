@@ -972,7 +972,31 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
         if (algo == XSW_ALGO_PRUNED) ensure_list(c, n);
         std::string err;
         const LaunchCtl lc{c->stream, c->d_list, c->list_cap, c->timing_on};
-        const int rc = dispatch_invert(c, A, a->dtype, a->out_dtype, algo, lc, err);
+        int rc;
+        if (a->lines < 16 && n >= (1LL << 16)) {
+            // a flat raster (a long vector of pixels: 1-D inputs arrive as one line) is re-cut into lines of 4096 samples + a
+            // tail, as on the host path: the core dimension is only a loop (windspeed.py:190), and a one-line raster would leave
+            // three of a workgroup's four waves idle
+            const size_t es = a->dtype == XSW_F32 ? 4 : 8, os = a->out_dtype == XSW_F32 ? 8 : 16;
+            const long long S = 4096, Lv = n / S, tail = n - Lv * S;
+            auto shift = [](const void *p, size_t bytes) -> const void * { return p ? (const char *)p + bytes : nullptr; };
+            KArgs M = A;
+            M.lines = Lv; M.samples = S; M.n = Lv * S;
+            rc = dispatch_invert(c, M, a->dtype, a->out_dtype, algo, lc, err);
+            if (!rc && tail) {
+                const size_t px = (size_t)(Lv * S);
+                KArgs Tl = A;
+                Tl.lines = 1; Tl.samples = tail; Tl.n = tail;
+                Tl.inc = shift(A.inc, px * es); Tl.s_co = shift(A.s_co, px * es); Tl.s_cr = shift(A.s_cr, px * es);
+                Tl.dsig_cr = shift(A.dsig_cr, px * es); Tl.anc = shift(A.anc, px * es * 2);
+                Tl.out_co = (void *)shift(A.out_co, px * os); Tl.out_cr = (void *)shift(A.out_cr, px * os);
+                Tl.out_idx = (int *)shift(A.out_idx, px * 12);
+                Tl.code_co = (unsigned *)shift(A.code_co, px * 4); Tl.code_cr = (unsigned *)shift(A.code_cr, px * 4);
+                rc = dispatch_invert(c, Tl, a->dtype, a->out_dtype, algo, lc, err);  // same stream, same work list: in order
+            }
+        } else {
+            rc = dispatch_invert(c, A, a->dtype, a->out_dtype, algo, lc, err);
+        }
         return rc ? fail(c, rc, "%s", err.c_str()) : XSW_OK;
     }
 
