@@ -341,6 +341,31 @@ class Context:
         """Thin call of xsw_expand_codes (pointers are ints or None): grid codes -> the complex winds xsw_invert stores."""
         self._check(self._lib.xsw_expand_codes(self._h, int(n), mem, out_dtype, code_co, code_cr, out_co, out_cr), "xsw_expand_codes")
 
+    def expand_codes_host(self, codes_co, codes_cr, out_dtype=np.complex128):
+        """Grid codes (uint32 arrays of one shape; either may be None) -> (ws_co, ws_cr) on the host, block-wise on the host
+        thread pool (xsw_expand_codes with XSW_MEM_HOST reads the context's host tables only: the blocks run side by side; the
+        context's lock is held for the whole expansion so that no LUT is installed meanwhile)."""
+        ref = codes_co if codes_co is not None else codes_cr
+        shape, n = ref.shape, ref.size
+        od = XSW_F32 if np.dtype(out_dtype) == np.complex64 else XSW_F64
+        cc = None if codes_co is None else np.ascontiguousarray(codes_co, dtype=np.uint32).reshape(-1)
+        cr = None if codes_cr is None else np.ascontiguousarray(codes_cr, dtype=np.uint32).reshape(-1)
+        o_co = None if cc is None else np.empty(n, out_dtype)
+        o_cr = None if cr is None else np.empty(n, out_dtype)
+        item = np.dtype(out_dtype).itemsize
+        at = lambda a, i, size: None if a is None else ctypes.c_void_p(a.ctypes.data + i * size)
+
+        def work(i):
+            m = min(_host.BLOCK, n - i)
+            rc = self._lib.xsw_expand_codes(self._h, m, MEM_HOST, od, at(cc, i, 4), at(cr, i, 4), at(o_co, i, item), at(o_cr, i, item))
+            if rc != 0:
+                raise XswError(f"xsw_expand_codes failed ({rc}): {self._lib.xsw_last_error(self._h).decode()}")
+
+        with self.lock:
+            if n:
+                list(_host.pool().map(work, range(0, n, _host.BLOCK)))
+        return (None if o_co is None else o_co.reshape(shape)), (None if o_cr is None else o_cr.reshape(shape))
+
     @_locked
     def set_host_threads(self, n):
         """Worker threads of the host-memory paths (0 = default: XSW_HOST_THREADS or 12)."""
@@ -369,11 +394,12 @@ class Context:
     @_locked
     def invert_host(self, inc, sigma0_co=None, sigma0_cr=None, dsig_cr=None, anc=None, dsig_co=0.1,
                     sigma0_is_db=False, algo="auto", dual_select=False, out_dtype=np.complex128, want_idx=False, want_codes=False,
-                    pinned=False, out_co=None, out_cr=None, stage=None):
+                    pinned=False, out_co=None, out_cr=None, stage=None, want_complex=True):
         """numpy-in / numpy-out wrapper of xsw_invert for host rasters of one dtype (float32 or float64).
         want_codes: also return the uint32 grid codes (co, cr) as a 4th element.  pinned: the rasters are page-locked
         (`pinned_empty`): XSW_MEM_HOST_PINNED.  out_co / out_cr: C-contiguous arrays of the broadcast shape and `out_dtype` to
-        write into (row tiles of one raster inverted by several contexts land in place).  stage: see `invert_raw`."""
+        write into (row tiles of one raster inverted by several contexts land in place).  stage: see `invert_raw`.
+        want_complex=False (with want_codes): only the grid codes are produced (nothing is expanded on the host)."""
         inc = np.asarray(inc)
         dt = inc.dtype
         if dt not in (np.float32, np.float64):
@@ -406,9 +432,9 @@ class Context:
         for o in (out_co, out_cr):
             if o is not None and (o.shape != tuple(shape) or o.dtype != out_dtype or not o.flags.c_contiguous):
                 raise ValueError("out_co / out_cr must be C-contiguous arrays of the broadcast shape and out_dtype")
-        if s_co is not None and out_co is None:
+        if s_co is not None and out_co is None and want_complex:
             out_co = np.empty(shape, out_dtype)
-        if s_cr is not None and out_cr is None:
+        if s_cr is not None and out_cr is None and want_complex:
             out_cr = np.empty(shape, out_dtype)
         if s_co is None:
             out_co = None

@@ -162,6 +162,7 @@ def invert_from_model_tiled(inc, sigma0, sigma0_dual=None, /, *, dst=0, group=No
         if default_invert:
             # the per-tile call skips the per-call ancillary assertion / warning (`_xsw_tile`): the whole-raster answer is passed in
             kw["_xsw_tile"] = any_valid_ancillary
+            kw["_xsw_codes"] = True  # numpy rasters: the tile's answer as 4-byte grid codes (a quarter of the complex128 bytes)
         res = invert(cut(inc), cut(sigma0), *(() if sigma0_dual is None else (cut(sigma0_dual),)), **kw)
     except BaseException as exc:  # reported to every rank below, then re-raised here
         failure = exc
@@ -171,6 +172,17 @@ def invert_from_model_tiled(inc, sigma0, sigma0_dual=None, /, *, dst=0, group=No
         raise failure
     if flag.item():
         raise RuntimeError("invert_from_model_tiled: the inversion failed on another rank (see its traceback); nothing was gathered")
+    from .windspeed.windspeed import CodedWinds
+    if isinstance(res, CodedWinds):  # gather the codes, expand and apply the return conventions on `dst`
+        gathered = []
+        for codes in (res.codes_co, res.codes_cr):
+            if codes is None:
+                gathered.append(None)
+                continue
+            t = torch.from_numpy(np.ascontiguousarray(codes).view(np.int32)).to(dev)
+            full = gather_rows(t, lines, dst=dst, group=group)
+            gathered.append(full.cpu().numpy().view(np.uint32) if rank == dst else None)
+        return res.finish(*gathered) if rank == dst else None
     parts = res if isinstance(res, tuple) else (res,)
     outs = []
     for p in parts:

@@ -194,9 +194,10 @@ def tile_rows(lines, parts):
     return [(k * base, lines if k == parts - 1 else (k + 1) * base) for k in range(parts)]
 
 
-def invert_numpy(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_co=0.1):
+def invert_numpy(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_co=0.1, codes=False):
     """(ws_co, ws_cr) complex128 for numpy rasters (None for a search that was not requested); any of
-    sigma0_co / sigma0_cr / anc may be None.
+    sigma0_co / sigma0_cr / anc may be None.  codes=True: the uint32 grid codes instead (include/xsw.h: out_code_*; what
+    `multi_gpu.invert_from_model_tiled` gathers -- 4 instead of 16 bytes per pixel -- and `expand_codes` turns into the winds).
 
     Raster dtypes follow the reference: the dB conversion runs in each sigma0's own dtype, then
     everything is handled as float64/complex128 (the gufunc signature, windspeed.py:308-318).  When
@@ -282,16 +283,18 @@ def invert_numpy(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_c
             ensure_luts(ctx, lut_co if want_co else None, lut_cr if want_cr else None)
             if options.host_threads:
                 ctx.set_host_threads(options.host_threads)
-            return ctx.invert_host(sl(full["inc"]), sigma0_co=None if not want_co else sl(full["sigma0_co"]),
+            res = ctx.invert_host(sl(full["inc"]), sigma0_co=None if not want_co else sl(full["sigma0_co"]),
                                    sigma0_cr=None if not want_cr else sl(full["sigma0_cr"]),
                                    dsig_cr=full["dsig_cr"] if (full["dsig_cr"] is None or np.isscalar(full["dsig_cr"])) else sl(full["dsig_cr"]),
                                    anc=None if full["anc"] is None else sl(full["anc"]), dsig_co=dsig_co, sigma0_is_db=is_db,
                                    algo=options.algo, out_dtype=np.complex128, out_co=None if out_co is None else sl(out_co),
-                                   out_cr=None if out_cr is None else sl(out_cr), stage=stage_for(rows))
+                                   out_cr=None if out_cr is None else sl(out_cr), stage=stage_for(rows), want_codes=codes,
+                                   want_complex=not codes)
+            return (res[3][0], res[3][1], None) if codes else res
 
     devs = _device_list()
     n = int(np.prod(shape, dtype=np.int64)) if len(shape) else 1
-    if devs is None or len(shape) < 2 or n < options.devices_min_pixels or shape[0] < 4 * len(devs):
+    if codes or devs is None or len(shape) < 2 or n < options.devices_min_pixels or shape[0] < 4 * len(devs):
         out_co, out_cr, _ = run(_lib.default_context(options.device), None, None, None)
         return out_co, out_cr  # None where that search did not run (the caller never reads it)
     # several GPUs: contiguous row tiles of the leading axis, one host thread and one context per GPU, results in place
@@ -306,6 +309,14 @@ def invert_numpy(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_c
         for f in futs:
             f.result()  # re-raises a tile's error here
     return out_co, out_cr
+
+
+def expand_codes(lut_co, lut_cr, codes_co, codes_cr):
+    """Grid codes -> (ws_co, ws_cr) complex128 on the host, from the tables of these LUTs (installed on the context if they are not)."""
+    ctx = _lib.default_context(options.device)
+    with ctx.lock:
+        ensure_luts(ctx, lut_co if codes_co is not None else None, lut_cr if codes_cr is not None else None)
+        return ctx.expand_codes_host(codes_co, codes_cr)
 
 
 def invert_device(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_co=0.1, dual_select=False):

@@ -50,6 +50,25 @@ def _is_dask(v):
     return da is not None and isinstance(data, da.Array)
 
 
+class CodedWinds:
+    """The answer of an inversion of numpy rasters as 4-byte grid codes (include/xsw.h: out_code_*) + what turns them into the
+    return value of `invert_from_model`: `finish()` expands them on the host (bit-identical to the direct call) and applies the
+    return conventions of windspeed.py:415-439.  What `multi_gpu.invert_from_model_tiled` sends between ranks."""
+
+    def __init__(self, mode, lut_co, lut_cr, codes_co, codes_cr):
+        self.mode, self.lut_co, self.lut_cr, self.codes_co, self.codes_cr = mode, lut_co, lut_cr, codes_co, codes_cr
+
+    def finish(self, codes_co=None, codes_cr=None):
+        cc = self.codes_co if codes_co is None else codes_co
+        cr = self.codes_cr if codes_cr is None else codes_cr
+        ws_co, ws_cr = _engine.expand_codes(self.lut_co, self.lut_cr, cc, cr)
+        if self.mode == "mono_co":
+            return ws_co
+        if self.mode == "mono_cr":
+            return _engine.abs_blocks(ws_cr)
+        return ws_co, _engine.dual_select(ws_co, ws_cr)
+
+
 def invert_from_model(inc, sigma0, sigma0_dual=None, /, ancillary_wind=None, dsig_co=0.1, dsig_cr=0.1, model=None,
                       **kwargs):
     """
@@ -81,6 +100,7 @@ def invert_from_model(inc, sigma0, sigma0_dual=None, /, ancillary_wind=None, dsi
     # private: set by multi_gpu.invert_from_model_tiled, whose per-rank call sees one row tile of the raster -- the ancillary-wind
     # precondition is a whole-raster property (windspeed.py:107, :112) and arrives as the all-reduced answer
     tile_any_valid = kwargs.pop("_xsw_tile", None)
+    want_codes = kwargs.pop("_xsw_codes", False)  # private (multi_gpu): numpy rasters -> `CodedWinds` instead of the winds
     models = model if isinstance(model, tuple) else (model, None)
     models = tuple(get_model(m) if m is not None else None for m in models)
     no_ancillary = ancillary_wind is None  # the reference substitutes an all-NaN array (sigma0 * nan, :71-86)
@@ -123,8 +143,8 @@ def invert_from_model(inc, sigma0, sigma0_dual=None, /, ancillary_wind=None, dsi
             return ws_co if models[0] is not None else ws_cr.abs()
         return ws_co, ws_cr
 
-    def _numpy(np_inc, np_co, np_cr, np_dsig, np_anc):
-        return _engine.invert_numpy(lut_co, lut_cr, np_inc, np_co, np_cr, np_dsig, np_anc, dsig_co=dsig_co)
+    def _numpy(np_inc, np_co, np_cr, np_dsig, np_anc, codes=False):
+        return _engine.invert_numpy(lut_co, lut_cr, np_inc, np_co, np_cr, np_dsig, np_anc, dsig_co=dsig_co, codes=codes)
 
     # cross-pol search disabled for every pixel when all cross sigma0 are NaN (:170) is implicit: NaN pixels skip it
     template = next((v for v in (sigma0, inc, sigma0_dual, ancillary_wind) if _is_xr(v)), None)
@@ -153,7 +173,11 @@ def invert_from_model(inc, sigma0, sigma0_dual=None, /, ancillary_wind=None, dsi
         if sigma0_cr is None:
             ws_cr = None
     else:
-        ws_co, ws_cr = _numpy(*[None if v is None else (v if np.isscalar(v) else np.asarray(v)) for v in args])
+        np_args = [None if v is None else (v if np.isscalar(v) else np.asarray(v)) for v in args]
+        if want_codes and template is None:
+            mode = "dual" if sigma0_dual is not None else ("mono_co" if models[0] is not None else "mono_cr")
+            return CodedWinds(mode, lut_co, lut_cr, *_numpy(*np_args, codes=True))
+        ws_co, ws_cr = _numpy(*np_args)
 
     if template is not None:
         def wrap(values):
