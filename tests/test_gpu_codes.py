@@ -299,3 +299,42 @@ def test_flat_raster_is_recut_into_tiles(gpu_ctx, default_luts):
     assert np.array_equal(_bits(g[0]), _bits(ref["co"].cpu().numpy().reshape(-1)))
     assert np.array_equal(_bits(g[1]), _bits(ref["cr"].cpu().numpy().reshape(-1)))
     assert np.array_equal(g[3][0], ref["cc"].cpu().numpy().reshape(-1).view(np.uint32))
+
+
+def test_staging_callback_contract(gpu_ctx, default_luts):
+    """xsw_invert_args.stage: a callback that fills a piece is used instead of the raster pointer (the raster passed for sigma0 is
+    never read); returning 0 leaves the default copy in place; an exception inside the callback aborts the call, crosses no C
+    frame and is re-raised to the caller -- and the context stays usable."""
+    import ctypes
+    lco, _ = default_luts
+    co, _ = lut_dicts(lco, None)
+    gpu_ctx.upload_luts(co=co)
+    inc, s_vv, _, _, anc = synthetic_scene(300, 700, np.float32, 37)
+    ref = gpu_ctx.invert_host(inc, sigma0_co=s_vv, anc=anc, out_dtype=np.complex64, algo="pruned")
+    calls = []
+    flat = s_vv.reshape(-1)
+
+    def stage(which, px0, npx, dst):
+        calls.append((which, px0, npx))
+        if which != 1:
+            return 0  # incidence and ancillary wind: the library's own copy
+        out = np.frombuffer((ctypes.c_char * (npx * 4)).from_address(dst), dtype=np.float32)
+        out[...] = flat[px0:px0 + npx]
+        return 1
+
+    junk = np.full_like(s_vv, 123.0)  # must not be read
+    got = gpu_ctx.invert_host(inc, sigma0_co=junk, anc=anc, out_dtype=np.complex64, algo="pruned", stage=stage)
+    assert np.array_equal(_bits(got[0]), _bits(ref[0]))
+    assert {c[0] for c in calls} == {0, 1, 4} and sum(c[2] for c in calls if c[0] == 1) == inc.size
+
+    def boom(which, px0, npx, dst):
+        raise ZeroDivisionError("in the staging callback")
+
+    with pytest.raises(ZeroDivisionError, match="staging callback"):
+        gpu_ctx.invert_host(inc, sigma0_co=s_vv, anc=anc, out_dtype=np.complex64, stage=boom)
+    again = gpu_ctx.invert_host(inc, sigma0_co=s_vv, anc=anc, out_dtype=np.complex64, algo="pruned")
+    assert np.array_equal(_bits(again[0]), _bits(ref[0]))
+    # page-locked memory of another context / a foreign pointer is refused by xsw_host_free
+    from xsarsea_amd import _lib
+    with pytest.raises(_lib.XswError, match="not a pointer of xsw_host_alloc"):
+        gpu_ctx._check(gpu_ctx._lib.xsw_host_free(gpu_ctx._h, ctypes.c_void_p(got[0].ctypes.data)), "xsw_host_free")
