@@ -35,17 +35,19 @@ def search_window(mag, theta_deg, j_ub, w0, inv_wstep, n_w, phi0, phi_last, inv_
     |c - m|^2/4 <= j_ub (uniform axes).  Float64; MRG index units of slack cover the 1e-6-of-a-step
     axis tolerance, the 1e-12 trig tables and the arithmetic.  theta_deg is the direction of m
     normalised into [phi0, phi0 + 360)."""
-    MRG = 1e-5
+    # (round 3: the device forms mag, sqrt(j_ub), asin and theta with float32 library calls -- stage 1 is VALU-bound -- and
+    # covers their error by wider margins; a window may only ever grow.  The same margins here.)
+    MRG = 2e-3
     j_ub = j_ub * (1.0 + 1e-9) + 1e-9
-    R = 2.0 * np.sqrt(j_ub) * (1.0 + 1e-9) + 1e-9
+    R = 2.0 * np.sqrt(j_ub) * (1.0 + 1e-6) + 1e-6
     if not (mag < 1e6 and R < 1e6):
         return 0, n_w - 1, 0, n_phi - 1
     xl, xh = (mag - R - w0) * inv_wstep, (mag + R - w0) * inv_wstep
     w_lo = int(max(np.ceil(np.clip(xl - MRG - 1e-9 * abs(xl), -4.0, n_w + 4.0)), 0))
     w_hi = int(min(np.floor(np.clip(xh + MRG + 1e-9 * abs(xh), -4.0, n_w + 4.0)), n_w - 1))
-    if not (R < mag * (1.0 - 1e-9)):
-        return w_lo, w_hi, 0, n_phi - 1  # the disc contains the origin: every direction
-    half = np.degrees(np.arcsin(R / mag)) + 1e-7
+    if not (R < mag * 0.999):
+        return w_lo, w_hi, 0, n_phi - 1  # the disc contains the origin (or nearly: no arcsine above 0.999): every direction
+    half = np.degrees(np.arcsin(R / mag)) + 2e-4
     yl, yh = (theta_deg - half - phi0) * inv_dphi, (theta_deg + half - phi0) * inv_dphi
     yl, yh = yl - MRG - 1e-9 * abs(yl), yh + MRG + 1e-9 * abs(yh)
     plo = np.ceil(np.clip(yl, -4.0, n_phi + 4.0))
@@ -134,7 +136,7 @@ def mono_rows(slice_wp):
 
 def band_radius(j_ub, dsig):
     """d such that every candidate with ((L - s)/dsig)^2 <= j_ub has |L - s| <= d (inflated: rounding never excludes one)."""
-    return abs(dsig) * np.sqrt(j_ub) * (1.0 + 1e-9) + 1e-12
+    return abs(dsig) * np.sqrt(j_ub) * (1.0 + 1e-6) + 1e-9
 
 
 def band_pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig, max_len=16):

@@ -368,7 +368,11 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                 b.inc_bin = P.i_inc | (bin << 16); b.rows = W.w_lo | (W.w_hi << 16); b.ipn = W.ip_lo | (ncols_p << 16);
                 b.bin_hi = bhi < XSW_INV_BINS ? bhi : (BITONIC ? XSW_INV_BINS /* the tabulated +inf threshold */ : -1);
                 slots[pos] = b;
+#ifdef XSW_TIMING_STAGE1_ONLY
+                res_[pos] = 0;   // (timing build: pretend the pass decided, so that nothing floods the work list)
+#else
                 res_[pos] = -1;
+#endif
             }
         }
     }
@@ -376,6 +380,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- stage 2: band passes, narrowest windows first (most pixels per pass)
+#ifndef XSW_TIMING_STAGE1_ONLY  // (timing / counter builds only: results are invalid without the passes)
     {
         auto run = [&](auto seg, auto kk, int c) {
             constexpr int S = decltype(seg)::value, K = decltype(kk)::value;
@@ -398,6 +403,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
             run(std::integral_constant<int, 64>{}, two{}, 10);
         }
     }
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -394,15 +394,30 @@ __device__ __forceinline__ CoWindow box_from_jub(const DevTables &L, double mag,
     CoWindow W;
     W.w_lo = 0; W.w_hi = L.n_w - 1; W.ip_lo = 0; W.ip_hi = L.n_phi - 1;
     W.geom = 0; W.mdiv = 0; W.band_d = 0.0;
+#ifndef XSW_GEOM_F64
+    // window geometry from float32 square root / arcsine / arctangent (a few instructions each instead of the ~20 / 70 / 90 of
+    // their float64 library forms: stage 1 is VALU-bound, profiles/r03_stage1_counters.json), with the margins widened to cover
+    // them -- a window may only ever grow: 2e-3 index units (mag from a float32 square root: 6e-8 relative of <= 80 m/s is
+    // 5e-5 index units; theta from atan2f: ~2e-5 deg), R inflated by 1e-6, the half angle by 2e-4 deg, and no arcsine above
+    // R / |m| = 0.999 (all directions instead: the arcsine's slope there would magnify the ratio's rounding)
+    const double MRG = 2e-3;
+    const double R = 2.0 * (double)__builtin_sqrtf((float)jub) * (1.0 + 1e-6) + 1e-6;
+#else
     const double MRG = 1e-5;
     const double R = 2.0 * sqrt(jub) * (1.0 + 1e-9) + 1e-9;
+#endif
     if (mag < 1e6 && R < 1e6) {
         const double nw = (double)L.n_w, np_ = (double)L.n_phi;
         const double xl = (mag - R - L.w0) * L.inv_wstep, xh = (mag + R - L.w0) * L.inv_wstep;
         W.w_lo = max((int)ceil(fmin(fmax(xl - MRG - 1e-9 * fabs(xl), -4.0), nw + 4.0)), 0);
         W.w_hi = min((int)floor(fmin(fmax(xh + MRG + 1e-9 * fabs(xh), -4.0), nw + 4.0)), L.n_w - 1);
+#ifndef XSW_GEOM_F64
+        if (R < mag * 0.999) {
+            const double half = (double)asinf((float)(R / mag)) * 57.29577951308232 + 2e-4;
+#else
         if (R < mag * (1.0 - 1e-9)) {
             const double half = asin(R / mag) * 57.29577951308232 + 1e-7;
+#endif
             double yl = (theta - half - L.phi0) * L.inv_dphi, yh = (theta + half - L.phi0) * L.inv_dphi;
             yl -= MRG + 1e-9 * fabs(yl);
             yh += MRG + 1e-9 * fabs(yh);
@@ -480,7 +495,11 @@ __device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pi
     CoWindow W = box_from_jub(L, mag, theta, jub);
     // the sigma0 term alone is >= 0 as well: ((LUT - s)/dsig)^2 <= J_ub is necessary, i.e. |LUT - s| <= |dsig| sqrt(J_ub)
     // (inflated: a candidate outside scores > J_ub (1 + 1e-9), above the exact score of the ray's best candidate)
+#ifndef XSW_GEOM_F64
+    W.band_d = (double)__builtin_sqrtf((float)jub) * (1.0 + 1e-6) * abs_dsig + 1e-9;
+#else
     W.band_d = sqrt(jub) * (1.0 + 1e-9) * abs_dsig + 1e-12;  // abs_dsig = |dsig_co| = 1 / |inv_dsig| to an ulp, far inside the inflation
+#endif
     return W;
 }
 
@@ -1010,8 +1029,13 @@ __device__ __forceinline__ void load_pixel(const DevTables &L, const KArgs &A, l
     }
     P.b_eff = L.phi_180 ? fabs(P.a_im) : P.a_im;  // windspeed.py:218-219
     // search-window geometry of the branch-and-bound kernel, one pixel per lane (64 at a time)
+#ifndef XSW_GEOM_F64
+    P.mag = (double)__builtin_sqrtf((float)(P.a_re * P.a_re + P.b_eff * P.b_eff));
+    double th = (double)atan2f((float)P.b_eff, (float)P.a_re) * 57.295779513082320877;
+#else
     P.mag = sqrt(P.a_re * P.a_re + P.b_eff * P.b_eff);
     double th = atan2(P.b_eff, P.a_re) * 57.295779513082320877;
+#endif
     if (th < L.phi0) th += 360.0;
     P.theta = th;
     P.ipr = (P.flags & F_CO_FINITE)
