@@ -459,11 +459,11 @@ def nesz_figures(args, ctx, stream, noise, inc, lines, samples):
     del out
     px = lines * samples
     achieved = 20.0 * px / dt / 1e9
-    return {"workload": f"nesz_flattening, {lines}x{samples} float32 noise + incidence -> float64 (k_nesz_colsum + k_nesz_colmean + k_nesz_center + k_nesz_rows)",
+    return {"workload": f"nesz_flattening, {lines}x{samples} float32 noise + incidence -> float64 (k_nesz_colsum + k_nesz_colmean + k_nesz_center + k_nesz_fit + k_nesz_eval)",
             "value": round(px / dt / 1e6, 1), "unit": "Mpixels/s", "ms_per_call": round(dt * 1e3, 3), "bytes_per_pixel": 20,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "note": "HIP events on the launch stream around the call's four launches (asynchronous, context-owned scratch)"}}
+                         "note": "HIP events on the launch stream around the call's five launches (asynchronous, context-owned scratch)"}}
 
 
 # ------------------------------------------------------------------------------------------ rank launcher
@@ -811,7 +811,13 @@ def main():
         bytes_px = (BYTES_READ_PX + BYTES_WRITE_PX) if mode == "mono" else (24 + 16)  # dual: +vh, +dsig; 2 outputs
         if coded:  # N > 1: the kernels write 4-byte codes instead of complex64
             bytes_px = (BYTES_READ_PX + 4) if mode == "mono" else (24 + 8)
-        achieved = bytes_px * lines * samples / (kernel_ms * 1e-3) / 1e9  # rank 0's tile / rank 0's kernel time
+        # the dominant kernel reads every pixel's inputs and writes the pixels it decides itself (the ones it hands to
+        # k_invert_band2 / k_invert_list are written there); the chain as a whole moves bytes_px per pixel
+        read_px = BYTES_READ_PX if mode == "mono" else 24
+        handed = (tm.get("last_band2_pixels", 0) + tm.get("last_list_pixels", 0)) if second_ms is not None else 0
+        achieved = (read_px * lines * samples + (bytes_px - read_px) * (lines * samples - handed)) / (kernel_ms * 1e-3) / 1e9  # rank 0's tile / rank 0's kernel time
+        chain_ms = kernel_ms + (second_ms or 0.0)
+        chain_ms_max = kernel_ms_max + (second_ms or 0.0)
         is_metric_shape = (mode == "mono" and args.resolution == "high" and cfg["lut"] == "cmod5n" and args.algo == "pruned"
                            and (lines, samples) == (20000, 20000))
         traffic, traffic_prov = None, None
@@ -821,7 +827,7 @@ def main():
                 traffic = int(tj["k_invert_20000x20000"]["hbm_bytes_per_launch"])
         cand_full = int(lut.shape[1] * lut.shape[2])
         evaluated = stats["cand_co"] / max(stats["pixels_co"], 1)
-        lane_ops = OPS_PER_CANDIDATE * stats["cand_co"] / world / (kernel_ms_max * 1e-3) if args.algo == "pruned" else \
+        lane_ops = OPS_PER_CANDIDATE * stats["cand_co"] / world / (chain_ms_max * 1e-3) if args.algo == "pruned" else \
             OPS_PER_CANDIDATE * cand_full * lines * samples / (kernel_ms * 1e-3)
         valu = {"bound": "valu", "unit": "lane-ops/s", "peak": LANE_OPS_PEAK,
                 "ops_per_candidate": OPS_PER_CANDIDATE,
@@ -829,7 +835,7 @@ def main():
                 "evaluated_candidates_per_pixel": round(evaluated, 1),
                 "pixels_exact_fallback": stats["pixels_exact"],
                 "achieved": float(f"{lane_ops:.4g}"), "frac": round(lane_ops / LANE_OPS_PEAK, 5),
-                "note": "useful work only: 6 lane-ops x candidates actually scored / kernel time / (256 CU x 128 lanes x 2.4 GHz); "
+                "note": "useful work only: 6 lane-ops x candidates scored (statistics pass, every window swept in k_invert_band) / the chain's kernel time / (256 CU x 128 lanes x 2.4 GHz); "
                         "the grid has candidates_per_pixel_full_grid points, all but the evaluated ones are excluded by an exact bound"}
         sq, sq_prov = (fresh_profile(f"{PROFILE_ROUND}_pmc_counters_summary.json") if is_metric_shape else (None, None))
         sq = (sq or {}).get("k_invert_band")
@@ -877,10 +883,16 @@ def main():
                          "second_kernel": None if second_ms is None else dict(
                              {"kernel": "k_invert_list", "kernel_ms": round(second_ms, 3), "pixels_last_launch": tm.get("last_list_pixels")},
                              **({"kernel": "k_invert_band2 + k_invert_list", "k_invert_band2_ms": round(tm.get("band2_kernel_ms", 0.0) / args.steps, 3),
-                                 "pixels_to_band2_last_launch": tm.get("last_band2_pixels")} if os.environ.get("XSW_BAND2", "0") not in ("", "0") else {})),
+                                 "k_invert_list_ms": round(tm["second_kernel_ms"] / args.steps, 3),
+                                 "pixels_to_band2_last_launch": tm.get("last_band2_pixels")} if tm.get("band2_kernel_ms", 0.0) > 0.0 else {})),
+                         "chain": {"kernels": "k_invert_band + k_invert_band2 + k_invert_list" if second_ms is not None else "k_invert",
+                                   "ms": round(chain_ms, 3), "achieved": round(bytes_px * lines * samples / (chain_ms * 1e-3) / 1e9, 3),
+                                   "frac": round(bytes_px * lines * samples / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
                          "step_kernels_ms": round(step_kernels_ms, 3),
-                         "note": f"algorithmic raster bytes ({bytes_px} B read+written per pixel x rank 0's {lines * samples} px) / mean "
+                         "note": f"algorithmic raster bytes ({read_px} B read per pixel x rank 0's {lines * samples} px + {bytes_px - read_px} B written per "
+                                 "pixel the kernel decides itself, i.e. not handed to k_invert_band2 / k_invert_list) / mean "
                                  "duration of the dominant kernel per step (HIP events on the launch stream, recorded by the library around each kernel); "
+                                 "chain: all bytes of the step / the three kernels' time; "
                                  "the search itself is bound by VALU issue and the texture-address path, not by HBM: see valu",
                          "valu": valu},
             "lut": timings,

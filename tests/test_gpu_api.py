@@ -243,6 +243,15 @@ def test_nesz_flatten_device(gpu_ctx):
         warnings.simplefilter("ignore")
         ref = ocp.nesz_flattening(noise, inc)
     assert dev.shape == ref.shape and np.isfinite(dev).all() and rel(dev, ref) <= 1e-10, rel(dev, ref)
+    # the same ragged raster in float32 (odd line length: the element-wise paths of the fit and the write pass), and an even
+    # crop of it that starts 4 bytes off a 16-byte boundary on the host (the device copies are aligned: the vector paths)
+    n32, i32 = noise.astype(np.float32), inc.astype(np.float32)
+    for a, b in ((n32, i32), (np.ascontiguousarray(n32[1:, 1:]), np.ascontiguousarray(i32[1:, 1:]))):
+        got = gpu_ctx.nesz_flatten_host(a, b)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref32 = ocp.nesz_flattening(a, b)
+        assert got.dtype == np.float64 and got.shape == ref32.shape and np.isfinite(got).all() and rel(got, ref32) <= 1e-5, rel(got, ref32)
     # one valid column only: every line fits a single point -> numpy's minimum-norm solution (slope = y/2x, icpt = y/2)
     one = np.full((4, 6), np.nan)
     one[:, 2] = [1e-3, 2e-3, 5e-4, 1e-3]

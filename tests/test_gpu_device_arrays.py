@@ -116,6 +116,16 @@ def test_detrend_and_nesz_on_device_tensors(gpu_ctx):
         xsarsea_amd.options.nesz_on_device = old
     nz = nesz_flattening(torch.from_numpy(sig).to(dev), torch.from_numpy(inc).to(dev))
     assert isinstance(nz, torch.Tensor) and bits_equal(nz.cpu().numpy(), nz_np)
+    # float32 rasters that start 4 bytes off a 16-byte boundary (contiguous views into a larger buffer): the kernels' element-wise
+    # loads must give the bits of the aligned vector loads
+    s32, i32 = torch.from_numpy(sig.astype(np.float32)).to(dev), torch.from_numpy(inc.astype(np.float32)).to(dev)
+    n = s32.numel()
+    off_s, off_i = torch.empty(n + 1, dtype=torch.float32, device=dev)[1:].view(s32.shape), torch.empty(n + 1, dtype=torch.float32, device=dev)[1:].view(s32.shape)
+    off_s.copy_(s32)
+    off_i.copy_(i32)
+    assert off_s.data_ptr() % 16 == 4 and off_s.is_contiguous()
+    assert bits_equal(nesz_flattening(off_s, off_i).cpu().numpy(), nesz_flattening(s32, i32).cpu().numpy())
+    assert bits_equal(xsarsea_amd.sigma0_detrend(off_s, off_i).cpu().numpy(), xsarsea_amd.sigma0_detrend(s32, i32).cpu().numpy())
 
 
 @pytest.mark.parametrize("mode", ["mono", "dual"])

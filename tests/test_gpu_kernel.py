@@ -668,16 +668,19 @@ for scale, inc_lo, inc_hi in ((1.0, 17.0, 25.0), (1.6, 20.0, 36.0), (2.5, 30.0, 
 """
 
 
-@pytest.mark.parametrize("list_cap", [None, "300"])
-def test_wide_window_kernel(list_cap):
-    """XSW_WIDE=1 (opt-in, fresh process): k_invert_band keeps the windows of <= 48 directions and hands the wider ones to
-    k_invert_band2 in its WIDE role (batched sweeps); four scenes from friendly to far-off a-priori winds == the exhaustive sweep on
-    every pixel, and with list capacities of 300 pixels the strip-walk (only the wide pixels are searched again) and the
-    every-tile route of k_invert_list run."""
+@pytest.mark.parametrize("long_run,list_cap", [(None, None), (None, "300"), ("1", None), ("1", "300"), ("0", None)])
+def test_long_run_kernel(long_run, list_cap):
+    """The three-kernel chain in a fresh process: k_invert_band hands the pixels whose band holds XSW_LONG_RUN (default 4) or more
+    rows along the a-priori direction to k_invert_band2 (batched sweeps clipped to the disc's chord).  Four scenes from friendly
+    to far-off a-priori winds == the exhaustive sweep on every pixel -- with the default threshold, with XSW_LONG_RUN=1 (every
+    eligible pixel goes through k_invert_band2) and 0 (none does); with list capacities of 300 pixels the strip walk (only the
+    handed pixels are searched again) and the every-tile route of k_invert_list run."""
     import subprocess
     import sys
     from conftest import REPO
-    env = dict(os.environ, XSW_WIDE="1")
+    env = {k: v for k, v in os.environ.items() if k not in ("XSW_LONG_RUN", "XSW_BAND2")}
+    if long_run is not None:
+        env["XSW_LONG_RUN"] = long_run
     if list_cap:
         env["XSW_LIST_CAP_TEST"] = list_cap
     r = subprocess.run([sys.executable, "-c", _BAND2_SCRIPT.format(repo=REPO)], env=env, capture_output=True, text=True, timeout=900)
@@ -687,7 +690,10 @@ def test_wide_window_kernel(list_cap):
     for _, scale, diff, launches, b2, _listed in rows:
         assert int(diff) == 0, f"scale {scale}: {diff} values differ from the exhaustive sweep"
         assert int(launches) == 1
-    assert any(int(r_[4]) > 0 for r_ in rows), "no pixel was handed to the wide kernel"
+    if long_run == "0":
+        assert all(int(r_[4]) == 0 for r_ in rows)
+    else:
+        assert any(int(r_[4]) > 0 for r_ in rows), "no pixel was handed to k_invert_band2"
 
 
 @pytest.mark.parametrize("list_cap", [None, "300"])

@@ -647,15 +647,16 @@ static int launch_invert(xsw_ctx *c, const KArgs &A, int algo, const LaunchCtl &
         B.list_count = lc.list;
         B.list = lc.list + 16;
         B.list_cap = (unsigned)std::min<size_t>(lc.list_cap, 0xfffffff0u);
-        // list B (k_invert_band -> k_invert_band2) follows list G.  Both roles of k_invert_band2 are opt-in:
-        // XSW_WIDE=1: k_invert_band keeps the window classes of <= 48 directions and hands the wider ones over to a kernel that
-        // sweeps their rows in batches at lower occupancy (1.5x on scenes whose a-priori wind is far off, -4 % on the benchmark
-        // scene); XSW_BAND2=1: the rise-then-fall rule, k_invert_band carries every class.  The statistics instantiation keeps
-        // the two-kernel chain.
-        static const bool wide_on = getenv("XSW_WIDE") != nullptr && atoi(getenv("XSW_WIDE")) != 0;
-        const bool bitonic2 = c->T.inv2 != nullptr && !A.stats, wide2 = !bitonic2 && wide_on && !A.stats;
+        // list B (k_invert_band -> k_invert_band2) follows list G.  Long-run role (the default): a pixel whose band holds
+        // XSW_LONG_RUN (4) or more rows along the a-priori direction is handed to k_invert_band2 -- one such pixel holds up every
+        // pixel of its pass in k_invert_band, and where the a-priori wind is far from the sigma0 contour most pixels are such.
+        // XSW_LONG_RUN=0: never (k_invert_band sweeps every window; A/B measurements).  XSW_BAND2=1 (opt-in): the
+        // rise-then-fall rule instead.  The statistics instantiation sweeps every window in k_invert_band as well.
+        static const int long_run_env = getenv("XSW_LONG_RUN") ? std::max(0, atoi(getenv("XSW_LONG_RUN"))) : 4;
+        const bool bitonic2 = c->T.inv2 != nullptr && !A.stats, wide2 = !bitonic2 && long_run_env > 0 && !A.stats;
         const bool band2 = bitonic2 || wide2;
         if (band2) { B.list_b_count = lc.list + 1; B.list_b = lc.list + 16 + lc.list_cap; B.list_b_cap = B.list_cap; }
+        B.long_run = long_run_env;
         if (hipMemsetAsync(lc.list, 0, 2 * sizeof(unsigned), lc.stream) != hipSuccess) return seterr(err, XSW_EHIP, "work-list reset failed");
         const unsigned list_blocks = (unsigned)std::min<long long>(nblocks, 256 * 8);  // 8 waves per SIMD
         // k_invert_band: x = XCD lane + 8 * line group, y = tile column inside the XCD's range (see the kernel)
@@ -1415,12 +1416,19 @@ static hipError_t launch_nesz(hipStream_t s, const void *noise, const void *inc,
     NeszPartial *part = (NeszPartial *)scratch;
     double *col = (double *)((char *)scratch + (size_t)nb * samples * sizeof(NeszPartial));
     double *x0 = col + 2 * samples;
+    double *fit = x0 + 8;  // [lines][2]
     const unsigned gx = (unsigned)((samples + 255) / 256);
-    hipLaunchKernelGGL((k_nesz_colsum<T>), dim3(gx, (unsigned)nb), dim3(256), 0, s, (const T *)noise, (const T *)inc, part, lines, samples, lpb);
+    hipLaunchKernelGGL((k_nesz_colsum<T, 1>), dim3(gx, (unsigned)nb), dim3(256), 0, s, (const T *)noise, (const T *)inc, part, lines, samples, lpb);
     hipLaunchKernelGGL(k_nesz_colmean, dim3(gx), dim3(256), 0, s, part, col, samples, nb);
     hipLaunchKernelGGL(k_nesz_center, dim3(1), dim3(1024), 0, s, col, x0, samples);
-    hipLaunchKernelGGL((k_nesz_rows<T>), dim3((unsigned)((lines + XSW_NESZ_LINES - 1) / XSW_NESZ_LINES)), dim3(256), 0, s, (const T *)noise, col, x0, out,
-                       lines, samples);
+    hipLaunchKernelGGL((k_nesz_fit<T>), dim3((unsigned)((lines + XSW_NESZ_LINES - 1) / XSW_NESZ_LINES)), dim3(XSW_NESZ_THREADS), 0, s, (const T *)noise, col,
+                       x0, fit, lines, samples);
+    // the write pass: column groups x line blocks, ~16 workgroups per CU
+    const long long egx = (samples + 256LL * XSW_NESZ_EV - 1) / (256LL * XSW_NESZ_EV);
+    long long enb = std::max<long long>(1, std::min<long long>((256LL * 16 + egx - 1) / egx, std::min<long long>(lines, 65535)));
+    const long long elpb = (lines + enb - 1) / enb;
+    enb = (lines + elpb - 1) / elpb;
+    hipLaunchKernelGGL((k_nesz_eval<sizeof(T) == 4>), dim3((unsigned)egx, (unsigned)enb), dim3(256), 0, s, col, fit, out, lines, samples, elpb);
     return hipGetLastError();
 }
 
@@ -1467,7 +1475,7 @@ extern "C" int xsw_nesz_flatten(xsw_ctx *c, int64_t lines, int64_t samples, int3
     const long long lpb = (lines + nb - 1) / nb;
     nb = (lines + lpb - 1) / lpb;
     // context-owned scratch (column partials, means, centring abscissa), grown on demand: no allocation on the steady-state path
-    const size_t scratch_bytes = (size_t)nb * samples * sizeof(NeszPartial) + (2 * (size_t)samples + 8) * sizeof(double);
+    const size_t scratch_bytes = (size_t)nb * samples * sizeof(NeszPartial) + (2 * (size_t)samples + 8 + 2 * (size_t)lines) * sizeof(double);
     if (scratch_bytes > c->nesz_cap) {
         HIPCHK(c, hipStreamSynchronize(c->stream));  // a previous call may still be using the old scratch
         if (c->nesz_scratch) (void)hipFree(c->nesz_scratch);

@@ -64,11 +64,8 @@ namespace xsw {
 #ifndef XSW_BAND_WAVES
 #define XSW_BAND_WAVES 8
 #endif
-#ifndef XSW_BAND_NARROW_CLASSES
-#define XSW_BAND_NARROW_CLASSES 8  // k_invert_band keeps window classes 0 .. 7 (<= 48 directions); wider ones go to k_invert_band2
-#endif
 #ifndef XSW_BAND_BATCH_S
-#define XSW_BAND_BATCH_S 32  // window classes of S >= this many lanes per pixel sweep their rows in batches (co_band_pass)
+#define XSW_BAND_BATCH_S 2  // window classes of S >= this many lanes per pixel sweep their rows in batches (co_band_pass)
 #endif
 #ifndef XSW_BAND_BATCH
 #define XSW_BAND_BATCH 4
@@ -99,6 +96,17 @@ __device__ __forceinline__ double ld_co(const char *__restrict__ base, unsigned 
 // column c < n is the RISING part of direction c (rows below the column's first decreasing step), column n + c its FALLING part
 // -- so a lane still owns one run of rows per column: only the table (L.inv2: rising and falling inverse tables side by side,
 // XSW_INV_BINS + 1 thresholds, the last one +inf) and the order of the two threshold bins differ between the two halves.
+// CHORD: the rows of a direction are also clipped to the chord the disc |c - m| <= 2 sqrt(J_ub) cuts out of that direction's ray
+// (the window is only the disc's bounding box in (speed, direction): in a wide window most directions cross the band rows
+// OUTSIDE the disc, where the wind term alone already exceeds J_ub).  Along direction e, with U = m . e and wh = w / 2:
+// wh^2 - U wh + |m|^2/4 <= J_ub  <=>  |wh - U/2| <= sqrt(U^2/4 - |m|^2/4 + J_ub).  J_ub is recovered from the band's half
+// width (thr_hi - thr_lo) / 2 = |dsig| sqrt(J_ub) (1 + 1e-6) + 1e-9 (co_window_lanes), i.e. already inflated; float32 square
+// root, inflated again, and XSW_CHORD_MRG index units of slack on the row bounds (as box_from_jub).
+#ifndef XSW_CHORD_MRG
+#define XSW_CHORD_MRG 2e-3
+#endif
+// k_invert_band2 only (its long-run role): in k_invert_band the clip costs more than it saves (measured with every window
+// swept there, band kernel at 20000^2: no clip 46.8 ms; segments of 64 lanes 47.2; >= 32: 48.4; >= 16: 50.6).
 template <int S, int K, bool COUNT, bool BITONIC, bool BATCH = false>
 __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig, int lane,
                                              const BandSlot *slots /* this wave's [64], sorted by class */, int *res /* [64], by slot */,
@@ -126,6 +134,13 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
     const unsigned inv0 = (unsigned)(i_inc * (BITONIC ? 2 : 1) * NB + ((unsigned)B.inc_bin >> 16)) * (unsigned)L.phi_pad * 2u;
     const unsigned inv1 = (unsigned)(i_inc * (BITONIC ? 2 : 1) * NB + max(B.bin_hi, 0)) * (unsigned)L.phi_pad * 2u;
     const unsigned inv_fall = (unsigned)NB * (unsigned)L.phi_pad * 2u;  // BITONIC: the falling table follows the rising one
+    constexpr bool CHORD = !BITONIC && BATCH;
+    double jrel = 0.0, inv_whs = 0.0;  // J_ub - |m|^2/4 (inflated); rows per unit of wh
+    if (CHORD) {
+        const double rs = 0.5 * (thr_hi - thr_lo) * fabs(inv_dsig);  // >= sqrt(J_ub) (1 + 1e-6)
+        jrel = fma(rs, rs, -B.m2) + 1e-9 * (rs * rs + B.m2);
+        inv_whs = 2.0 * L.inv_wstep;
+    }
     double best = inf, second = inf;
     int brow = 0, bip = 0;
     unsigned ncand = 0;
@@ -159,7 +174,16 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
             const int ra = (int)*(const unsigned short *)((const char *)inv_tab + o_first);
             const int rb = (int)*(const unsigned short *)((const char *)inv_tab + o_last);
             r[j] = max(ra, w_lo);
-            const int last = (BITONIC || B.bin_hi >= 0) ? min(rb - 1, w_hi) : w_hi;  // BITONIC: the "no threshold above" bin is tabulated
+            int last = (BITONIC || B.bin_hi >= 0) ? min(rb - 1, w_hi) : w_hi;  // BITONIC: the "no threshold above" bin is tabulated
+            if (CHORD) {
+                const double Uh = 0.5 * U[j];
+                const double disc = fma(Uh, Uh, jrel);  // (half chord)^2 in wh units; < 0: the ray misses the disc
+                const double h = (double)__builtin_sqrtf((float)fmax(disc, 0.0)) * (1.0 + 1e-6) + 1e-6;
+                const double xc = (Uh - wh0) * inv_whs, xh = fma(h, inv_whs, XSW_CHORD_MRG);
+                const int c_lo = (int)ceil(fmax(xc - xh, -4.0)), c_hi = (int)floor(fmin(xc + xh, 40000.0));
+                r[j] = max(r[j], c_lo);
+                last = disc < 0.0 ? r[j] - 1 : min(last, c_hi);
+            }
             nrow[j] = act[j] ? last - r[j] + 1 : 0;
             nmax = max(nmax, nrow[j]);
         }
@@ -171,9 +195,9 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
             for (int j = 0; j < K; ++j) nrow[j] = 0;
         }
         if (BATCH && S >= XSW_BAND_BATCH_S) {
-            // wide windows (one or two pixels per pass: an a-priori wind far from the sigma0 contour): their runs are several rows
-            // long and the sweep is a chain of dependent load round trips -- take the rows XSW_BAND_BATCH at a time, all loads of
-            // a batch in flight before the first is scored.  (Narrow windows have 1-3 rows per direction: batching costs there.)
+            // k_invert_band2's pixels (long runs of band rows: an a-priori wind far from the sigma0 contour, or a flat stretch of
+            // the GMF): the sweep is a chain of dependent load round trips -- take the rows XSW_BAND_BATCH at a time, all loads
+            // of a batch in flight before the first is scored.  (k_invert_band's runs are 1-3 rows: batching costs there.)
 #pragma unroll 1
             for (int t0 = 0; t0 < XSW_BAND_MAX; t0 += XSW_BAND_BATCH) {
                 unsigned long long left[K], any_left = 0ULL;
@@ -264,21 +288,22 @@ __device__ __forceinline__ void list_append(unsigned *__restrict__ count, unsign
 // store.  Body of k_invert_band (tiles of the raster) and k_invert_band2 (pixels of a work list, BITONIC rule).
 // COUNT = true: the statistics instantiation (xsw_stats_enable): candidates are counted per pass; its own kernel so that the
 // production kernel carries one copy of each pass (half the code).
-// ROLE: 0 = every window class (the statistics instantiation; the rise-then-fall rule; no second kernel available);
-//       1 = the NARROW classes only, windows of more than XSW_BAND_NARROW_MAX directions are left to the second band kernel (list B);
-//       2 = every class, the wide ones sweeping their rows in batches (k_invert_band2 in its default, WIDE role).
+// ROLE: 0 = every window class in this kernel (the statistics instantiation; the rise-then-fall rule; XSW_WIDE=0);
+//       1 = pixels whose band holds A.long_run or more rows along the a-priori direction are handed to the second band kernel
+//           (list B), the others are swept here (k_invert_band's default);
+//       2 = the rows swept in batches and clipped to the disc's chord (k_invert_band2 in its default, LONG-RUN role).
 template <typename T, typename TO, bool CR, bool COUNT, bool BITONIC, int ROLE = 0>
 __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, long long i, bool in, int lane, BandSlot *__restrict__ slots,
-                                          int *__restrict__ res_, bool wide_only = false /* ROLE 2, strip walk: the narrow pixels are k_invert_band's */)
+                                          int *__restrict__ res_, bool strip_walk = false /* ROLE 2 walking every strip: the short-run pixels are k_invert_band's */)
 {
     const double nan = __builtin_nan("");
     int flags, my_flat = -1, my_icr = -1;
     unsigned cand = 0;
     constexpr int NC = 11;  // window classes: S lanes x K directions = 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128 (and wider: chunks)
     int pos = -1, first[NC] = {}, ncls[NC] = {};  // slot of this lane's pixel; slot range of each class
-    bool skip = false;        // ROLE 2 walking every strip (list B overflowed): not one of the wide pixels this kernel is for
+    bool skip = false;        // ROLE 2 walking every strip (list B overflowed): not one of the long-run pixels this kernel is for
     bool to_bitonic = false;  // left to the second band kernel: its window leaves the monotone rows of a rise-then-fall slice
-                              // (XSW_BAND2=1), or -- ROLE 1 -- it is wider than the classes this kernel carries
+                              // (XSW_BAND2=1), or -- ROLE 1 -- its band holds a long run of rows
     {
         // ---- stage 1, one pixel per lane: classify, incidence bin, upper bound along the a-priori direction, window
         Pixel P;
@@ -298,7 +323,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
             const int nrows_p = W.w_hi - W.w_lo + 1;
             ncols_p = W.ip_hi - W.ip_lo + 1;
             const bool need = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0 && !loose && ncols_p >= 1 && nrows_p >= 1;
-            if (ROLE == 2 && wide_only) skip = !need || !(W.w_hi < L.mono_rows[need ? P.i_inc : 0]);  // everything k_invert_band did not hand over
+            if (ROLE == 2 && strip_walk) skip = !need || !(W.w_hi < L.mono_rows[need ? P.i_inc : 0]);  // everything k_invert_band did not hand over
             if (BITONIC) {
                 eligb = need && L.bitonic_ok[need ? P.i_inc : 0] != 0;  // every column of the slice rises, then falls
             } else {
@@ -311,17 +336,46 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
             // the next power of two).  The slots are written SORTED by class (slot = pixels of narrower classes + rank inside the
             // class): a pass takes the next 64/S slots of its class, no per-pass ranking, and a lane picks its result up from its
             // slot once, after the last pass
+            // threshold bins of the slice's inverse table: the largest grid threshold <= s - d (bin 0 also stands for anything
+            // below the grid; the check repeats the builder's own expression, k_inv_rows), and the smallest grid threshold
+            // > s + d (none: the band may reach the window's last row)
+            const double thr_lo = P.s_co - W.band_d, thr_hi = P.s_co + W.band_d;
+            int bin = 0, bhi = XSW_INV_BINS;
+            if (eligb) {
+                const double *g = (BITONIC ? L.inv_grid2 : L.inv_grid) + 3 * P.i_inc;
+                const double t0 = g[0], width = g[1];
+                bin = (int)fmin(fmax((thr_lo - t0) * g[2], 0.0), (double)(XSW_INV_BINS - 1));
+                if (bin > 0 && fma((double)bin, width, t0) > thr_lo) --bin;
+                if (bin > 0 && fma((double)bin, width, t0) > thr_lo) bin = 0;
+                bhi = (int)fmin(fmax((thr_hi - t0) * g[2], -1.0), (double)XSW_INV_BINS) + 1;
+                if (bhi < XSW_INV_BINS && !(fma((double)bhi, width, t0) > thr_hi)) ++bhi;
+                if (bhi < XSW_INV_BINS && !(fma((double)bhi, width, t0) > thr_hi)) bhi = XSW_INV_BINS;
+            }
             int myc = NC;
             if (eligb) {
                 const int nv = BITONIC ? 2 * ncols_p : ncols_p;
                 const int p2 = 31 - __clz(max(nv, 2) - 1);  // 2^p2 < n <= 2^(p2 + 1)
                 myc = nv <= 4 ? 0 : min(2 * p2 - 3 + (nv > (3 << (p2 - 1)) ? 1 : 0), NC - 1);
-                if (ROLE == 1 && myc >= XSW_BAND_NARROW_CLASSES) {  // a wide window: the second band kernel's
+            }
+            if (ROLE == 1 || (ROLE == 2 && strip_walk)) {
+                // LONG runs: the rows the band holds along the a-priori direction (the inverse table's own answer) are what a
+                // pass's trip count follows, and one pixel with a long run holds up every pixel of its pass.  Pixels with at least
+                // A.long_run such rows go to k_invert_band2, which sees long runs only (batched sweeps, chord clip, fewer waves
+                // per SIMD); its strip walk repeats this per-pixel decision.
+                int run = 0;
+                if (eligb) {
+                    const unsigned short *col = L.inv_rows + (size_t)P.i_inc * XSW_INV_BINS * L.phi_pad + P.ipr;
+                    const int ra = (int)col[(size_t)bin * L.phi_pad];
+                    const int rb = bhi < XSW_INV_BINS ? (int)col[(size_t)bhi * L.phi_pad] : W.w_hi + 1;
+                    run = min(rb - 1, W.w_hi) - max(ra, W.w_lo) + 1;
+                }
+                const bool handed = eligb && run >= A.long_run;
+                if (ROLE == 1 && handed) {  // the second band kernel's
                     myc = NC;
                     eligb = false;
                     to_bitonic = true;
                 }
-                if (ROLE == 2 && wide_only && myc < XSW_BAND_NARROW_CLASSES) {  // k_invert_band has dealt with it (decided, or listed)
+                if (ROLE == 2 && eligb && !handed) {  // k_invert_band has dealt with it (decided, or listed)
                     myc = NC;
                     eligb = false;
                     skip = true;
@@ -342,7 +396,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
             // ITS part-filled last pass (their slots lie right before that class's: only the boundary moves; a narrow window in
             // a wide segment merely leaves lanes idle): one pass less each time
 #pragma unroll
-            for (int c = 0; c + 1 < (ROLE == 1 ? XSW_BAND_NARROW_CLASSES : NC); ++c) {
+            for (int c = 0; c + 1 < NC; ++c) {
                 const int np = 64 / (2 << (c >> 1)), npn = 64 / (2 << ((c + 1) >> 1));  // pixels per pass of this class / of the next
                 const int rem = ncls[c] % np;
                 const int added = (ncls[c + 1] + rem + npn - 1) / npn - (ncls[c + 1] + npn - 1) / npn;
@@ -352,19 +406,8 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
             if (eligb) {
                 BandSlot b;
                 const double ah = 0.5 * P.a_re, bh = 0.5 * P.b_eff;
-                b.sn = -P.s_co * A.inv_dsig_co; b.thr_lo = P.s_co - W.band_d; b.thr_hi = P.s_co + W.band_d;
+                b.sn = -P.s_co * A.inv_dsig_co; b.thr_lo = thr_lo; b.thr_hi = thr_hi;
                 b.ah = ah; b.bh = bh; b.m2 = ah * ah + bh * bh;
-                // threshold bin of the slice's inverse table: the largest grid threshold <= s - d (bin 0 also stands for
-                // anything below the grid); the check repeats the builder's own expression (k_inv_rows)
-                const double *g = (BITONIC ? L.inv_grid2 : L.inv_grid) + 3 * P.i_inc;
-                const double t0 = g[0], width = g[1];
-                int bin = (int)fmin(fmax((b.thr_lo - t0) * g[2], 0.0), (double)(XSW_INV_BINS - 1));
-                if (bin > 0 && fma((double)bin, width, t0) > b.thr_lo) --bin;
-                if (bin > 0 && fma((double)bin, width, t0) > b.thr_lo) bin = 0;
-                // the smallest grid threshold > s + d (none: the band may reach the window's last row)
-                int bhi = (int)fmin(fmax((b.thr_hi - t0) * g[2], -1.0), (double)XSW_INV_BINS) + 1;
-                if (bhi < XSW_INV_BINS && !(fma((double)bhi, width, t0) > b.thr_hi)) ++bhi;
-                if (bhi < XSW_INV_BINS && !(fma((double)bhi, width, t0) > b.thr_hi)) bhi = XSW_INV_BINS;
                 b.inc_bin = P.i_inc | (bin << 16); b.rows = W.w_lo | (W.w_hi << 16); b.ipn = W.ip_lo | (ncols_p << 16);
                 b.bin_hi = bhi < XSW_INV_BINS ? bhi : (BITONIC ? XSW_INV_BINS /* the tabulated +inf threshold */ : -1);
                 slots[pos] = b;
@@ -397,18 +440,16 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
         run(std::integral_constant<int, 8>{}, three{}, 5);
         run(std::integral_constant<int, 16>{}, two{}, 6);
         run(std::integral_constant<int, 16>{}, three{}, 7);
-        if (ROLE != 1) {  // (ROLE 1 carries no pass for the wide classes)
-            run(std::integral_constant<int, 32>{}, two{}, 8);
-            run(std::integral_constant<int, 32>{}, three{}, 9);
-            run(std::integral_constant<int, 64>{}, two{}, 10);
-        }
+        run(std::integral_constant<int, 32>{}, two{}, 8);
+        run(std::integral_constant<int, 32>{}, three{}, 9);
+        run(std::integral_constant<int, 64>{}, two{}, 10);
     }
 #endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (pos >= 0) my_flat = res_[pos];  // -1: undecided by its pass
-    if (ROLE == 2 && wide_only) {  // strip walk: lanes without a co-pol search, and the pixels k_invert_band kept, are not this kernel's
+    if (ROLE == 2 && strip_walk) {  // strip walk: lanes without a co-pol search, and the pixels k_invert_band kept, are not this kernel's
         skip = skip || (flags & F_NEED_CO) == 0;
         in = in && !skip;
     }
@@ -499,8 +540,8 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND2_WAVES) void k_inv
     if (count > (long long)A.list_b_cap) {
         // list B overflowed (k_invert_band kept counting but could not append): which pixels it meant is unknown, so this kernel
         // walks EVERY strip of the raster.  Rise-then-fall role: every pixel goes through the rule (it holds for monotone windows
-        // as well: their falling runs are empty; results do not depend on which kernel wrote a pixel).  Wide role: stage 1 is
-        // redone for every pixel and only the wide windows -- what k_invert_band did not keep -- are searched.
+        // as well: their falling runs are empty; results do not depend on which kernel wrote a pixel).  Long-run role: stage 1 is
+        // redone for every pixel and only the long-run pixels -- what k_invert_band did not keep -- are searched.
         // (strips in linear order, one per wave: measured 2x faster for this kernel than k_invert_band's XCD-aware tile walk as a
         // grid-stride loop -- the heavy pixels of a scene cluster, and the linear order spreads them over all the waves)
         const long long strips_per_line = (A.samples + 63) >> 6, nstrips = strips_per_line * A.lines;

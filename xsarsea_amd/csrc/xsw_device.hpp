@@ -86,8 +86,9 @@ struct KArgs {
     unsigned *list;             // two-kernel path (nullable): k_invert_band appends the flat index of every pixel it leaves
     unsigned *list_count;       // undecided; k_invert_list then inverts exactly those, 64 per wave
     unsigned list_cap;          // entries the list holds; the counter runs on past it (overflow: k_invert_list takes every tile)
-    unsigned *list_b, *list_b_count;  // list B (nullable): pixels k_invert_band hands to k_invert_band2 (rise-then-fall columns)
+    unsigned *list_b, *list_b_count;  // list B (nullable): pixels k_invert_band hands to k_invert_band2 (long runs of band rows; rise-then-fall columns)
     unsigned list_b_cap;
+    int long_run;               // k_invert_band, ROLE 1: rows along the a-priori direction from which a pixel is handed to k_invert_band2
     long long n, lines, samples;
     double dsig_co, inv_dsig_co, dsig_cr_scalar;
     int is_db, dual_select;

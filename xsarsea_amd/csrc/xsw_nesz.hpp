@@ -6,12 +6,12 @@
 //                (slope, icpt) = degree-1 least squares of y[ok] against inc_row[ok]                    (:133-149)
 //                out[l][s] = 10 ** ((inc_row[s] * slope + icpt - 1) / 10)   for EVERY s                (:152)
 //
-// Three kernels, all HBM-bound streaming passes (float32 rasters: 8 B read in the first, 4 B read + 8 B written in the
-// third, per pixel):
-//   k_nesz_colsum   partial column sums/counts over blocks of lines (one or four columns per thread, coalesced rows)
-//   k_nesz_colmean  finishes the column means in line-block order (deterministic) + the centring abscissa x0
-//   k_nesz_rows     one workgroup per line: five float64 moments about x0 (n, Sx, Sy, Sxx, Sxy), closed-form fit,
-//                   then the line's outputs from the column abscissae (no second read of the raster).
+// Three HBM-bound streaming passes (float32 rasters: 8 B read in the first, 4 B read in the second, 8 B written in the third,
+// per pixel) and two small kernels:
+//   k_nesz_colsum   partial column sums/counts over blocks of lines (V columns per thread, coalesced rows)
+//   k_nesz_colmean  finishes the column means in line-block order (deterministic); k_nesz_center: the centring abscissa x0
+//   k_nesz_fit      XSW_NESZ_LINES lines per workgroup: five float64 moments about x0 (n, Sx, Sy, Sxx, Sxy), closed-form fit
+//   k_nesz_eval     the raster from the column abscissae and the lines' coefficients (write only).
 // Sums are float64 whatever the raster dtype (numpy accumulates float32 rasters in float32); the fit is the closed
 // form of the normal equations about x0 instead of numpy's SVD: results agree with the host route to ~1e-13 relative
 // for float64 rasters (tests state 1e-10), ~1e-6 for float32 rasters (numpy's float32 log10 and float32 column sums).
@@ -26,40 +26,63 @@ struct NeszPartial {  // per (line block, column)
     int cnt_n, cnt_i;
 };
 
-template <typename T>
+// V columns per thread (vector loads when the lines are aligned to them; otherwise -- and for the last, partial group of
+// columns -- element by element).  grid.x tiles the column groups, grid.y the line blocks.  The library launches V = 1: wider
+// loads measured slower at 20000^2 float32 (V = 1: 0.59 ms, 2: 0.64 ms, 4: 0.66 ms in the same run).
+template <typename T, int V>
 __global__ __launch_bounds__(256) void k_nesz_colsum(const T *__restrict__ noise, const T *__restrict__ inc,
                                                      NeszPartial *__restrict__ part, long long lines, long long samples,
                                                      long long lines_per_block)
 {
-    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    const long long s = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (s >= samples) return;
     const long long l0 = (long long)blockIdx.y * lines_per_block;
     const long long l1 = l0 + lines_per_block < lines ? l0 + lines_per_block : lines;
-    double sn = 0.0, si = 0.0;
-    int cn = 0, ci = 0;
+    double sn[V], si[V];
+    int cn[V], ci[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { sn[k] = si[k] = 0.0; cn[k] = ci[k] = 0; }
+    auto add = [&](int k, T a, T b) {
+        const double x = (double)a, y = (double)b;
+        if (x == x) { sn[k] += x; ++cn[k]; }
+        if (y == y) { si[k] += y; ++ci[k]; }
+    };
     const T *pn = noise + l0 * samples + s, *pi = inc + l0 * samples + s;
-    long long l = l0;
-    for (; l + 4 <= l1; l += 4) {  // four lines in flight per lane
-        T a[4], b[4];
+    const bool vec = s + V <= samples && (samples % V) == 0 && (((size_t)noise | (size_t)inc) & (sizeof(vec_t) - 1)) == 0;
+    if (vec) {
+        long long l = l0;
+        for (; l + 4 <= l1; l += 4) {  // four lines in flight per lane
+            vec_t a[4], b[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { a[u] = pn[u * samples]; b[u] = pi[u * samples]; }
+            for (int u = 0; u < 4; ++u) { a[u] = *(const vec_t *)(pn + u * samples); b[u] = *(const vec_t *)(pi + u * samples); }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const double x = (double)a[u], y = (double)b[u];
-            if (x == x) { sn += x; ++cn; }
-            if (y == y) { si += y; ++ci; }
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < V; ++k) add(k, a[u][k], b[u][k]);
+            pn += 4 * samples; pi += 4 * samples;
         }
-        pn += 4 * samples; pi += 4 * samples;
+        for (; l < l1; ++l) {
+            const vec_t a = *(const vec_t *)pn, b = *(const vec_t *)pi;
+#pragma unroll
+            for (int k = 0; k < V; ++k) add(k, a[k], b[k]);
+            pn += samples; pi += samples;
+        }
+    } else {
+        for (long long l = l0; l < l1; ++l) {
+#pragma unroll
+            for (int k = 0; k < V; ++k)
+                if (s + k < samples) add(k, pn[k], pi[k]);
+            pn += samples; pi += samples;
+        }
     }
-    for (; l < l1; ++l) {
-        const double x = (double)*pn, y = (double)*pi;
-        if (x == x) { sn += x; ++cn; }
-        if (y == y) { si += y; ++ci; }
-        pn += samples; pi += samples;
-    }
-    NeszPartial p;
-    p.sum_n = sn; p.sum_i = si; p.cnt_n = cn; p.cnt_i = ci;
-    part[(long long)blockIdx.y * samples + s] = p;
+#pragma unroll
+    for (int k = 0; k < V; ++k)
+        if (s + k < samples) {
+            NeszPartial p;
+            p.sum_n = sn[k]; p.sum_i = si[k]; p.cnt_n = cn[k]; p.cnt_i = ci[k];
+            part[(long long)blockIdx.y * samples + s + k] = p;
+        }
 }
 
 // col[0][s] = noise_mean, col[1][s] = inc_row (NaN for a column without a valid sample, as np.nanmean)
@@ -107,7 +130,7 @@ __global__ __launch_bounds__(1024) void k_nesz_center(const double *__restrict__
 
 // log10 / exp10 for the arguments of this kernel (positive normal finite doubles; |t| < 300), ~1e-15 relative: frexp + atanh
 // series, and 2^k * exp(g) with a degree-13 Taylor polynomial.  About 55 float64 instructions for the pair instead of the
-// ~120 of the library calls, which are what bounds k_nesz_rows (one of each per pixel); anything else goes to the library.
+// ~120 of the library calls, which bound the float64 passes (one of each per pixel); anything else goes to the library.
 __device__ __forceinline__ double nesz_log10(double v)
 {
     if (!(v >= 2.2250738585072014e-308 && v <= 1.7976931348623157e308)) return log10(v);  // 0, negative, denormal, inf, NaN
@@ -147,13 +170,23 @@ __device__ __forceinline__ double nesz_exp10(double t)
 #ifndef XSW_NESZ_LINES
 #define XSW_NESZ_LINES 4
 #endif
+#ifndef XSW_NESZ_F32_GROUP
+#define XSW_NESZ_F32_GROUP 2  // float32 samples per lane and trip
+#endif
+#ifndef XSW_NESZ_THREADS
+#define XSW_NESZ_THREADS 256
+#endif
+// The fit of XSW_NESZ_LINES lines per workgroup: (slope, intercept) -> fit[line][2]; k_nesz_eval then writes the raster.  A
+// pure read pass followed by a pure write pass runs faster than one kernel doing both per line (measured at 20000^2 float32,
+// round 3: fit 0.38 ms + eval 0.60 ms against 1.16 ms).
 template <typename T>
-__global__ __launch_bounds__(256) void k_nesz_rows(const T *__restrict__ noise, const double *__restrict__ col,
-                                                   const double *__restrict__ x0p, double *__restrict__ out,
-                                                   long long lines, long long samples)
+__global__ __launch_bounds__(XSW_NESZ_THREADS) void k_nesz_fit(const T *__restrict__ noise, const double *__restrict__ col,
+                                                  const double *__restrict__ x0p, double *__restrict__ fit,
+                                                  long long lines, long long samples)
 {
     constexpr int R = XSW_NESZ_LINES;
-    __shared__ double sh[5][4][R];
+    constexpr int NW = XSW_NESZ_THREADS / 64;
+    __shared__ double sh[5][NW][R];
     const long long l0 = (long long)blockIdx.x * R;
     const double *mean = col, *xs = col + samples;
     const double x0 = *x0p;
@@ -176,22 +209,30 @@ __global__ __launch_bounds__(256) void k_nesz_rows(const T *__restrict__ noise, 
         // polyfit sees x[ok]: a NaN abscissa (column without valid incidence) poisons the fit there; here too
         if (isfinite(y)) { n[j] += 1.0; sx[j] += x; sy[j] += y; sxx[j] += x * x; sxy[j] += x * y; }
     };
-    // two samples per lane and trip (adjacent: 8/16-byte accesses when the line is aligned), R lines each, then the tail
-    const long long pairs = samples >> 1;
-    const bool al = ((samples * sizeof(T)) & (sizeof(T) * 2 - 1)) == 0 && (((size_t)noise) & (sizeof(T) * 2 - 1)) == 0 && (samples & 1) == 0;
-    for (long long q = threadIdx.x; q < pairs; q += blockDim.x) {
-        const long long s = q * 2;
-        const double m0 = mean[s], m1 = mean[s + 1], x0s = xs[s] - x0, x1s = xs[s + 1] - x0;
+    // V samples per lane and trip (adjacent: one 16-byte access when the lines are aligned), R lines each, then the tail
+    constexpr int V = (sizeof(T) == 4 ? XSW_NESZ_F32_GROUP : 2);
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    const long long groups = samples / V;
+    const bool al = (samples % V) == 0 && (((size_t)noise) & (sizeof(vec_t) - 1)) == 0;
+    for (long long q = threadIdx.x; q < groups; q += blockDim.x) {
+        const long long s = q * V;
+        double m[V], xc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) { m[k] = mean[s + k]; xc[k] = xs[s + k] - x0; }
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            T v0, v1;
-            if (al) { typedef T v2 __attribute__((ext_vector_type(2))); const v2 t = *(const v2 *)(row[j] + s); v0 = t.x; v1 = t.y; }
-            else { v0 = row[j][s]; v1 = row[j][s + 1]; }
-            take(j, (double)v0, m0, x0s);
-            take(j, (double)v1, m1, x1s);
+            T v[V];
+            if (al) { const vec_t t = *(const vec_t *)(row[j] + s);
+#pragma unroll
+                for (int k = 0; k < V; ++k) v[k] = t[k]; }
+            else {
+#pragma unroll
+                for (int k = 0; k < V; ++k) v[k] = row[j][s + k]; }
+#pragma unroll
+            for (int k = 0; k < V; ++k) take(j, (double)v[k], m[k], xc[k]);
         }
     }
-    for (long long s = pairs * 2 + threadIdx.x; s < samples; s += blockDim.x)
+    for (long long s = groups * V + threadIdx.x; s < samples; s += blockDim.x)
 #pragma unroll
         for (int j = 0; j < R; ++j) take(j, (double)row[j][s], mean[s], xs[s] - x0);
     const int w = threadIdx.x >> 6;
@@ -205,11 +246,9 @@ __global__ __launch_bounds__(256) void k_nesz_rows(const T *__restrict__ noise, 
     double slope[R], icpt[R];  // in the uncentred abscissa: y = slope * x_raw + icpt
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        const double nn = sh[0][0][j] + sh[0][1][j] + sh[0][2][j] + sh[0][3][j];
-        const double ssx = sh[1][0][j] + sh[1][1][j] + sh[1][2][j] + sh[1][3][j];
-        const double ssy = sh[2][0][j] + sh[2][1][j] + sh[2][2][j] + sh[2][3][j];
-        const double ssxx = sh[3][0][j] + sh[3][1][j] + sh[3][2][j] + sh[3][3][j];
-        const double ssxy = sh[4][0][j] + sh[4][1][j] + sh[4][2][j] + sh[4][3][j];
+        double nn = 0.0, ssx = 0.0, ssy = 0.0, ssxx = 0.0, ssxy = 0.0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) { nn += sh[0][k][j]; ssx += sh[1][k][j]; ssy += sh[2][k][j]; ssxx += sh[3][k][j]; ssxy += sh[4][k][j]; }
         if (nn == 0.0) {  // nothing to fit: the reference returns a NaN line (utils.py:146-149)
             slope[j] = nan; icpt[j] = nan;
         } else {
@@ -226,27 +265,52 @@ __global__ __launch_bounds__(256) void k_nesz_rows(const T *__restrict__ noise, 
             }
         }
     }
-    for (long long q = threadIdx.x; q < pairs; q += blockDim.x) {
-        const long long s = q * 2;
-        const double xa = xs[s], xb = xs[s + 1];
+    if (threadIdx.x < R && live[threadIdx.x]) {
+        double sl = slope[0], ic = icpt[0];
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-            if (!live[j]) continue;
-            double *o = out + (l0 + j) * samples + s;
-            const double ta = (xa * slope[j] + icpt[j] - 1.0) * 0.1, tb = (xb * slope[j] + icpt[j] - 1.0) * 0.1;
-            const double ra = F32 ? (double)__builtin_amdgcn_exp2f((float)(ta * 3.321928094887362)) : nesz_exp10(ta);
-            const double rb = F32 ? (double)__builtin_amdgcn_exp2f((float)(tb * 3.321928094887362)) : nesz_exp10(tb);
-            if ((((size_t)o) & 15) == 0) { double2 t; t.x = ra; t.y = rb; *(double2 *)o = t; }
-            else { o[0] = ra; o[1] = rb; }
+        for (int j = 1; j < R; ++j) { sl = (int)threadIdx.x == j ? slope[j] : sl; ic = (int)threadIdx.x == j ? icpt[j] : ic; }
+        fit[2 * (l0 + threadIdx.x)] = sl;
+        fit[2 * (l0 + threadIdx.x) + 1] = ic;
+    }
+}
+
+// out[l][s] = 10 ** ((inc_row[s] * slope[l] + icpt[l] - 1) / 10): a thread keeps its EV column abscissae in registers and
+// streams down its block of lines (the line's two coefficients are wave-uniform: scalar loads); only the stores touch HBM.
+#ifndef XSW_NESZ_EV
+#define XSW_NESZ_EV 2
+#endif
+template <bool F32>
+__global__ __launch_bounds__(256) void k_nesz_eval(const double *__restrict__ col, const double *__restrict__ fit, double *__restrict__ out,
+                                                   long long lines, long long samples, long long lines_per_block)
+{
+    constexpr int EV = XSW_NESZ_EV;
+    const long long s = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * EV;
+    if (s >= samples) return;
+    const long long l0 = (long long)blockIdx.y * lines_per_block;
+    const long long l1 = l0 + lines_per_block < lines ? l0 + lines_per_block : lines;
+    const double *xs = col + samples;
+    double x[EV];
+#pragma unroll
+    for (int k = 0; k < EV; ++k) x[k] = xs[s + k < samples ? s + k : samples - 1];
+    const bool vec = s + EV <= samples && (samples & 1) == 0 && (((size_t)out) & 15) == 0;
+    double *o = out + l0 * samples + s;
+    for (long long l = l0; l < l1; ++l, o += samples) {
+        const double sl = fit[2 * l], ic = fit[2 * l + 1];
+        double r[EV];
+#pragma unroll
+        for (int k = 0; k < EV; ++k) {
+            const double t = (x[k] * sl + ic - 1.0) * 0.1;
+            r[k] = F32 ? (double)__builtin_amdgcn_exp2f((float)(t * 3.321928094887362)) : nesz_exp10(t);
+        }
+        if (vec) {
+#pragma unroll
+            for (int k = 0; k < EV; k += 2) { double2 t; t.x = r[k]; t.y = r[k + 1]; *(double2 *)(o + k) = t; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < EV; ++k)
+                if (s + k < samples) o[k] = r[k];
         }
     }
-    for (long long s = pairs * 2 + threadIdx.x; s < samples; s += blockDim.x)
-#pragma unroll
-        for (int j = 0; j < R; ++j)
-            if (live[j]) {
-                const double tt = (xs[s] * slope[j] + icpt[j] - 1.0) * 0.1;
-                out[(l0 + j) * samples + s] = F32 ? (double)__builtin_amdgcn_exp2f((float)(tt * 3.321928094887362)) : nesz_exp10(tt);
-            }
 }
 
 }  // namespace xsw
