@@ -820,11 +820,14 @@ def main():
         chain_ms_max = kernel_ms_max + (second_ms or 0.0)
         is_metric_shape = (mode == "mono" and args.resolution == "high" and cfg["lut"] == "cmod5n" and args.algo == "pruned"
                            and (lines, samples) == (20000, 20000))
-        traffic, traffic_prov = None, None
+        traffic, traffic_prov, chain_traffic = None, None, None
         if is_metric_shape:
             tj, traffic_prov = fresh_profile(f"{PROFILE_ROUND}_hbm_traffic_summary.json")
             if tj:
-                traffic = int(tj["k_invert_20000x20000"]["hbm_bytes_per_launch"])
+                # the dominant kernel's own traffic when the profile has it per kernel (else the whole chain's)
+                per = tj.get("per_kernel_20000x20000", {}).get("k_invert_band")
+                traffic = int((per or tj["k_invert_20000x20000"])["hbm_bytes_per_launch"])
+                chain_traffic = int(tj["k_invert_20000x20000"]["hbm_bytes_per_launch"])
         cand_full = int(lut.shape[1] * lut.shape[2])
         evaluated = stats["cand_co"] / max(stats["pixels_co"], 1)
         lane_ops = OPS_PER_CANDIDATE * stats["cand_co"] / world / (chain_ms_max * 1e-3) if args.algo == "pruned" else \
@@ -887,7 +890,8 @@ def main():
                                  "pixels_to_band2_last_launch": tm.get("last_band2_pixels")} if tm.get("band2_kernel_ms", 0.0) > 0.0 else {})),
                          "chain": {"kernels": "k_invert_band + k_invert_band2 + k_invert_list" if second_ms is not None else "k_invert",
                                    "ms": round(chain_ms, 3), "achieved": round(bytes_px * lines * samples / (chain_ms * 1e-3) / 1e9, 3),
-                                   "frac": round(bytes_px * lines * samples / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
+                                   "frac": round(bytes_px * lines * samples / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                                   "traffic": chain_traffic},
                          "step_kernels_ms": round(step_kernels_ms, 3),
                          "note": f"algorithmic raster bytes ({read_px} B read per pixel x rank 0's {lines * samples} px + {bytes_px - read_px} B written per "
                                  "pixel the kernel decides itself, i.e. not handed to k_invert_band2 / k_invert_list) / mean "

@@ -20,6 +20,9 @@ for c in ("FETCH_SIZE","WRITE_SIZE"):
             name="k_detrend" if "k_detrend" in k else ("k_invert" if "k_invert" in k else None)  # k_invert_band + k_invert_list of one inversion are summed
             if name and r["Counter_Name"]==c:
                 vals[name][c]=vals[name].get(c,0.0)+float(r["Counter_Value"])
+                if name=="k_invert":  # and per kernel of the chain (k_invert_band / k_invert_band2 / k_invert_list)
+                    sub=k.split("<")[0].split("::")[-1]
+                    vals[sub][c]=vals[sub].get(c,0.0)+float(r["Counter_Value"])
 n=20000*20000
 cal_read = (4.0*n)/(vals["k_detrend"]["FETCH_SIZE"]*1024)      # true bytes / reported bytes, 4-B-per-lane loads
 cal_write= (8.0*n)/(vals["k_detrend"]["WRITE_SIZE"]*1024)
@@ -29,6 +32,8 @@ out={"raw_KiB":vals,"calibration":{"read_true_over_reported":cal_read,"write_tru
      "k_invert_20000x20000":{"fetch_bytes_reported":inv_r,"write_bytes_reported":inv_w,
       "fetch_bytes_calibrated":inv_r*cal_read,"write_bytes_calibrated":inv_w*cal_write,
       "hbm_bytes_per_launch":inv_r*cal_read+inv_w*cal_write,"algorithmic_bytes_per_launch":24.0*n}}
+out["per_kernel_20000x20000"]={k:{"fetch_bytes_calibrated":v.get("FETCH_SIZE",0.0)*1024*cal_read,"write_bytes_calibrated":v.get("WRITE_SIZE",0.0)*1024*cal_write,
+      "hbm_bytes_per_launch":v.get("FETCH_SIZE",0.0)*1024*cal_read+v.get("WRITE_SIZE",0.0)*1024*cal_write} for k,v in vals.items() if k.startswith("k_invert_")}
 json.dump(out,open(f"{R}/gpurun_out/traffic/summary.json","w"),indent=1)
 print(json.dumps(out,indent=1))
 PY
