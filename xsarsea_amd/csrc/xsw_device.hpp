@@ -449,9 +449,27 @@ __device__ __forceinline__ CoWindow box_from_jub(const DevTables &L, double mag,
 // the windows from 18.4 x 25.2 to 16.2 x 22.8 (directions x speeds) for two short bisections more per pixel
 // (measured, band kernel at 20000^2: 1 ray 93.9 ms; 3 full rays 85.3; side rays seeded, 4 / 3 steps 84.5 / 83.9; 5 and 7 rays 87.7 / 88.8).
 #ifndef XSW_RAY_SIDE_STEPS
-#define XSW_RAY_SIDE_STEPS 3
+#define XSW_RAY_SIDE_STEPS 2
 #endif
-template <int NRAYS = 1, int RAY_D = 2>
+// One probe of a ray: the scores of row pair `mid` (one 16-byte load).  Returns the smaller one; `right` = the second row scores
+// lower than the first (the minimum of a unimodal column lies to the right of the pair's first row).
+__device__ __forceinline__ double ray_probe(const double *__restrict__ ray, int mid, int n_w, double whs, double wh0, double inv_dsig,
+                                            double sn, double ur, bool &right)
+{
+    const double2 v = *(const double2 *)(ray + 2 * mid);  // w_pad is even: the pad row is masked below
+    const double wh_a = fma((double)(2 * mid), whs, wh0), wh_b = wh_a + whs;
+    const double da = fma(v.x, inv_dsig, sn), db = fma(v.y, inv_dsig, sn);
+    const double Ja = fma(da, da, wh_a * (wh_a - ur));
+    const double Jb = (2 * mid + 1 < n_w) ? fma(db, db, wh_b * (wh_b - ur)) : __builtin_inf();
+    right = Jb < Ja;
+    return vmin(Ja, Jb);
+}
+// SEEDED (the band kernels: L.inv_rows is installed): the first ray does not bisect the whole column.  Its minimum lies next to
+// the row where the column crosses the observed sigma0 -- the sigma0 term is steep (dsig_co is a fraction of a dB), the wind
+// term is not -- and the inverse-row table (xsw_band.hpp) has that row: probe its row pair, then gallop away from it (strides
+// 1, 2, 4, ... pairs) for as long as the slope keeps its sign, then bisect what is left.  Every probe is a real candidate, so
+// a column that is not unimodal still only loosens the bound; the trip count is that of the wave's slowest lane.
+template <int NRAYS = 1, int RAY_D = 2, bool SEEDED = false>
 __device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pixel &P, double inv_dsig, double abs_dsig, bool &loose)
 {
     const double inf = __builtin_inf();
@@ -473,19 +491,42 @@ __device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pi
         const int ipr = fin ? min(max(P.ipr + ((q & 1) ? -dq : dq), 0), L.n_phi - 1) : 0;
         const double ur = 2.0 * (ah * L.cphi[ipr] + bh * L.sphi[ipr]);
         const double *__restrict__ ray = L.coT + ((size_t)(fin ? P.i_inc : 0) * L.n_phi + ipr) * L.w_pad;
+        if (SEEDED && q == 0) {
+            int lo = 0, hi = fin ? npairs : 0;
+            int mid = npairs >> 1;
+            if (fin) {
+                const double *g = L.inv_grid + 3 * P.i_inc;
+                const int bin = (int)fmin(fmax((s - g[0]) * g[2], 0.0), (double)(XSW_INV_BINS - 1));
+                mid = min((int)L.inv_rows[((size_t)P.i_inc * XSW_INV_BINS + bin) * L.phi_pad + ipr] >> 1, npairs - 1);
+            }
+            int stride = 1, state = 0;  // state: 0 first probe, 1 galloping right, 2 galloping left, 3 bisecting
+#pragma unroll 1
+            while (__ballot(lo < hi) != 0ULL) {  // wave-uniform; every trip shrinks every open bracket
+                bool right;
+                const double j = ray_probe(ray, mid, L.n_w, whs, wh0, inv_dsig, sn, ur, right);
+                rbest = vmin(rbest, j);
+                const bool open = lo < hi;
+                lo = (open && right) ? mid + 1 : lo;
+                hi = (open && !right) ? mid : hi;
+                state = state == 0 ? (right ? 1 : 2) : ((state == 1 && right) || (state == 2 && !right)) ? state : 3;
+                const int far = state == 1 ? lo + stride - 1 : hi - stride;
+                mid = state == 3 ? (lo + hi) >> 1 : far;
+                mid = min(max(mid, lo), max(hi - 1, 0));
+                stride <<= 1;
+            }
+            seed = lo;
+            continue;
+        }
         // q > 0: any score seen is a valid upper bound, so a side ray may start from a bracket around the first ray's
         // result (the minimum moves by a row or two per degree); a minimum outside the bracket only loosens the bound
         constexpr int half = 1 << (XSW_RAY_SIDE_STEPS - 1);
         int lo = q == 0 ? 0 : max(seed - half, 0), hi = q == 0 ? npairs : min(seed + half, npairs);
         for (int it = (q == 0 ? 32 - __clz(npairs) : XSW_RAY_SIDE_STEPS); it > 0; --it) {  // wave-uniform trip count
             const int mid = min((lo + hi) >> 1, npairs - 1);
-            const double2 v = *(const double2 *)(ray + 2 * mid);  // w_pad is even: the pad row is masked below
-            const double wh_a = fma((double)(2 * mid), whs, wh0), wh_b = wh_a + whs;
-            const double da = fma(v.x, inv_dsig, sn), db = fma(v.y, inv_dsig, sn);
-            const double Ja = fma(da, da, wh_a * (wh_a - ur));
-            const double Jb = (2 * mid + 1 < L.n_w) ? fma(db, db, wh_b * (wh_b - ur)) : inf;
-            const bool open = lo < hi, right = Jb < Ja;
-            rbest = vmin(rbest, vmin(Ja, Jb));
+            bool right;
+            const double j = ray_probe(ray, mid, L.n_w, whs, wh0, inv_dsig, sn, ur, right);
+            rbest = vmin(rbest, j);
+            const bool open = lo < hi;
             lo = (open && right) ? mid + 1 : lo;
             hi = (open && !right) ? mid : hi;
         }
