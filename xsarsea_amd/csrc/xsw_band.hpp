@@ -58,6 +58,12 @@ namespace xsw {
 #ifndef XSW_BAND_NO_VCHECK
 #define XSW_BAND_NO_VCHECK 1  // k_invert_band scores the rows its tables name without comparing them with the band's thresholds
 #endif
+#ifndef XSW_BAND_NO_CLAMP
+#define XSW_BAND_NO_CLAMP 0  // (1: no clamp of the row to the window -- slower, the masked lanes then touch new cache lines: 34.1 vs 33.7 ms)
+#endif
+#ifndef XSW_BAND_HI_MASK
+#define XSW_BAND_HI_MASK 1
+#endif
 #ifndef XSW_BAND_SEEDED
 #define XSW_BAND_SEEDED 1  // first ray seeded from the inverse-row table (co_window_lanes)
 #endif
@@ -187,7 +193,7 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
                 const double h = (double)__builtin_sqrtf((float)fmax(disc, 0.0)) * (1.0 + 1e-6) + 1e-6;
                 const double xc = (Uh - wh0) * inv_whs, xh = fma(h, inv_whs, XSW_CHORD_MRG);
                 const int c_lo = (int)ceil(fmax(xc - xh, -4.0)), c_hi = (int)floor(fmin(xc + xh, 40000.0));
-                r[j] = max(r[j], c_lo);
+                r[j] = max(r[j], min(c_lo, L.n_w));
                 last = disc < 0.0 ? r[j] - 1 : min(last, c_hi);
             }
             nrow[j] = act[j] ? last - r[j] + 1 : 0;
@@ -243,7 +249,9 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 if (left[j] == 0ULL) continue;  // wave-uniform: the j-th directions of this pass have no rows left (often the upper half)
-                const int rc = min(r[j] + t, w_hi);
+                // (a lane past its run -- masked below -- may read past the window, up to XSW_BAND_MAX rows: the table is padded by
+                // 260 rows, xsw.hip; r[j] <= n_w)
+                const int rc = XSW_BAND_NO_CLAMP ? r[j] + t : min(r[j] + t, w_hi);
                 const double v = ld_co(base, off0[j], rc, rowB);
                 // the end rows may lie just outside the band: candidates of the window all the same, so scoring them is harmless
                 // and cheaper than the two comparisons that would mask them (band kernel at 20000^2: 35.65 -> 33.9 ms)
@@ -251,7 +259,8 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
                 const double wh = fma((double)rc, whs, wh0);
                 const double dd = fma(v, inv_dsig, sn);
                 double J = fma(dd, dd, wh * (wh - U[j]));
-                J = inb ? J : inf;
+                // a masked lane scores ~9e307 (finite, above the 1e300 "nothing scored" mark): one select on the high word
+                J = XSW_BAND_HI_MASK ? __hiloint2double(inb ? __double2hiint(J) : 0x7FE00000, __double2loint(J)) : (inb ? J : inf);
                 second = vmin(second, vmax(J, best));
                 const bool lt = J < best;
                 brow = lt ? rc : brow;
