@@ -170,15 +170,15 @@ int xsw_lut_upload(xsw_ctx *ctx, const xsw_lut *co, const xsw_lut *cr);
 /* Replaces _invert_from_model_numpy (windspeed.py:132-331).  Asynchronous on the context's stream
  * when mem == XSW_MEM_DEVICE; synchronous (returns with outputs filled) for host memory.
  * XSW_ALGO_PRUNED on a LUT whose columns rise monotonically with wind speed (every built-in GMF over most of its rows) runs
- * as two launches: k_invert_band decides the pixels its band rule can, k_invert_list the rest from a work list owned by the
- * context (4 bytes per EIGHTH pixel of the largest raster seen; a scene that leaves more than an eighth of its pixels
- * undecided overflows the list, which k_invert_list answers by inverting every tile itself; if the list cannot be allocated
- * the one-kernel path runs); any other LUT, and XSW_ALGO_EXACT, take the general kernel.  (Environment XSW_BAND2=1 inserts a
- * third kernel between the two, k_invert_band2: the band rule on both branches of LUT columns that rise and then fall, for
- * the pixels whose search window leaves the monotone rows; exact, tested, off by default -- it does not pay on CMOD5.N.
- * XSW_WIDE=1 gives the same third kernel its other role: k_invert_band then keeps the search windows of <= 48 directions and
- * hands the wider ones over to be swept in batches at lower occupancy: 1.5x on scenes whose a-priori wind is far from the
- * sigma0 contour, 4 % slower on the benchmark scene, hence off by default too.)
+ * as three launches: k_invert_band decides the pixels its band rule can and hands those whose band holds a long run of rows
+ * along the a-priori direction (XSW_LONG_RUN = 4 or more: one such pixel would hold up every pixel of its pass) to
+ * k_invert_band2, which sweeps long runs only (rows in batches, clipped to the chord of the search disc); k_invert_list does
+ * the rest from a work list owned by the context (two lists of 4 bytes per EIGHTH pixel of the largest raster seen; a scene
+ * that hands on more than an eighth of its pixels overflows a list, which the consumer answers by walking every strip / tile
+ * itself; if the lists cannot be allocated the one-kernel path runs); any other LUT, and XSW_ALGO_EXACT, take the general
+ * kernel.  Environment XSW_LONG_RUN=0 takes k_invert_band2 out of the chain (A/B measurements).  (Environment XSW_BAND2=1
+ * gives the middle kernel another role instead: the band rule on both branches of LUT columns that rise and then fall, for the
+ * pixels whose search window leaves the monotone rows; exact, tested, off by default -- it does not pay on CMOD5.N.)
  * Results do not depend on the route (environment variable XSW_NO_BAND=1 forces the general kernel: A/B measurements). */
 int xsw_invert(xsw_ctx *ctx, const xsw_invert_args *args);
 
@@ -208,7 +208,7 @@ typedef struct {
     double first_kernel_ms;  /* k_invert_band, summed over the launches                               */
     double second_kernel_ms; /* k_invert_list, summed over the launches                               */
     int64_t last_list_pixels;/* pixels the most recent launch left to k_invert_list                   */
-    double band2_kernel_ms;  /* k_invert_band2 (the band rule on rise-then-fall columns, between the two), summed */
+    double band2_kernel_ms;  /* k_invert_band2 (the pixels with long runs of band rows, between the two), summed   */
     int64_t last_band2_pixels;/* pixels the most recent launch handed to k_invert_band2              */
 } xsw_timing;
 int xsw_timing_enable(xsw_ctx *ctx, int on);
