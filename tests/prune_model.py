@@ -307,3 +307,28 @@ def bitonic_band_rows(up, dn, b_lo, b_hi, bins, w_lo, w_hi):
     rise = (max(int(up[b_lo]), w_lo), min(int(up[bh]) - 1, w_hi))
     fall = (max(int(dn[bh]), w_lo), min(int(dn[b_lo]) - 1, w_hi))
     return rise, fall
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Chord clip (round 3, k_invert_band2): the window is only the bounding box of the disc |c - m| <= 2 sqrt(J_ub).  Along one
+# direction e (unit vector), with U = m . e and wh = w / 2:  |w e - m|^2 / 4 = wh^2 - U wh + |m|^2/4 <= J_ub
+#   <=>  |wh - U/2| <= sqrt(U^2/4 - |m|^2/4 + J_ub):  the rows of that direction that can hold the argmin are one interval.
+# The device recovers J_ub from the band's half width (thr_hi - thr_lo) / 2 = band_radius(j_ub, dsig) and takes the square
+# root in float32; the same operations here.
+CHORD_MRG = 2e-3
+
+
+def chord_rows(ah, bh, cphi_e, sphi_e, thr_lo, thr_hi, inv_dsig, w0, inv_wstep):
+    """(c_lo, c_hi) = first and last speed row of direction e inside the (inflated) disc, or None when the ray misses it.
+    ah, bh = m / 2; thr_lo, thr_hi = s -+ d as the slot holds them."""
+    m2 = ah * ah + bh * bh
+    rs = 0.5 * (thr_hi - thr_lo) * abs(inv_dsig)  # >= sqrt(J_ub) (1 + 1e-6)
+    jrel = (rs * rs - m2) + 1e-9 * (rs * rs + m2)
+    uh = ah * cphi_e + bh * sphi_e
+    disc = uh * uh + jrel
+    if disc < 0.0:
+        return None
+    h = float(np.sqrt(np.float32(max(disc, 0.0)))) * (1.0 + 1e-6) + 1e-6
+    inv_whs = 2.0 * inv_wstep
+    xc, xh = (uh - 0.5 * w0) * inv_whs, h * inv_whs + CHORD_MRG
+    return int(np.ceil(max(xc - xh, -4.0))), int(np.floor(min(xc + xh, 40000.0)))

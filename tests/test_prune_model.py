@@ -239,3 +239,42 @@ def test_cmod5n_columns_rise_then_fall():
             assert ok, (inc_ax[i], phi_ax[p])
             falls += P < len(w_ax)
     assert falls > 0
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_chord_rows_contain_the_disc(seed):
+    """k_invert_band2's chord clip: along every direction, every grid speed whose wind term alone is <= j_ub lies inside the
+    clipped row interval (and a direction reported as missing the disc has none) -- also with the disc's boundary exactly on
+    grid points, tiny and huge discs, m at the origin, and J_ub recovered from the rounded band thresholds as on the device."""
+    rng = np.random.default_rng(100 + seed)
+    for case in range(400):
+        n_w, n_phi = int(rng.integers(2, 120)), int(rng.integers(2, 90))
+        w0, wstep = rng.choice([0.2, 0.5, 3.0]), rng.choice([0.1, 0.25, 1.0])
+        w_ax = w0 + wstep * np.arange(n_w)
+        phi_ax = np.linspace(0.0, rng.choice([180.0, 360.0]), n_phi)
+        inv_wstep = (n_w - 1) / (w_ax[-1] - w_ax[0])
+        if case % 3 == 0:  # boundary through grid points
+            mag, R, theta = w_ax[rng.integers(0, n_w)], wstep * rng.integers(0, 12), phi_ax[rng.integers(0, n_phi)]
+        elif case % 7 == 1:
+            mag, R, theta = 0.0, rng.uniform(0, 30), 0.0
+        else:
+            mag, R, theta = rng.uniform(0, 1.3 * w_ax[-1]), rng.uniform(0, 8) ** 2 / 8 * rng.choice([1e-3, 1.0, 1.0, 10.0]), rng.uniform(0, 360)
+        j_true = (R / 2) ** 2
+        a, b = mag * np.cos(np.radians(theta)), mag * np.sin(np.radians(theta))
+        dsig = float(rng.choice([0.01, 0.1, 1.0, 5.0]))
+        s = rng.uniform(-40.0, 5.0)
+        j_ub = j_true * (1.0 + 1e-9) + 1e-9               # co_window_lanes
+        d = pm.band_radius(j_ub, dsig)
+        thr_lo, thr_hi = s - d, s + d                      # what the slot holds (rounded)
+        for ip in range(n_phi):
+            c, sn = np.cos(np.radians(phi_ax[ip])), np.sin(np.radians(phi_ax[ip]))
+            inside = np.nonzero(((w_ax * c - a) ** 2 + (w_ax * sn - b) ** 2) / 4 <= j_true)[0]
+            rows = pm.chord_rows(0.5 * a, 0.5 * b, c, sn, thr_lo, thr_hi, 1.0 / dsig, w0, inv_wstep)
+            if rows is None:
+                assert inside.size == 0, (case, ip, mag, R, theta)
+            else:
+                if inside.size:
+                    assert rows[0] <= inside.min() and inside.max() <= rows[1], (case, ip, mag, R, theta, rows, inside.min(), inside.max())
+                # ... and it is tight: at most two rows of slack at either end (the inflations are ~1e-6 of the radius)
+                kept = max(min(rows[1], n_w - 1) - max(rows[0], 0) + 1, 0)
+                assert kept <= inside.size + 4, (case, ip, mag, R, theta, rows, inside.size)
