@@ -1,4 +1,4 @@
-// Fast path of the branch-and-bound inversion: `k_invert_band` (round 2).  tests/prune_model.py: band_pruned_argmin is its
+// Fast path of the branch-and-bound inversion: `k_invert_band` (round 2) and `k_invert_band2` (round 3).  tests/prune_model.py: band_pruned_argmin is its
 // executable specification.
 //
 // Besides the disc |c - m| <= 2 sqrt(J_ub) of the window (xsw_device.hpp), the sigma0 term bounds the candidates on its
@@ -8,11 +8,14 @@
 // -- 1..4 candidates instead of the 7..40 rows of the window column: 22 (three-ray bound) instead of 552 candidates per
 // pixel on the benchmark scene.
 //
-// Two kernels make one inversion (xsw.hip: launch_invert): this one finishes every pixel the band rule decides and appends
-// the others to a work list (one atomicAdd per wave); `k_invert_list` (the general algorithm: window sweep, exact scan, any
-// LUT) then inverts exactly those (window outside the monotone rows, non-finite inputs, near-ties, bands longer than
-// XSW_BAND_MAX rows, cross-pol pixels the interval rule cannot decide).  Keeping the rare, register-hungry paths out of this
-// kernel is what lets it run at 8 waves per SIMD.
+// Three kernels make one inversion (xsw.hip: launch_invert).  `k_invert_band` finishes every pixel the band rule decides,
+// EXCEPT the pixels whose band holds a long run of rows along the a-priori direction (a pass runs as many trips as its longest
+// run: one such pixel holds up every pixel of its pass): those go on list B for `k_invert_band2`, the same wave body on listed
+// pixels with the rows swept in batches and clipped to the chord of the search disc (ROLE 2 below).  What neither decides is
+// appended to the work list (one atomicAdd per wave) and inverted by `k_invert_list` (the general algorithm: window sweep, exact
+// scan, any LUT): window outside the monotone rows, non-finite inputs, near-ties, bands longer than XSW_BAND_MAX rows, cross-pol
+// pixels the interval rule cannot decide.  Keeping the rare, register-hungry paths out of k_invert_band is what lets it run at
+// 8 waves per SIMD.
 //
 // Finding the interval: a monotone column is inverted ONCE, at LUT install (L.inv_rows: for 2048 dB thresholds per incidence
 // slice, the first row of every direction at or above the threshold; xsw_lutbuild.hpp).  The largest threshold <= s - d
@@ -27,7 +30,8 @@
 // sl + S, ...: every load of a segment reads contiguous words); classes S*K = 4, 6, 8, 12, ..., 96, 128 directions, wider
 // windows loop over chunks in the S = 64 class; on each trip a direction group whose lanes have no rows left is skipped:
 //   * the lane reads its directions' first / last candidate rows from the table, clips them to the window, and scores that
-//     many rows (a row counts if s - d <= LUT <= s + d; scores are formed directly, no forward differences);
+//     many rows (every row the tables name is scored: at most one at either end lies outside s - d <= LUT <= s + d, and it is
+//     a candidate of the window all the same; scores are formed directly, no forward differences);
 //   * segment argmin by DPP; the unique candidate within eps of the minimum is the reference's argmin (same settle rule as
 //     co_box_search); the winner lane writes it next to the slot.  Near-ties, several survivors, runs longer than
 //     XSW_BAND_MAX -> work list.
