@@ -373,6 +373,16 @@ static int install_co(xsw_ctx *c, const xsw_lut *l, const double *d_dense)
             e = hipGetLastError();
         }
         T.mono_rows = d_mono;
+        T.tail_min = nullptr;
+        static const bool tail_off = getenv("XSW_NO_TAIL_CUT") != nullptr;  // A/B measurements only
+        if (e == hipSuccess && !tail_off) {
+            double *d_tail = nullptr;
+            if (hipMalloc((void **)&d_tail, (size_t)nI * sizeof(double) + 64) == hipSuccess) {
+                c->co_allocs.push_back(d_tail);
+                hipLaunchKernelGGL(k_tail_min, dim3((unsigned)nI), dim3(256), 0, c->stream, d_dense, nW, nP, d_mono, d_tail);
+                if (hipGetLastError() == hipSuccess) T.tail_min = d_tail;
+            } else (void)hipGetLastError();
+        }
         // inverse of the monotone rows (co_band_pass starts its sweep from a table look-up instead of a bisection)
         T.inv_rows = nullptr; T.inv_grid = nullptr;
         const size_t inv_n = (size_t)nI * XSW_INV_BINS * ppad;

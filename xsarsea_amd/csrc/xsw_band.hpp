@@ -68,6 +68,12 @@ namespace xsw {
 #ifndef XSW_BAND_HI_MASK
 #define XSW_BAND_HI_MASK 1
 #endif
+#ifndef XSW_LONG_RUN_MAX
+#define XSW_LONG_RUN_MAX 64
+#endif
+#ifndef XSW_LONG_RUN_MAX_CUT
+#define XSW_LONG_RUN_MAX_CUT 24  // ... of a window that was cut at the last monotone row (its band lies on the flat top)
+#endif
 #ifndef XSW_BAND_SEEDED
 #define XSW_BAND_SEEDED 1  // first ray seeded from the inverse-row table (co_window_lanes)
 #endif
@@ -341,14 +347,24 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
         if (todo) {
             bool loose = false;
             const CoWindow W = co_window_lanes<XSW_BAND_RAYS, XSW_BAND_RAY_D, XSW_BAND_SEEDED != 0>(L, P, A.inv_dsig_co, fabs(A.dsig_co), loose);
-            const int nrows_p = W.w_hi - W.w_lo + 1;
+            // A window that reaches past the slice's monotone rows is still the band rule's if no row up there can be in the band:
+            // every LUT value of the rows >= mono_rows (any direction) lies above s + d (L.tail_min: CMOD5.N saturates and then
+            // falls back slowly, so this is the common case of an a-priori wind well above the one sigma0 points to).  Those
+            // rows cannot hold the argmin (their sigma0 term alone exceeds J_ub): the window is cut at the last monotone row.
+            int w_hi_e = W.w_hi;
+            if (!BITONIC && L.tail_min) {
+                const bool fin1 = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0;
+                const int mono1 = L.mono_rows[fin1 ? P.i_inc : 0];
+                if (fin1 && W.w_hi >= mono1 && P.s_co + W.band_d < L.tail_min[P.i_inc]) w_hi_e = mono1 - 1;
+            }
+            const int nrows_p = w_hi_e - W.w_lo + 1;
             ncols_p = W.ip_hi - W.ip_lo + 1;
             const bool need = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0 && !loose && ncols_p >= 1 && nrows_p >= 1;
-            if (ROLE == 2 && strip_walk) skip = !need || !(W.w_hi < L.mono_rows[need ? P.i_inc : 0]);  // everything k_invert_band did not hand over
+            if (ROLE == 2 && strip_walk) skip = !need || !(w_hi_e < L.mono_rows[need ? P.i_inc : 0]);  // everything k_invert_band did not hand over
             if (BITONIC) {
                 eligb = need && L.bitonic_ok[need ? P.i_inc : 0] != 0;  // every column of the slice rises, then falls
             } else {
-                eligb = need && W.w_hi < L.mono_rows[need ? P.i_inc : 0];  // the window stays inside the monotone rows
+                eligb = need && w_hi_e < L.mono_rows[need ? P.i_inc : 0];  // the window stays inside the monotone rows
                 to_bitonic = need && !eligb && L.inv2 != nullptr && L.bitonic_ok[P.i_inc] != 0;
             }
             if (COUNT) cand += (unsigned)__popcll(__ballot(eligb)) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)) + (XSW_BAND_RAYS - 1) * 2 * XSW_RAY_SIDE_STEPS);
@@ -388,10 +404,17 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                     const unsigned short *tab = L.inv_rows + (size_t)P.i_inc * XSW_INV_BINS * L.phi_pad;
                     auto run_at = [&](int ip) {
                         const int ra = (int)tab[(size_t)bin * L.phi_pad + ip];
-                        const int rb = bhi < XSW_INV_BINS ? (int)tab[(size_t)bhi * L.phi_pad + ip] : W.w_hi + 1;
-                        return min(rb - 1, W.w_hi) - max(ra, W.w_lo) + 1;
+                        const int rb = bhi < XSW_INV_BINS ? (int)tab[(size_t)bhi * L.phi_pad + ip] : w_hi_e + 1;
+                        return min(rb - 1, w_hi_e) - max(ra, W.w_lo) + 1;
                     };
                     run = run_at(P.ipr);  // (the window's first and last directions as well: hands over 3.5x the pixels for 2 ms less here, 4 ms more there)
+                }
+                // (a run beyond XSW_LONG_RUN_MAX rows -- the flat top of a saturating GMF -- would overflow k_invert_band2's sweep
+                // after costing it the most: such a pixel goes straight to the general kernel)
+                if (eligb && run > (w_hi_e < W.w_hi ? XSW_LONG_RUN_MAX_CUT : XSW_LONG_RUN_MAX)) {
+                    myc = NC;
+                    eligb = false;
+                    if (ROLE == 2) skip = true;
                 }
                 const bool handed = eligb && run >= A.long_run;
                 if (ROLE == 1 && handed) {  // the second band kernel's
@@ -432,7 +455,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                 const double ah = 0.5 * P.a_re, bh = 0.5 * P.b_eff;
                 b.sn = -P.s_co * A.inv_dsig_co; b.thr_lo = thr_lo; b.thr_hi = thr_hi;
                 b.ah = ah; b.bh = bh; b.m2 = ah * ah + bh * bh;
-                b.inc_bin = P.i_inc | (bin << 16); b.rows = W.w_lo | (W.w_hi << 16); b.ipn = W.ip_lo | (ncols_p << 16);
+                b.inc_bin = P.i_inc | (bin << 16); b.rows = W.w_lo | (w_hi_e << 16); b.ipn = W.ip_lo | (ncols_p << 16);
                 b.bin_hi = bhi < XSW_INV_BINS ? bhi : (BITONIC ? XSW_INV_BINS /* the tabulated +inf threshold */ : -1);
                 slots[pos] = b;
 #ifdef XSW_TIMING_STAGE1_ONLY

@@ -46,6 +46,7 @@ struct DevTables {
     int phi_180;   // windspeed.py:152-156
     int prunable;  // uniform axes, finite LUT: branch-and-bound allowed
     int co_off32;  // the padded co table is < 4 GB: 32-bit byte offsets from its base address every word
+    const double *tail_min;  // [n_inc] the smallest LUT value of rows >= mono_rows[i], any direction (+inf: none); nullable
     const int *mono_rows;  // [n_inc] every column of slice i is non-decreasing in wind speed over rows [0, mono_rows[i]) (band pruning)
     // inverse of the monotone rows (band pruning): inv_rows[i][b][p] = first row r < mono_rows[i] of column p with
     // LUT >= fma(b, inv_grid[3i+1], inv_grid[3i]) (a uniform dB grid per slice, XSW_INV_BINS bins), else mono_rows[i]
@@ -448,6 +449,9 @@ __device__ __forceinline__ CoWindow box_from_jub(const DevTables &L, double mag,
 // grid directions to either side of it (any candidate bounds the minimum from above).  On the benchmark scene that takes
 // the windows from 18.4 x 25.2 to 16.2 x 22.8 (directions x speeds) for two short bisections more per pixel
 // (measured, band kernel at 20000^2: 1 ray 93.9 ms; 3 full rays 85.3; side rays seeded, 4 / 3 steps 84.5 / 83.9; 5 and 7 rays 87.7 / 88.8).
+#ifndef XSW_STRIP_RAYS
+#define XSW_STRIP_RAYS 1  // rays of the upper bound in the general kernel (invert_strip)
+#endif
 #ifndef XSW_RAY_SIDE_STEPS
 #define XSW_RAY_SIDE_STEPS 2
 #endif
@@ -1206,7 +1210,7 @@ __device__ __forceinline__ void invert_strip(const DevTables &L, const KArgs &A,
     unsigned long long relay = 0;  // pixels laid out for a 16/32-lane segment that co_box_search has to lay out again
     if (use_prune && todo) {
         bool loose = false;
-        W = co_window_lanes(L, P, A.inv_dsig_co, fabs(A.dsig_co), loose);
+        W = co_window_lanes<XSW_STRIP_RAYS, 2>(L, P, A.inv_dsig_co, fabs(A.dsig_co), loose);
         if (loose) P.flags &= ~F_CO_FINITE;  // -> exact_scan_co
         const unsigned long long fin_m = __ballot((P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0);
         cand += (unsigned)__popcll(fin_m) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)));
@@ -1312,8 +1316,15 @@ __global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert(DevTa
 // Second kernel of the two-kernel path: inverts the pixels k_invert_band left undecided (A.list, A.list_count), 64 per wave,
 // with the general algorithm.  The pixels are scattered, so their rasters are gathered; they are few (0.2 % on the
 // benchmark scene).  Fixed grid; every wave strides over the list.
+// The compiler's free choice for this kernel is 152 VGPRs (175 dual-pol) = 3 (2) waves per SIMD, and the kernel waits for loads
+// 68 % of the time (rocprofv3, a-priori x 1.6 scene: 5400 VALU wave-instructions and 580 loads per listed pixel, VALU issue 28 %).
+// Capped at 128 VGPRs = 4 waves per SIMD (20 B of spills): list time 562 -> 500 ms on that scene, 19 -> 15 ms on a-priori x 0.6,
+// 18.8 -> 16.0 ms on incidence 17..25 deg; 5 / 6 / 8 waves spill 130-370 B and are faster on some scenes, slower on others.
+#ifndef XSW_LIST_WAVES
+#define XSW_LIST_WAVES 4
+#endif
 template <typename T, typename TO, bool CR>
-__global__ __launch_bounds__(256, XSW_INVERT_WAVES_PER_SIMD) void k_invert_list(DevTables L, KArgs A)
+__global__ __launch_bounds__(256, XSW_LIST_WAVES) void k_invert_list(DevTables L, KArgs A)
 {
     const int lane = threadIdx.x & 63;
     const long long count = (long long)*A.list_count;

@@ -82,6 +82,26 @@ __global__ __launch_bounds__(256) void k_mono_rows(const double *__restrict__ de
     if (first < n_w) atomicMin(&out[i], first);
 }
 
+// tail[i] = the smallest value of slice i in rows >= mono[i], any direction (+inf when every row is monotone): a pixel whose band
+// ends below it has no candidate up there (band_wave: the window is cut at the last monotone row).  One workgroup per slice.
+__global__ __launch_bounds__(256) void k_tail_min(const double *__restrict__ dense, int n_w, int n_phi, const int *__restrict__ mono,
+                                                  double *__restrict__ tail)
+{
+    const int i = blockIdx.x;
+    const double *sl = dense + (size_t)i * n_w * n_phi;
+    const long long k0 = (long long)mono[i] * n_phi, n = (long long)n_w * n_phi;
+    double lo = __builtin_inf();
+    for (long long k = k0 + threadIdx.x; k < n; k += blockDim.x) lo = fmin(lo, sl[k]);
+    __shared__ double slo[256];
+    slo[threadIdx.x] = lo;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) slo[threadIdx.x] = fmin(slo[threadIdx.x], slo[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tail[i] = slo[0];
+}
+
 // dB range of the monotone rows of each slice -> the slice's uniform threshold grid {t0, width, 1 / width}
 __global__ __launch_bounds__(256) void k_inv_range(const double *__restrict__ dense, int n_w, int n_phi, const int *__restrict__ mono,
                                                    double *__restrict__ grid)
