@@ -173,10 +173,10 @@ int xsw_lut_upload(xsw_ctx *ctx, const xsw_lut *co, const xsw_lut *cr);
  * as three launches: k_invert_band decides the pixels its band rule can and hands those whose band holds a long run of rows
  * along the a-priori direction (XSW_LONG_RUN = 4 or more: one such pixel would hold up every pixel of its pass) to
  * k_invert_band2, which sweeps long runs only (rows in batches, clipped to the chord of the search disc); k_invert_list does
- * the rest from a work list owned by the context (two lists of 4 bytes per EIGHTH pixel of the largest raster seen; a scene
- * that hands on more than an eighth of its pixels overflows a list, which the consumer answers by walking every strip / tile
- * itself; if the lists cannot be allocated the one-kernel path runs); any other LUT, and XSW_ALGO_EXACT, take the general
- * kernel.  Environment XSW_LONG_RUN=0 takes k_invert_band2 out of the chain (A/B measurements).  (Environment XSW_BAND2=1
+ * the rest from a work list owned by the context (two lists of 4 bytes per EIGHTH pixel of the largest raster seen, plus two
+ * strip masks of one bit per pixel; a scene that hands on more than an eighth of its pixels overflows a list, which the
+ * consumer answers by walking the strips of the raster and taking exactly the pixels marked in the mask; if the lists cannot
+ * be allocated the one-kernel path runs); any other LUT, and XSW_ALGO_EXACT, take the general kernel.  Environment XSW_LONG_RUN=0 takes k_invert_band2 out of the chain (A/B measurements).  (Environment XSW_BAND2=1
  * gives the middle kernel another role instead: the band rule on both branches of LUT columns that rise and then fall, for the
  * pixels whose search window leaves the monotone rows; exact, tested, off by default -- it does not pay on CMOD5.N.)
  * Results do not depend on the route (environment variable XSW_NO_BAND=1 forces the general kernel: A/B measurements). */

@@ -134,12 +134,19 @@ def mono_rows(slice_wp):
     return int(first.min()) + 1
 
 
+def tail_min(slice_wp, mono, w_hi=None):
+    """Smallest LUT value of the rows mono .. w_hi (default: to the last row), any direction; +inf when there is no such row:
+    numpy restatement of one entry of k_tail_min's table."""
+    hi = slice_wp.shape[0] if w_hi is None else w_hi + 1
+    return float(slice_wp[mono:hi].min()) if mono < hi else np.inf
+
+
 def band_radius(j_ub, dsig):
     """d such that every candidate with ((L - s)/dsig)^2 <= j_ub has |L - s| <= d (inflated: rounding never excludes one)."""
     return abs(dsig) * np.sqrt(j_ub) * (1.0 + 1e-6) + 1e-9
 
 
-def band_pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig, max_len=16):
+def band_pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig, max_len=16, tail_cut=True):
     """Like pruned_argmin, with the band rule on top of the disc window.  Returns (i_wspd, i_phi, n_evaluated, used_band);
     falls back to pruned_argmin when the window leaves the monotone rows, a band is longer than max_len, or the screening
     cannot decide (the device then re-does the pixel with the window sweep)."""
@@ -189,9 +196,15 @@ def band_pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig, 
         r = pruned_argmin(slice_wp, wspd, phi, cphi, sphi, False, s, a, b, dsig)
         return r[0], r[1], r[2], False
 
-    if w_hi >= mono_rows(slice_wp) or ip_hi - ip_lo + 1 > 64:
-        return fallback()
     d = band_radius(j_ub, dsig)
+    mono = mono_rows(slice_wp)
+    if w_hi >= mono and tail_cut and s + d < tail_min(slice_wp, mono, None if tail_cut == "whole" else w_hi):
+        # Tail cut (round 3; band_wave, L.tail_min = k_tail_min at LUT install): the window reaches past the monotone rows, but
+        # every LUT value of the rows mono .. w_hi -- any direction -- lies above s + d, so none of those rows is in the band:
+        # their sigma0 term alone exceeds J_ub.  (tail_cut="whole": the minimum over all the rows >= mono, the first form.)  The window is cut at the last monotone row and the band rule applies to what is left.
+        w_hi = mono - 1
+    if w_hi >= mono or w_hi < w_lo or ip_hi - ip_lo + 1 > 64:
+        return fallback()
     cand = []
     for ip in range(ip_lo, ip_hi + 1):
         c = slice_wp[:, ip]

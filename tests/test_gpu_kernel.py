@@ -668,21 +668,25 @@ for scale, inc_lo, inc_hi in ((1.0, 17.0, 25.0), (1.6, 20.0, 36.0), (2.5, 30.0, 
 """
 
 
-@pytest.mark.parametrize("long_run,list_cap", [(None, None), (None, "300"), ("1", None), ("1", "300"), ("0", None)])
+@pytest.mark.parametrize("long_run,list_cap", [(None, None), (None, "300"), ("1", None), ("1", "300"), ("0", None), (None, "300-nomask")])
 def test_long_run_kernel(long_run, list_cap):
     """The three-kernel chain in a fresh process: k_invert_band hands the pixels whose band holds XSW_LONG_RUN (default 4) or more
     rows along the a-priori direction to k_invert_band2 (batched sweeps clipped to the disc's chord).  Four scenes from friendly
     to far-off a-priori winds == the exhaustive sweep on every pixel -- with the default threshold, with XSW_LONG_RUN=1 (every
     eligible pixel goes through k_invert_band2) and 0 (none does); with list capacities of 300 pixels the strip walk (only the
-    handed pixels are searched again) and the every-tile route of k_invert_list run."""
+    handed pixels are searched again) and the every-tile route of k_invert_list run.  Overflowed lists are replaced by the strip
+    masks (one bit per pixel: only the marked pixels are taken, in tile order); "300-nomask" (XSW_NO_STRIP_MASKS=1) runs the
+    routes without them (stage 1 redone for every pixel / every tile inverted by the general kernel)."""
     import subprocess
     import sys
     from conftest import REPO
-    env = {k: v for k, v in os.environ.items() if k not in ("XSW_LONG_RUN", "XSW_BAND2")}
+    env = {k: v for k, v in os.environ.items() if k not in ("XSW_LONG_RUN", "XSW_BAND2", "XSW_NO_STRIP_MASKS")}
     if long_run is not None:
         env["XSW_LONG_RUN"] = long_run
     if list_cap:
-        env["XSW_LIST_CAP_TEST"] = list_cap
+        env["XSW_LIST_CAP_TEST"] = list_cap.split("-")[0]
+        if list_cap.endswith("nomask"):
+            env["XSW_NO_STRIP_MASKS"] = "1"
     r = subprocess.run([sys.executable, "-c", _BAND2_SCRIPT.format(repo=REPO)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     rows = [l.split() for l in r.stdout.splitlines() if l.startswith("RESULT")]
@@ -696,7 +700,7 @@ def test_long_run_kernel(long_run, list_cap):
         assert any(int(r_[4]) > 0 for r_ in rows), "no pixel was handed to k_invert_band2"
 
 
-@pytest.mark.parametrize("list_cap", [None, "300"])
+@pytest.mark.parametrize("list_cap", [None, "300", "300-nomask"])
 def test_band2_rise_then_fall_columns(list_cap):
     """XSW_BAND2=1 (opt-in, fresh process: read at LUT install): windows that leave the monotone rows of the LUT (high winds at
     near-range incidences, where CMOD5.N saturates and turns over; a-priori winds far above the truth) are handed to
@@ -706,9 +710,11 @@ def test_band2_rise_then_fall_columns(list_cap):
     import subprocess
     import sys
     from conftest import REPO
-    env = dict(os.environ, XSW_BAND2="1")
+    env = dict({k: v for k, v in os.environ.items() if k != "XSW_NO_STRIP_MASKS"}, XSW_BAND2="1")
     if list_cap:
-        env["XSW_LIST_CAP_TEST"] = list_cap
+        env["XSW_LIST_CAP_TEST"] = list_cap.split("-")[0]
+        if list_cap.endswith("nomask"):
+            env["XSW_NO_STRIP_MASKS"] = "1"
     r = subprocess.run([sys.executable, "-c", _BAND2_SCRIPT.format(repo=REPO)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     rows = [l.split() for l in r.stdout.splitlines() if l.startswith("RESULT")]
@@ -716,3 +722,26 @@ def test_band2_rise_then_fall_columns(list_cap):
     for _, scale, diff, launches, b2, _listed in rows:
         assert int(diff) == 0, f"scale {scale}: {diff} values differ from the exhaustive sweep"
         assert int(launches) == 1 and (float(scale) < 1.0 or int(b2) > 0)
+
+
+def test_tail_cut_keeps_saturating_windows_in_the_band_kernels():
+    """Round 3: a window that reaches past the monotone rows of its slice stays with the band rule when no LUT value up there can
+    be in the band (L.tail_min, tests/prune_model.py: tail_cut).  Same four scenes, fresh processes: results == the exhaustive
+    sweep with and without the cut (XSW_NO_TAIL_CUT=1 is the A/B switch), and with the cut fewer pixels of the a-priori x 1.6
+    scene are left to the general kernel (this small scene: 3127 against 3680; the 8e7-pixel scenes of DESIGN 7c: 6 % against 22 %)."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    listed = {}
+    for off in (False, True):
+        env = {k: v for k, v in os.environ.items() if k not in ("XSW_LONG_RUN", "XSW_BAND2", "XSW_NO_TAIL_CUT", "XSW_LIST_CAP_TEST")}
+        if off:
+            env["XSW_NO_TAIL_CUT"] = "1"
+        r = subprocess.run([sys.executable, "-c", _BAND2_SCRIPT.format(repo=REPO)], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        rows = [l.split() for l in r.stdout.splitlines() if l.startswith("RESULT")]
+        assert len(rows) == 4
+        for _, scale, diff, launches, _b2, n_list in rows:
+            assert int(diff) == 0, f"scale {scale}, cut off={off}: {diff} values differ from the exhaustive sweep"
+            listed[(off, float(scale))] = int(n_list)
+    assert listed[(False, 1.6)] < listed[(True, 1.6)] and listed[(False, 2.5)] <= listed[(True, 2.5)], listed

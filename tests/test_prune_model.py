@@ -108,6 +108,41 @@ def test_band_rule_never_excludes_the_argmin(kind):
     assert pm.mono_rows(co[0]) < len(w_ax) and (kind in ("noisy", "rolloff") or pm.mono_rows(co[-1]) == len(w_ax))
 
 
+@pytest.mark.parametrize("kind", ["cmod5n", "rolloff"])
+def test_tail_cut_keeps_saturating_windows_with_the_band_rule(kind):
+    """Round 3: an a-priori wind well above the one sigma0 points to puts the window's upper rows on the saturated top of
+    CMOD5.N (past the monotone rows).  When every LUT value up there lies above s + d the window is cut at the last monotone row
+    (L.tail_min): same argmin as the oracle, and clearly more pixels decided by the band rule than without the cut.  A top that
+    rolls off steeply falls back below the observed sigma0: no cut there."""
+    rng = np.random.default_rng({"cmod5n": 11, "rolloff": 12}[kind])
+    inc_ax, w_ax, phi_ax = np.linspace(18, 30, 7), np.linspace(0.5, 79.5, 396), np.linspace(0, 180, 91)
+    co = 10 * np.log10(gmf.gmf_cmod5n(inc_ax[:, None, None], w_ax[None, :, None], phi_ax[None, None, :]) + 1e-15)
+    if kind == "rolloff":
+        co = co - 0.004 * np.maximum(w_ax[None, :, None] - 30.0, 0.0) ** 2
+    assert all(pm.mono_rows(co[k]) < len(w_ax) for k in range(len(inc_ax)))
+    lco = olut.Lut(co, inc_ax, w_ax, phi_ax, "dB", "x", "co", "VV")
+    p = oinv.Prepared(lco, None)
+    n = 900
+    inc, wt, pt = rng.uniform(18, 30, n), rng.uniform(3, 22, n), rng.uniform(-180, 180, n)
+    s = oinv.to_db(gmf.gmf_cmod5n(inc, wt, pt) * rng.gamma(100, 1 / 100, n))
+    anc = rng.uniform(1.2, 2.6, n) * wt * np.exp(1j * np.deg2rad(pt + rng.normal(0, 10, n)))  # a-priori speed 1.2 .. 2.6 x the truth
+    nan = np.full(n, np.nan)
+    idx = cport.invert_numpy(p, inc, s, nan, nan, anc, return_idx=True, reference_layout=False)[2]
+    cphi, sphi = np.cos(np.radians(phi_ax)), np.sin(np.radians(phi_ax))
+    used_cut = used_plain = 0
+    for i in range(n):
+        ii = np.argmin(np.abs(inc_ax - inc[i]))
+        r = pm.band_pruned_argmin(co[ii], w_ax, phi_ax, cphi, sphi, p.phi_180, s[i], anc[i].real, anc[i].imag, 0.1, max_len=64)
+        assert (r[0], r[1]) == (idx[i, 0], idx[i, 1]), (kind, i, r, idx[i])
+        used_cut += r[3]
+        used_plain += pm.band_pruned_argmin(co[ii], w_ax, phi_ax, cphi, sphi, p.phi_180, s[i], anc[i].real, anc[i].imag, 0.1,
+                                            max_len=64, tail_cut=False)[3]
+    if kind == "cmod5n":
+        assert used_cut > used_plain + 0.05 * n, (used_cut, used_plain)
+    else:  # the rolled-off top falls back below every observed sigma0: the cut must never fire there
+        assert used_cut == used_plain, (used_cut, used_plain)
+
+
 @pytest.mark.parametrize("kind", ["smooth", "quantised", "steps", "flat"])
 def test_inverse_row_table_interval_is_a_tight_superset_of_the_band(kind):
     """The rows a lane reads off the inverse-row table always contain the exact band  {r in window: s - d <= col[r] <= s + d}

@@ -40,6 +40,8 @@ struct xsw_ctx {
     std::vector<hipEvent_t> timing_events;  // quadruples (start, after k_invert_band, after k_invert_band2, end) on the launch stream
     unsigned *d_list = nullptr;  // hand-over k_invert_band -> k_invert_list: [0] = count, [16..] = pixel indices
     size_t list_cap = 0;         // entries (context-owned, grown on demand: an eighth of the largest raster seen)
+    unsigned long long *d_masks = nullptr;  // strip masks (2 x mask_strips words, after the lists in the same allocation)
+    size_t mask_strips = 0;
     double *d_ratio = nullptr;  // detrend ratio row (context-owned, grown on demand)
     size_t ratio_cap = 0;
     void *nesz_scratch = nullptr;  // xsw_nesz_flatten: column partials + means (context-owned, grown on demand)
@@ -377,9 +379,10 @@ static int install_co(xsw_ctx *c, const xsw_lut *l, const double *d_dense)
         static const bool tail_off = getenv("XSW_NO_TAIL_CUT") != nullptr;  // A/B measurements only
         if (e == hipSuccess && !tail_off) {
             double *d_tail = nullptr;
-            if (hipMalloc((void **)&d_tail, (size_t)nI * sizeof(double) + 64) == hipSuccess) {
+            static const int tail_global = getenv("XSW_TAIL_GLOBAL") != nullptr ? 1 : 0;  // A/B: one minimum per slice
+            if (hipMalloc((void **)&d_tail, (size_t)nI * nW * sizeof(double) + 64) == hipSuccess) {
                 c->co_allocs.push_back(d_tail);
-                hipLaunchKernelGGL(k_tail_min, dim3((unsigned)nI), dim3(256), 0, c->stream, d_dense, nW, nP, d_mono, d_tail);
+                hipLaunchKernelGGL(k_tail_min, dim3((unsigned)nI), dim3(256), 0, c->stream, d_dense, nW, nP, d_mono, d_tail, tail_global);
                 if (hipGetLastError() == hipSuccess) T.tail_min = d_tail;
             } else (void)hipGetLastError();
         }
@@ -634,6 +637,8 @@ struct LaunchCtl {
     unsigned *list;    // [0] = count, [16 ..] = entries; nullptr: one-kernel path
     size_t list_cap;   // entries
     bool timing;       // xsw_timing_enable events (context stream only)
+    unsigned long long *masks = nullptr;  // strip masks (KArgs::mask_g, then mask_b), mask_strips words each; nullptr: none
+    size_t mask_strips = 0;
 };
 
 template <typename T, typename TO>
@@ -667,6 +672,10 @@ static int launch_invert(xsw_ctx *c, const KArgs &A, int algo, const LaunchCtl &
         const bool band2 = bitonic2 || wide2;
         if (band2) { B.list_b_count = lc.list + 1; B.list_b = lc.list + 16 + lc.list_cap; B.list_b_cap = B.list_cap; }
         B.long_run = long_run_env;
+        // strip masks: what the consumers walk when a list overflows (only the marked pixels instead of the whole raster)
+        static const bool masks_off = getenv("XSW_NO_STRIP_MASKS") != nullptr;  // A/B measurements and the tests of the old route
+        const size_t nstrips = (size_t)(strips_per_line * A.lines);
+        if (lc.masks && nstrips <= lc.mask_strips && !masks_off) { B.mask_g = lc.masks; B.mask_b = lc.masks + lc.mask_strips; }
         if (hipMemsetAsync(lc.list, 0, 2 * sizeof(unsigned), lc.stream) != hipSuccess) return seterr(err, XSW_EHIP, "work-list reset failed");
         const unsigned list_blocks = (unsigned)std::min<long long>(nblocks, 256 * 8);  // 8 waves per SIMD
         // k_invert_band: x = XCD lane + 8 * line group, y = tile column inside the XCD's range (see the kernel)
@@ -732,17 +741,24 @@ static size_t list_entries_for(long long n)
     if (test_cap) return (size_t)std::max(atoll(test_cap), 16LL);
     return (size_t)std::max<long long>(n / 8, 1 << 16);
 }
-static void ensure_list(xsw_ctx *c, long long n)
+// strips of 64 samples a raster of n pixels in `lines` lines can have, however it is cut (as given, or into lines of 4096)
+static size_t strips_for(long long n, long long lines) { return (size_t)(n / 64 + std::max<long long>(lines, n / 4096) + 64); }
+static void ensure_list(xsw_ctx *c, long long n, long long lines)
 {
-    const size_t want = list_entries_for(n);
-    if (want <= c->list_cap) return;
+    const size_t want = (list_entries_for(n) + 1) & ~(size_t)1, want_strips = strips_for(n, lines);  // even: the masks stay 8-byte aligned
+    if (want <= c->list_cap && want_strips <= c->mask_strips) return;
     (void)hipStreamSynchronize(c->stream);  // the old list may still be in use
     if (c->d_list) (void)hipFree(c->d_list);
     c->d_list = nullptr;
-    c->list_cap = 0;
+    c->d_masks = nullptr;
+    c->list_cap = c->mask_strips = 0;
     static const bool no_list = getenv("XSW_FAIL_LIST_ALLOC") != nullptr;  // tests: the allocation-failure route
-    if (!no_list && hipMalloc((void **)&c->d_list, (2 * want + 16) * sizeof(unsigned)) == hipSuccess) c->list_cap = want;  // lists G and B
-    else { c->d_list = nullptr; (void)hipGetLastError(); }
+    // lists G and B, then the two strip masks (0.25 B per pixel)
+    if (!no_list && hipMalloc((void **)&c->d_list, (2 * want + 16) * sizeof(unsigned) + 2 * want_strips * sizeof(unsigned long long)) == hipSuccess) {
+        c->list_cap = want;
+        c->d_masks = (unsigned long long *)(c->d_list + 16 + 2 * want);
+        c->mask_strips = want_strips;
+    } else { c->d_list = nullptr; (void)hipGetLastError(); }
 }
 
 // ---- grid codes -> complex winds (xsw.h: xsw_expand_codes)
@@ -980,9 +996,9 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
         A.inc = a->inc; A.s_co = a->sigma0_co; A.s_cr = a->sigma0_cr; A.dsig_cr = a->dsig_cr; A.anc = a->anc;
         A.out_co = a->out_co; A.out_cr = a->out_cr; A.out_idx = a->out_idx;
         A.code_co = a->out_code_co; A.code_cr = a->out_code_cr;
-        if (algo == XSW_ALGO_PRUNED) ensure_list(c, n);
+        if (algo == XSW_ALGO_PRUNED) ensure_list(c, n, a->lines);
         std::string err;
-        const LaunchCtl lc{c->stream, c->d_list, c->list_cap, c->timing_on};
+        const LaunchCtl lc{c->stream, c->d_list, c->list_cap, c->timing_on, c->d_masks, c->mask_strips};
         int rc;
         if (a->lines < 16 && n >= (1LL << 16)) {
             // a flat raster (a long vector of pixels: 1-D inputs arrive as one line) is re-cut into lines of 4096 samples + a
@@ -1037,7 +1053,8 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
                  o_dsig = o_cr + (a->sigma0_cr ? pad(max_px * es) : 0), o_anc = o_dsig + (a->dsig_cr ? pad(max_px * es) : 0),
                  o_cc = o_anc + (a->anc ? pad(max_px * es * 2) : 0), o_ccr = o_cc + (want_co ? pad(max_px * 4) : 0),
                  o_end = o_ccr + (want_cr ? pad(max_px * 4) : 0);
-    const size_t list_cap = std::max<size_t>(max_px / 4, 1 << 14), dev_bytes = o_end + (2 * list_cap + 16) * sizeof(unsigned);  // lists G and B
+    const size_t list_cap = std::max<size_t>(max_px / 4, 1 << 14) & ~(size_t)1, mask_strips = strips_for((long long)max_px, lines_per_chunk);
+    const size_t o_masks = o_end + pad((2 * list_cap + 16) * sizeof(unsigned)), dev_bytes = o_masks + 2 * mask_strips * sizeof(unsigned long long);  // lists G and B, strip masks
     const int dtype = a->dtype, out_dtype = a->out_dtype;
     static const bool prof = getenv("XSW_HOST_PROFILE") != nullptr;  // phase times of the pipeline on stderr (experiments)
     std::atomic<long long> t_stage{0}, t_gpu{0}, t_expand{0}, t_reserve{0};
@@ -1083,7 +1100,7 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
         B.anc = a->anc ? w.dev + o_anc : nullptr;
         B.code_co = want_co ? (unsigned *)(w.dev + o_cc) : nullptr;
         B.code_cr = want_cr ? (unsigned *)(w.dev + o_ccr) : nullptr;
-        const LaunchCtl lc{w.s, (unsigned *)(w.dev + o_end), list_cap, false};
+        const LaunchCtl lc{w.s, (unsigned *)(w.dev + o_end), list_cap, false, (unsigned long long *)(w.dev + o_masks), mask_strips};
         rc = dispatch_invert(c, B, dtype, out_dtype, algo, lc, err);
         if (rc) return rc;
         if (o_end > o_cc) e = hipMemcpyAsync(w.pin + o_cc, w.dev + o_cc, o_end - o_cc, hipMemcpyDeviceToHost, w.s);

@@ -321,7 +321,9 @@ __device__ __forceinline__ void list_append(unsigned *__restrict__ count, unsign
 //       2 = the rows swept in batches and clipped to the disc's chord (k_invert_band2 in its default, LONG-RUN role).
 template <typename T, typename TO, bool CR, bool COUNT, bool BITONIC, int ROLE = 0>
 __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, long long i, bool in, int lane, BandSlot *__restrict__ slots,
-                                          int *__restrict__ res_, bool strip_walk = false /* ROLE 2 walking every strip: the short-run pixels are k_invert_band's */)
+                                          int *__restrict__ res_, bool strip_walk = false /* ROLE 2 walking every strip: the short-run pixels are k_invert_band's */,
+                                          long long strip = -1 /* the wave's pixels are strip `strip` of the raster (lane = sample); -1: listed pixels */,
+                                          bool mask_owner = false /* k_invert_band: writes the strip's words of both masks */)
 {
     const double nan = __builtin_nan("");
     int flags, my_flat = -1, my_icr = -1;
@@ -348,14 +350,15 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
             bool loose = false;
             const CoWindow W = co_window_lanes<XSW_BAND_RAYS, XSW_BAND_RAY_D, XSW_BAND_SEEDED != 0>(L, P, A.inv_dsig_co, fabs(A.dsig_co), loose);
             // A window that reaches past the slice's monotone rows is still the band rule's if no row up there can be in the band:
-            // every LUT value of the rows >= mono_rows (any direction) lies above s + d (L.tail_min: CMOD5.N saturates and then
-            // falls back slowly, so this is the common case of an a-priori wind well above the one sigma0 points to).  Those
-            // rows cannot hold the argmin (their sigma0 term alone exceeds J_ub): the window is cut at the last monotone row.
+            // every LUT value of the rows mono_rows .. w_hi (any direction) lies above s + d (L.tail_min[i][w_hi]: CMOD5.N
+            // saturates and then falls back slowly, so this is the common case of an a-priori wind well above the one sigma0
+            // points to).  Those rows cannot hold the argmin (their sigma0 term alone exceeds J_ub): the window is cut at the
+            // last monotone row.
             int w_hi_e = W.w_hi;
             if (!BITONIC && L.tail_min) {
                 const bool fin1 = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0;
                 const int mono1 = L.mono_rows[fin1 ? P.i_inc : 0];
-                if (fin1 && W.w_hi >= mono1 && P.s_co + W.band_d < L.tail_min[P.i_inc]) w_hi_e = mono1 - 1;
+                if (fin1 && W.w_hi >= mono1 && P.s_co + W.band_d < L.tail_min[P.i_inc * L.n_w + W.w_hi]) w_hi_e = mono1 - 1;
             }
             const int nrows_p = w_hi_e - W.w_lo + 1;
             ncols_p = W.ip_hi - W.ip_lo + 1;
@@ -534,8 +537,22 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
     }
     // hand the undecided pixels over: a window that left the monotone rows of a rise-then-fall slice goes to k_invert_band2 (list
     // B, the band rule on both branches of the columns), everything else -- and what k_invert_band2 cannot decide -- to k_invert_list
-    if (!BITONIC && A.list_b) list_append(A.list_b_count, A.list_b, A.list_b_cap, unresolved && to_bitonic, i, lane);
-    list_append(A.list_count, A.list, A.list_cap, unresolved && !(!BITONIC && A.list_b && to_bitonic), i, lane);
+    const bool to_b = !BITONIC && A.list_b && to_bitonic;
+    if (!BITONIC && A.list_b) list_append(A.list_b_count, A.list_b, A.list_b_cap, unresolved && to_b, i, lane);
+    list_append(A.list_count, A.list, A.list_cap, unresolved && !to_b, i, lane);
+    if (A.mask_g) {
+        // the strip masks (KArgs): what a consumer walks when its list has overflowed
+        const unsigned long long mg = __ballot(unresolved && !to_b);
+        if (mask_owner) {  // k_invert_band: every strip's words, every launch (no reset needed)
+            const unsigned long long mb = __ballot(unresolved && to_b);
+            if (lane == 0) { A.mask_g[strip] = mg; A.mask_b[strip] = mb; }
+        } else if (strip >= 0) {  // k_invert_band2 walking the strips of mask_b
+            if (lane == 0 && mg) atomicOr(&A.mask_g[strip], mg);
+        } else if (unresolved && !to_b) {  // k_invert_band2 on listed pixels: one bit per undecided pixel
+            const long long ln = i / A.samples, sm = i - ln * A.samples;
+            atomicOr(&A.mask_g[ln * ((A.samples + 63) >> 6) + (sm >> 6)], 1ULL << (sm & 63));
+        }
+    }
     if (in) {
         if (!unresolved) {
             Pixel Q;  // what store_pixel reads: flags and the ancillary wind (reloaded: not kept live through the passes)
@@ -569,7 +586,7 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, CR ? XSW_BAND_WAVES_CR : XS
     const long long smp = col * 64 + lane;
     const bool in = smp < A.samples;
     const long long i = line * A.samples + (in ? smp : A.samples - 1);
-    band_wave<T, TO, CR, COUNT, false, ROLE>(L, A, i, in, lane, slots[wv], res_[wv]);
+    band_wave<T, TO, CR, COUNT, false, ROLE>(L, A, i, in, lane, slots[wv], res_[wv], false, line * strips_per_line + col, true);
 }
 
 // Second kernel of the three-kernel chain: the pixels k_invert_band left on list B (their window leaves the monotone rows of a
@@ -591,11 +608,19 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND2_WAVES) void k_inv
         // redone for every pixel and only the long-run pixels -- what k_invert_band did not keep -- are searched.
         // (strips in linear order, one per wave: measured 2x faster for this kernel than k_invert_band's XCD-aware tile walk as a
         // grid-stride loop -- the heavy pixels of a scene cluster, and the linear order spreads them over all the waves)
+        // With the strip masks (A.mask_b: the pixels k_invert_band meant) only the marked pixels of the marked strips are taken.
         const long long strips_per_line = (A.samples + 63) >> 6, nstrips = strips_per_line * A.lines;
         for (long long c = (long long)blockIdx.x * XSW_BAND_WG_WAVES + wv; c < nstrips; c += nwaves) {  // wave-uniform
             const long long line = c / strips_per_line, smp = (c - line * strips_per_line) * 64 + lane;
             const bool in = smp < A.samples;
-            band_wave<T, TO, CR, false, BITONIC, BITONIC ? 0 : 2>(L, A, line * A.samples + (in ? smp : A.samples - 1), in, lane, slots[wv], res_[wv], !BITONIC);
+            const long long i = line * A.samples + (in ? smp : A.samples - 1);
+            if (A.mask_b) {
+                const unsigned long long m = A.mask_b[c];  // wave-uniform address
+                if (m != 0ULL)
+                    band_wave<T, TO, CR, false, BITONIC, BITONIC ? 0 : 2>(L, A, i, in && ((m >> lane) & 1ULL) != 0ULL, lane, slots[wv], res_[wv], false, c);
+            } else {
+                band_wave<T, TO, CR, false, BITONIC, BITONIC ? 0 : 2>(L, A, i, in, lane, slots[wv], res_[wv], !BITONIC, c);
+            }
             __builtin_amdgcn_wave_barrier();
         }
         return;

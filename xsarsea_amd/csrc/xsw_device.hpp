@@ -46,7 +46,7 @@ struct DevTables {
     int phi_180;   // windspeed.py:152-156
     int prunable;  // uniform axes, finite LUT: branch-and-bound allowed
     int co_off32;  // the padded co table is < 4 GB: 32-bit byte offsets from its base address every word
-    const double *tail_min;  // [n_inc] the smallest LUT value of rows >= mono_rows[i], any direction (+inf: none); nullable
+    const double *tail_min;  // [n_inc][n_w] the smallest LUT value of rows mono_rows[i] .. r, any direction (+inf: r < mono_rows[i]); nullable
     const int *mono_rows;  // [n_inc] every column of slice i is non-decreasing in wind speed over rows [0, mono_rows[i]) (band pruning)
     // inverse of the monotone rows (band pruning): inv_rows[i][b][p] = first row r < mono_rows[i] of column p with
     // LUT >= fma(b, inv_grid[3i+1], inv_grid[3i]) (a uniform dB grid per slice, XSW_INV_BINS bins), else mono_rows[i]
@@ -89,6 +89,11 @@ struct KArgs {
     unsigned list_cap;          // entries the list holds; the counter runs on past it (overflow: k_invert_list takes every tile)
     unsigned *list_b, *list_b_count;  // list B (nullable): pixels k_invert_band hands to k_invert_band2 (long runs of band rows; rise-then-fall columns)
     unsigned list_b_cap;
+    // one 64-bit word per strip of 64 samples (strip = line * ceil(samples / 64) + strip column; nullable): bit l of mask_g =
+    // pixel l of the strip is left to k_invert_list, of mask_b = handed to k_invert_band2.  Written by k_invert_band for every
+    // strip of every launch (k_invert_band2 ORs its own undecided pixels into mask_g); READ only when a list has overflowed:
+    // the consumer then walks the strips and takes exactly the marked pixels instead of redoing the whole raster.
+    unsigned long long *mask_g, *mask_b;
     int long_run;               // k_invert_band, ROLE 1: rows along the a-priori direction from which a pixel is handed to k_invert_band2
     long long n, lines, samples;
     double dsig_co, inv_dsig_co, dsig_cr_scalar;
@@ -1333,6 +1338,8 @@ __global__ __launch_bounds__(256, XSW_LIST_WAVES) void k_invert_list(DevTables L
         // the list overflowed (k_invert_band kept counting but could not append): its pixels are unknown, so every tile of the
         // raster is inverted by the general algorithm -- k_invert's tile walk as a grid-stride loop.  Results do not depend on
         // which kernel wrote a pixel; only scenes that defeat the band rule wholesale come here.
+        // With the strip masks (A.mask_g: which pixels of every strip the band kernels left undecided) only those pixels are
+        // inverted -- in tile order, rasters read in place; without them (no room for the masks) every pixel is.
         const long long strips_per_line = (A.samples + 63) >> 6, line_groups = (A.lines + 3) >> 2;
         const long long cols_per_xcd = (strips_per_line + 7) >> 3, nb = 8 * cols_per_xcd * line_groups;
         for (long long b = blockIdx.x; b < nb; b += gridDim.x) {
@@ -1341,8 +1348,13 @@ __global__ __launch_bounds__(256, XSW_LIST_WAVES) void k_invert_list(DevTables L
             const long long line = (j % line_groups) * 4 + (threadIdx.x >> 6);
             if (col >= strips_per_line || line >= A.lines) continue;  // wave-uniform
             const long long smp = col * 64 + lane;
-            const bool in = smp < A.samples;
-            invert_strip<T, TO, 1, CR>(L, A, line * A.samples + (in ? smp : A.samples - 1), in, lane);
+            bool in = smp < A.samples;
+            if (A.mask_g) {
+                const unsigned long long m = A.mask_g[line * strips_per_line + col];  // wave-uniform address
+                if (m == 0ULL) continue;
+                in = in && ((m >> lane) & 1ULL) != 0ULL;
+            }
+            invert_strip<T, TO, 1, CR>(L, A, line * A.samples + (smp < A.samples ? smp : A.samples - 1), in, lane);
         }
         return;
     }

@@ -82,24 +82,30 @@ __global__ __launch_bounds__(256) void k_mono_rows(const double *__restrict__ de
     if (first < n_w) atomicMin(&out[i], first);
 }
 
-// tail[i] = the smallest value of slice i in rows >= mono[i], any direction (+inf when every row is monotone): a pixel whose band
-// ends below it has no candidate up there (band_wave: the window is cut at the last monotone row).  One workgroup per slice.
+// tail[i][r] = the smallest value of slice i in rows mono[i] .. r, any direction (+inf for r < mono[i]): a pixel whose band ends
+// below tail[i][w_hi] has no candidate in the rows of its window past the monotone ones (band_wave: the window is cut at the last
+// monotone row).  One workgroup per slice: row minima over the directions, then a running minimum over the rows.
+// whole_tail (A/B, XSW_TAIL_GLOBAL=1): every row >= mono[i] holds the minimum over ALL the rows past the monotone ones.
 __global__ __launch_bounds__(256) void k_tail_min(const double *__restrict__ dense, int n_w, int n_phi, const int *__restrict__ mono,
-                                                  double *__restrict__ tail)
+                                                  double *__restrict__ tail, int whole_tail)
 {
-    const int i = blockIdx.x;
+    const int i = blockIdx.x, m = mono[i];
     const double *sl = dense + (size_t)i * n_w * n_phi;
-    const long long k0 = (long long)mono[i] * n_phi, n = (long long)n_w * n_phi;
-    double lo = __builtin_inf();
-    for (long long k = k0 + threadIdx.x; k < n; k += blockDim.x) lo = fmin(lo, sl[k]);
-    __shared__ double slo[256];
-    slo[threadIdx.x] = lo;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) slo[threadIdx.x] = fmin(slo[threadIdx.x], slo[threadIdx.x + st]);
-        __syncthreads();
+    double *out = tail + (size_t)i * n_w;
+    const double inf = __builtin_inf();
+    for (int r = threadIdx.x; r < n_w; r += blockDim.x) {
+        double lo = inf;
+        if (r >= m)
+            for (int p = 0; p < n_phi; ++p) lo = fmin(lo, sl[(size_t)r * n_phi + p]);
+        out[r] = lo;
     }
-    if (threadIdx.x == 0) tail[i] = slo[0];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double run = inf;
+        for (int r = 0; r < n_w; ++r) { run = fmin(run, out[r]); out[r] = run; }
+        if (whole_tail)
+            for (int r = m; r < n_w; ++r) out[r] = run;
+    }
 }
 
 // dB range of the monotone rows of each slice -> the slice's uniform threshold grid {t0, width, 1 / width}
