@@ -134,11 +134,11 @@ def mono_rows(slice_wp):
     return int(first.min()) + 1
 
 
-def tail_min(slice_wp, mono, w_hi=None):
-    """Smallest LUT value of the rows mono .. w_hi (default: to the last row), any direction; +inf when there is no such row:
-    numpy restatement of one entry of k_tail_min's table."""
-    hi = slice_wp.shape[0] if w_hi is None else w_hi + 1
-    return float(slice_wp[mono:hi].min()) if mono < hi else np.inf
+def tail_min(slice_wp, mono, ip_lo=None, ip_hi=None):
+    """Smallest LUT value of the rows >= mono in the directions ip_lo .. ip_hi (default: all of them); +inf when every row is
+    monotone: what a query of k_tail_min's sparse table returns."""
+    cols = slice(None) if ip_lo is None else slice(ip_lo, ip_hi + 1)
+    return float(slice_wp[mono:, cols].min()) if mono < slice_wp.shape[0] else np.inf
 
 
 def band_radius(j_ub, dsig):
@@ -198,10 +198,10 @@ def band_pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig, 
 
     d = band_radius(j_ub, dsig)
     mono = mono_rows(slice_wp)
-    if w_hi >= mono and tail_cut and s + d < tail_min(slice_wp, mono, None if tail_cut == "whole" else w_hi):
+    if w_hi >= mono and tail_cut and s + d < (tail_min(slice_wp, mono) if tail_cut == "whole" else tail_min(slice_wp, mono, ip_lo, ip_hi)):
         # Tail cut (round 3; band_wave, L.tail_min = k_tail_min at LUT install): the window reaches past the monotone rows, but
-        # every LUT value of the rows mono .. w_hi -- any direction -- lies above s + d, so none of those rows is in the band:
-        # their sigma0 term alone exceeds J_ub.  (tail_cut="whole": the minimum over all the rows >= mono, the first form.)  The window is cut at the last monotone row and the band rule applies to what is left.
+        # every LUT value of the rows >= mono in the window's directions lies above s + d, so none of those rows is in the band:
+        # their sigma0 term alone exceeds J_ub.  (tail_cut="whole": the minimum over all the directions, the first form.)  The window is cut at the last monotone row and the band rule applies to what is left.
         w_hi = mono - 1
     if w_hi >= mono or w_hi < w_lo or ip_hi - ip_lo + 1 > 64:
         return fallback()

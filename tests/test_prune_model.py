@@ -129,7 +129,7 @@ def test_tail_cut_keeps_saturating_windows_with_the_band_rule(kind):
     nan = np.full(n, np.nan)
     idx = cport.invert_numpy(p, inc, s, nan, nan, anc, return_idx=True, reference_layout=False)[2]
     cphi, sphi = np.cos(np.radians(phi_ax)), np.sin(np.radians(phi_ax))
-    used_cut = used_plain = 0
+    used_cut = used_plain = used_whole = 0
     for i in range(n):
         ii = np.argmin(np.abs(inc_ax - inc[i]))
         r = pm.band_pruned_argmin(co[ii], w_ax, phi_ax, cphi, sphi, p.phi_180, s[i], anc[i].real, anc[i].imag, 0.1, max_len=64)
@@ -137,10 +137,12 @@ def test_tail_cut_keeps_saturating_windows_with_the_band_rule(kind):
         used_cut += r[3]
         used_plain += pm.band_pruned_argmin(co[ii], w_ax, phi_ax, cphi, sphi, p.phi_180, s[i], anc[i].real, anc[i].imag, 0.1,
                                             max_len=64, tail_cut=False)[3]
-    if kind == "cmod5n":
-        assert used_cut > used_plain + 0.05 * n, (used_cut, used_plain)
+        used_whole += pm.band_pruned_argmin(co[ii], w_ax, phi_ax, cphi, sphi, p.phi_180, s[i], anc[i].real, anc[i].imag, 0.1,
+                                            max_len=64, tail_cut="whole")[3]
+    if kind == "cmod5n":  # and the minimum over the window's own directions cuts more windows than the one over all directions
+        assert used_cut > used_whole > used_plain + 0.05 * n, (used_cut, used_whole, used_plain)
     else:  # the rolled-off top falls back below every observed sigma0: the cut must never fire there
-        assert used_cut == used_plain, (used_cut, used_plain)
+        assert used_cut == used_whole == used_plain, (used_cut, used_whole, used_plain)
 
 
 @pytest.mark.parametrize("kind", ["smooth", "quantised", "steps", "flat"])

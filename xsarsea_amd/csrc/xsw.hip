@@ -380,9 +380,9 @@ static int install_co(xsw_ctx *c, const xsw_lut *l, const double *d_dense)
         if (e == hipSuccess && !tail_off) {
             double *d_tail = nullptr;
             static const int tail_global = getenv("XSW_TAIL_GLOBAL") != nullptr ? 1 : 0;  // A/B: one minimum per slice
-            if (hipMalloc((void **)&d_tail, (size_t)nI * nW * sizeof(double) + 64) == hipSuccess) {
+            if (hipMalloc((void **)&d_tail, (size_t)nI * (XSW_TAIL_LEVELS + 1) * ppad * sizeof(double) + 64) == hipSuccess) {
                 c->co_allocs.push_back(d_tail);
-                hipLaunchKernelGGL(k_tail_min, dim3((unsigned)nI), dim3(256), 0, c->stream, d_dense, nW, nP, d_mono, d_tail, tail_global);
+                hipLaunchKernelGGL(k_tail_min, dim3((unsigned)nI), dim3(256), 0, c->stream, d_dense, nW, nP, (int)ppad, d_mono, d_tail, tail_global);
                 if (hipGetLastError() == hipSuccess) T.tail_min = d_tail;
             } else (void)hipGetLastError();
         }
@@ -675,7 +675,10 @@ static int launch_invert(xsw_ctx *c, const KArgs &A, int algo, const LaunchCtl &
         // strip masks: what the consumers walk when a list overflows (only the marked pixels instead of the whole raster)
         static const bool masks_off = getenv("XSW_NO_STRIP_MASKS") != nullptr;  // A/B measurements and the tests of the old route
         const size_t nstrips = (size_t)(strips_per_line * A.lines);
-        if (lc.masks && nstrips <= lc.mask_strips && !masks_off) { B.mask_g = lc.masks; B.mask_b = lc.masks + lc.mask_strips; }
+        if (lc.masks && nstrips <= lc.mask_strips && !masks_off) {
+            B.mask_g = lc.masks; B.mask_b = lc.masks + nstrips;  // side by side: one reset (0.25 B per pixel)
+            if (hipMemsetAsync(lc.masks, 0, 2 * nstrips * sizeof(unsigned long long), lc.stream) != hipSuccess) return seterr(err, XSW_EHIP, "strip-mask reset failed");
+        }
         if (hipMemsetAsync(lc.list, 0, 2 * sizeof(unsigned), lc.stream) != hipSuccess) return seterr(err, XSW_EHIP, "work-list reset failed");
         const unsigned list_blocks = (unsigned)std::min<long long>(nblocks, 256 * 8);  // 8 waves per SIMD
         // k_invert_band: x = XCD lane + 8 * line group, y = tile column inside the XCD's range (see the kernel)

@@ -300,15 +300,30 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
 
 // Compact append of the wave's flagged pixels to a work list: one atomicAdd per wave.  Past the capacity the counter keeps
 // running (the consumer sees count > cap and falls back to inverting every tile: k_invert_list).
-__device__ __forceinline__ void list_append(unsigned *__restrict__ count, unsigned *__restrict__ list, unsigned cap, bool flag, long long i, int lane)
+// Returns true for a lane whose pixel did not fit (the caller marks it in the strip mask instead).
+__device__ __forceinline__ bool list_append(unsigned *__restrict__ count, unsigned *__restrict__ list, unsigned cap, bool flag, long long i, int lane)
 {
     const unsigned long long um = __ballot(flag);
-    if (!um) return;
+    if (!um) return false;
     unsigned base = 0;
     if (lane == 0) base = atomicAdd(count, (unsigned)__popcll(um));
     base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
     const unsigned at = base + __builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
     if (flag && at < cap) list[at] = (unsigned)i;
+    return flag && at >= cap;
+}
+// Marks pixel i (lanes with `flag`) in a strip mask: one atomicOr per wave when the wave's pixels are strip `strip` of the raster
+// (lane = sample), one per pixel when they are listed pixels.
+__device__ __forceinline__ void mask_mark(unsigned long long *__restrict__ mask, bool flag, long long i, long long strip, long long samples, int lane)
+{
+    const unsigned long long m = __ballot(flag);
+    if (!m) return;
+    if (strip >= 0) {
+        if (lane == 0) atomicOr(&mask[strip], m);
+    } else if (flag) {
+        const long long ln = i / samples, sm = i - ln * samples;
+        atomicOr(&mask[ln * ((samples + 63) >> 6) + (sm >> 6)], 1ULL << (sm & 63));
+    }
 }
 
 // One wave's 64 pixels (lane l: pixel i, `in` = the lane has one) through stage 1, the band passes, the cross-pol phase and the
@@ -322,8 +337,7 @@ __device__ __forceinline__ void list_append(unsigned *__restrict__ count, unsign
 template <typename T, typename TO, bool CR, bool COUNT, bool BITONIC, int ROLE = 0>
 __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, long long i, bool in, int lane, BandSlot *__restrict__ slots,
                                           int *__restrict__ res_, bool strip_walk = false /* ROLE 2 walking every strip: the short-run pixels are k_invert_band's */,
-                                          long long strip = -1 /* the wave's pixels are strip `strip` of the raster (lane = sample); -1: listed pixels */,
-                                          bool mask_owner = false /* k_invert_band: writes the strip's words of both masks */)
+                                          long long strip = -1 /* the wave's pixels are strip `strip` of the raster (lane = sample); -1: listed pixels */)
 {
     const double nan = __builtin_nan("");
     int flags, my_flat = -1, my_icr = -1;
@@ -350,15 +364,20 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
             bool loose = false;
             const CoWindow W = co_window_lanes<XSW_BAND_RAYS, XSW_BAND_RAY_D, XSW_BAND_SEEDED != 0>(L, P, A.inv_dsig_co, fabs(A.dsig_co), loose);
             // A window that reaches past the slice's monotone rows is still the band rule's if no row up there can be in the band:
-            // every LUT value of the rows mono_rows .. w_hi (any direction) lies above s + d (L.tail_min[i][w_hi]: CMOD5.N
-            // saturates and then falls back slowly, so this is the common case of an a-priori wind well above the one sigma0
-            // points to).  Those rows cannot hold the argmin (their sigma0 term alone exceeds J_ub): the window is cut at the
-            // last monotone row.
+            // every LUT value of the rows >= mono_rows in the window's directions lies above s + d (L.tail_min, a sparse table over
+            // the directions: CMOD5.N saturates and then falls back slowly, so this is the common case of an a-priori wind well
+            // above the one sigma0 points to; upwind and crosswind saturate several dB apart, hence per direction).  Those rows
+            // cannot hold the argmin (their sigma0 term alone exceeds J_ub): the window is cut at the last monotone row.
             int w_hi_e = W.w_hi;
             if (!BITONIC && L.tail_min) {
                 const bool fin1 = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0;
                 const int mono1 = L.mono_rows[fin1 ? P.i_inc : 0];
-                if (fin1 && W.w_hi >= mono1 && P.s_co + W.band_d < L.tail_min[P.i_inc * L.n_w + W.w_hi]) w_hi_e = mono1 - 1;
+                if (fin1 && W.w_hi >= mono1 && W.ip_hi >= W.ip_lo) {
+                    const int len = W.ip_hi - W.ip_lo + 1, k = min(31 - __clz(len), XSW_TAIL_LEVELS);
+                    const double *tk = L.tail_min + ((size_t)P.i_inc * (XSW_TAIL_LEVELS + 1) + k) * L.phi_pad;
+                    const double lo = fmin(tk[W.ip_lo], tk[k < XSW_TAIL_LEVELS ? W.ip_hi - (1 << k) + 1 : W.ip_lo]);
+                    if (P.s_co + W.band_d < lo) w_hi_e = mono1 - 1;
+                }
             }
             const int nrows_p = w_hi_e - W.w_lo + 1;
             ncols_p = W.ip_hi - W.ip_lo + 1;
@@ -538,20 +557,14 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
     // hand the undecided pixels over: a window that left the monotone rows of a rise-then-fall slice goes to k_invert_band2 (list
     // B, the band rule on both branches of the columns), everything else -- and what k_invert_band2 cannot decide -- to k_invert_list
     const bool to_b = !BITONIC && A.list_b && to_bitonic;
-    if (!BITONIC && A.list_b) list_append(A.list_b_count, A.list_b, A.list_b_cap, unresolved && to_b, i, lane);
-    list_append(A.list_count, A.list, A.list_cap, unresolved && !to_b, i, lane);
+    // (a pixel that does not fit into its list is marked in the list's strip mask instead: the consumer takes the list, then the
+    // marked pixels -- KArgs::mask_g / mask_b, zeroed before every launch, touched only when a list overflows)
+    bool drop_b = false;
+    if (!BITONIC && A.list_b) drop_b = list_append(A.list_b_count, A.list_b, A.list_b_cap, unresolved && to_b, i, lane);
+    const bool drop_g = list_append(A.list_count, A.list, A.list_cap, unresolved && !to_b, i, lane);
     if (A.mask_g) {
-        // the strip masks (KArgs): what a consumer walks when its list has overflowed
-        const unsigned long long mg = __ballot(unresolved && !to_b);
-        if (mask_owner) {  // k_invert_band: every strip's words, every launch (no reset needed)
-            const unsigned long long mb = __ballot(unresolved && to_b);
-            if (lane == 0) { A.mask_g[strip] = mg; A.mask_b[strip] = mb; }
-        } else if (strip >= 0) {  // k_invert_band2 walking the strips of mask_b
-            if (lane == 0 && mg) atomicOr(&A.mask_g[strip], mg);
-        } else if (unresolved && !to_b) {  // k_invert_band2 on listed pixels: one bit per undecided pixel
-            const long long ln = i / A.samples, sm = i - ln * A.samples;
-            atomicOr(&A.mask_g[ln * ((A.samples + 63) >> 6) + (sm >> 6)], 1ULL << (sm & 63));
-        }
+        if (!BITONIC && A.list_b) mask_mark(A.mask_b, drop_b, i, strip, A.samples, lane);
+        mask_mark(A.mask_g, drop_g, i, strip, A.samples, lane);
     }
     if (in) {
         if (!unresolved) {
@@ -586,7 +599,7 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, CR ? XSW_BAND_WAVES_CR : XS
     const long long smp = col * 64 + lane;
     const bool in = smp < A.samples;
     const long long i = line * A.samples + (in ? smp : A.samples - 1);
-    band_wave<T, TO, CR, COUNT, false, ROLE>(L, A, i, in, lane, slots[wv], res_[wv], false, line * strips_per_line + col, true);
+    band_wave<T, TO, CR, COUNT, false, ROLE>(L, A, i, in, lane, slots[wv], res_[wv], false, line * strips_per_line + col);
 }
 
 // Second kernel of the three-kernel chain: the pixels k_invert_band left on list B (their window leaves the monotone rows of a
@@ -601,36 +614,41 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND2_WAVES) void k_inv
     __shared__ int res_[XSW_BAND_WG_WAVES][64];
     const long long count = (long long)*A.list_b_count;
     const long long nwaves = (long long)gridDim.x * XSW_BAND_WG_WAVES;
-    if (count > (long long)A.list_b_cap) {
-        // list B overflowed (k_invert_band kept counting but could not append): which pixels it meant is unknown, so this kernel
-        // walks EVERY strip of the raster.  Rise-then-fall role: every pixel goes through the rule (it holds for monotone windows
-        // as well: their falling runs are empty; results do not depend on which kernel wrote a pixel).  Long-run role: stage 1 is
-        // redone for every pixel and only the long-run pixels -- what k_invert_band did not keep -- are searched.
-        // (strips in linear order, one per wave: measured 2x faster for this kernel than k_invert_band's XCD-aware tile walk as a
-        // grid-stride loop -- the heavy pixels of a scene cluster, and the linear order spreads them over all the waves)
-        // With the strip masks (A.mask_b: the pixels k_invert_band meant) only the marked pixels of the marked strips are taken.
-        const long long strips_per_line = (A.samples + 63) >> 6, nstrips = strips_per_line * A.lines;
+    const long long strips_per_line = (A.samples + 63) >> 6, nstrips = strips_per_line * A.lines;
+    if (count > (long long)A.list_b_cap && !A.mask_b) {
+        // list B overflowed (k_invert_band kept counting but could not append) and there are no strip masks: which pixels it meant
+        // is unknown, so this kernel walks EVERY strip of the raster.  Rise-then-fall role: every pixel goes through the rule (it
+        // holds for monotone windows as well: their falling runs are empty; results do not depend on which kernel wrote a pixel).
+        // Long-run role: stage 1 is redone for every pixel and only the long-run pixels -- what k_invert_band did not keep -- are
+        // searched.  (strips in linear order, one per wave: measured 2x faster for this kernel than k_invert_band's XCD-aware tile
+        // walk as a grid-stride loop -- the heavy pixels of a scene cluster, and the linear order spreads them over all the waves)
         for (long long c = (long long)blockIdx.x * XSW_BAND_WG_WAVES + wv; c < nstrips; c += nwaves) {  // wave-uniform
             const long long line = c / strips_per_line, smp = (c - line * strips_per_line) * 64 + lane;
             const bool in = smp < A.samples;
-            const long long i = line * A.samples + (in ? smp : A.samples - 1);
-            if (A.mask_b) {
-                const unsigned long long m = A.mask_b[c];  // wave-uniform address
-                if (m != 0ULL)
-                    band_wave<T, TO, CR, false, BITONIC, BITONIC ? 0 : 2>(L, A, i, in && ((m >> lane) & 1ULL) != 0ULL, lane, slots[wv], res_[wv], false, c);
-            } else {
-                band_wave<T, TO, CR, false, BITONIC, BITONIC ? 0 : 2>(L, A, i, in, lane, slots[wv], res_[wv], !BITONIC, c);
-            }
+            band_wave<T, TO, CR, false, BITONIC, BITONIC ? 0 : 2>(L, A, line * A.samples + (in ? smp : A.samples - 1), in, lane, slots[wv], res_[wv], !BITONIC, c);
             __builtin_amdgcn_wave_barrier();
         }
         return;
     }
-    for (long long c = (long long)blockIdx.x * XSW_BAND_WG_WAVES + wv; c * 64 < count; c += nwaves) {  // wave-uniform
+    const long long nlist = count < (long long)A.list_b_cap ? count : (long long)A.list_b_cap;
+    for (long long c = (long long)blockIdx.x * XSW_BAND_WG_WAVES + wv; c * 64 < nlist; c += nwaves) {  // wave-uniform
         const long long k = c * 64 + lane;
-        const bool in = k < count;
-        const long long i = (long long)A.list_b[in ? k : count - 1];
+        const bool in = k < nlist;
+        const long long i = (long long)A.list_b[in ? k : nlist - 1];
         band_wave<T, TO, CR, false, BITONIC, BITONIC ? 0 : 2>(L, A, i, in, lane, slots[wv], res_[wv]);
         __builtin_amdgcn_wave_barrier();
+    }
+    if (count > (long long)A.list_b_cap) {
+        // the pixels that did not fit into list B are marked in mask_b: the marked pixels of the marked strips, in linear order
+        for (long long c = (long long)blockIdx.x * XSW_BAND_WG_WAVES + wv; c < nstrips; c += nwaves) {  // wave-uniform
+            const unsigned long long m = A.mask_b[c];  // wave-uniform address
+            if (m == 0ULL) continue;
+            const long long line = c / strips_per_line, smp = (c - line * strips_per_line) * 64 + lane;
+            const bool in = smp < A.samples;
+            band_wave<T, TO, CR, false, BITONIC, BITONIC ? 0 : 2>(L, A, line * A.samples + (in ? smp : A.samples - 1), in && ((m >> lane) & 1ULL) != 0ULL, lane,
+                                                                 slots[wv], res_[wv], false, c);
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 

@@ -46,7 +46,7 @@ struct DevTables {
     int phi_180;   // windspeed.py:152-156
     int prunable;  // uniform axes, finite LUT: branch-and-bound allowed
     int co_off32;  // the padded co table is < 4 GB: 32-bit byte offsets from its base address every word
-    const double *tail_min;  // [n_inc][n_w] the smallest LUT value of rows mono_rows[i] .. r, any direction (+inf: r < mono_rows[i]); nullable
+    const double *tail_min;  // [n_inc][XSW_TAIL_LEVELS + 1][phi_pad] sparse table over the directions of the smallest LUT value in rows >= mono_rows[i] (k_tail_min); nullable
     const int *mono_rows;  // [n_inc] every column of slice i is non-decreasing in wind speed over rows [0, mono_rows[i]) (band pruning)
     // inverse of the monotone rows (band pruning): inv_rows[i][b][p] = first row r < mono_rows[i] of column p with
     // LUT >= fma(b, inv_grid[3i+1], inv_grid[3i]) (a uniform dB grid per slice, XSW_INV_BINS bins), else mono_rows[i]
@@ -78,6 +78,9 @@ struct DevTables {
     double inc_cr0, inv_inccrstep;
 };
 
+#ifndef XSW_TAIL_LEVELS
+#define XSW_TAIL_LEVELS 7  // levels of the sparse table of tail minima (DevTables::tail_min): windows of up to 2^7 - 1 directions
+#endif
 struct KArgs {
     const void *inc, *s_co, *s_cr, *dsig_cr, *anc;
     void *out_co, *out_cr;
@@ -90,9 +93,10 @@ struct KArgs {
     unsigned *list_b, *list_b_count;  // list B (nullable): pixels k_invert_band hands to k_invert_band2 (long runs of band rows; rise-then-fall columns)
     unsigned list_b_cap;
     // one 64-bit word per strip of 64 samples (strip = line * ceil(samples / 64) + strip column; nullable): bit l of mask_g =
-    // pixel l of the strip is left to k_invert_list, of mask_b = handed to k_invert_band2.  Written by k_invert_band for every
-    // strip of every launch (k_invert_band2 ORs its own undecided pixels into mask_g); READ only when a list has overflowed:
-    // the consumer then walks the strips and takes exactly the marked pixels instead of redoing the whole raster.
+    // pixel l of the strip is left to k_invert_list, of mask_b = handed to k_invert_band2, and DID NOT FIT into the list.  Zeroed
+    // before every launch; a producer ORs a pixel in only when its append falls past the list's capacity, the consumer takes
+    // the list and then -- if the counter ran past the capacity -- the marked pixels of the marked strips, instead of redoing
+    // the whole raster.
     unsigned long long *mask_g, *mask_b;
     int long_run;               // k_invert_band, ROLE 1: rows along the a-priori direction from which a pixel is handed to k_invert_band2
     long long n, lines, samples;
@@ -1334,42 +1338,51 @@ __global__ __launch_bounds__(256, XSW_LIST_WAVES) void k_invert_list(DevTables L
     const int lane = threadIdx.x & 63;
     const long long count = (long long)*A.list_count;
     const long long nwaves = (long long)gridDim.x * 4;
-    if (count > (long long)A.list_cap) {
-        // the list overflowed (k_invert_band kept counting but could not append): its pixels are unknown, so every tile of the
-        // raster is inverted by the general algorithm -- k_invert's tile walk as a grid-stride loop.  Results do not depend on
-        // which kernel wrote a pixel; only scenes that defeat the band rule wholesale come here.
-        // With the strip masks (A.mask_g: which pixels of every strip the band kernels left undecided) only those pixels are
-        // inverted -- in tile order, rasters read in place; without them (no room for the masks) every pixel is.
-        const long long strips_per_line = (A.samples + 63) >> 6, line_groups = (A.lines + 3) >> 2;
-        const long long cols_per_xcd = (strips_per_line + 7) >> 3, nb = 8 * cols_per_xcd * line_groups;
+    const long long strips_per_line = (A.samples + 63) >> 6, line_groups = (A.lines + 3) >> 2;
+    const long long cols_per_xcd = (strips_per_line + 7) >> 3, nb = 8 * cols_per_xcd * line_groups;
+    if (count > (long long)A.list_cap && !A.mask_g) {
+        // the list overflowed (k_invert_band kept counting but could not append) and there are no strip masks: its pixels are
+        // unknown, so every tile of the raster is inverted by the general algorithm -- k_invert's tile walk as a grid-stride loop.
+        // Results do not depend on which kernel wrote a pixel.
         for (long long b = blockIdx.x; b < nb; b += gridDim.x) {
             const long long xcd = b & 7, j = b >> 3;
             const long long col = xcd * cols_per_xcd + j / line_groups;
             const long long line = (j % line_groups) * 4 + (threadIdx.x >> 6);
             if (col >= strips_per_line || line >= A.lines) continue;  // wave-uniform
             const long long smp = col * 64 + lane;
-            bool in = smp < A.samples;
-            if (A.mask_g) {
-                const unsigned long long m = A.mask_g[line * strips_per_line + col];  // wave-uniform address
-                if (m == 0ULL) continue;
-                in = in && ((m >> lane) & 1ULL) != 0ULL;
-            }
-            invert_strip<T, TO, 1, CR>(L, A, line * A.samples + (smp < A.samples ? smp : A.samples - 1), in, lane);
+            const bool in = smp < A.samples;
+            invert_strip<T, TO, 1, CR>(L, A, line * A.samples + (in ? smp : A.samples - 1), in, lane);
         }
         return;
     }
+    const long long nlist = count < (long long)A.list_cap ? count : (long long)A.list_cap;
     // XSW_LIST_PX pixels per wave and pass: the cooperative stage takes the pixels one after the other, so fewer pixels per
     // wave spread a short list over more SIMDs (the per-lane stage runs with idle lanes, which costs nothing here)
 #ifndef XSW_LIST_PX
 #define XSW_LIST_PX 16
 #endif
     // a long list (a LUT or scene the band rule rarely applies to) fills the waves instead: 64 pixels per wave
-    const int ppw = count >= 64LL * nwaves ? 64 : XSW_LIST_PX;  // measured at 2.3e5 pixels: 16 per wave 2.6 ms, 64 per wave 3.5 ms
-    for (long long c = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); c * ppw < count; c += nwaves) {  // wave-uniform
+    const int ppw = nlist >= 64LL * nwaves ? 64 : XSW_LIST_PX;  // measured at 2.3e5 pixels: 16 per wave 2.6 ms, 64 per wave 3.5 ms
+    for (long long c = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); c * ppw < nlist; c += nwaves) {  // wave-uniform
         const long long k = c * ppw + lane;
-        const bool in = lane < ppw && k < count;
-        const long long i = (long long)A.list[in ? k : count - 1];
+        const bool in = lane < ppw && k < nlist;
+        const long long i = (long long)A.list[in ? k : nlist - 1];
         invert_strip<T, TO, 1, CR>(L, A, i, in, lane);
+    }
+    if (count > (long long)A.list_cap) {
+        // the pixels that did not fit into the list are marked in mask_g (one bit per pixel, a word per strip): the marked pixels
+        // of the marked strips, k_invert's tile walk as a grid-stride loop, rasters read in place
+        for (long long b = blockIdx.x; b < nb; b += gridDim.x) {
+            const long long xcd = b & 7, j = b >> 3;
+            const long long col = xcd * cols_per_xcd + j / line_groups;
+            const long long line = (j % line_groups) * 4 + (threadIdx.x >> 6);
+            if (col >= strips_per_line || line >= A.lines) continue;  // wave-uniform
+            const unsigned long long m = A.mask_g[line * strips_per_line + col];  // wave-uniform address
+            if (m == 0ULL) continue;
+            const long long smp = col * 64 + lane;
+            const bool in = smp < A.samples;
+            invert_strip<T, TO, 1, CR>(L, A, line * A.samples + (in ? smp : A.samples - 1), in && ((m >> lane) & 1ULL) != 0ULL, lane);
+        }
     }
 }
 

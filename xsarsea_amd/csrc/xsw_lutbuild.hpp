@@ -82,29 +82,48 @@ __global__ __launch_bounds__(256) void k_mono_rows(const double *__restrict__ de
     if (first < n_w) atomicMin(&out[i], first);
 }
 
-// tail[i][r] = the smallest value of slice i in rows mono[i] .. r, any direction (+inf for r < mono[i]): a pixel whose band ends
-// below tail[i][w_hi] has no candidate in the rows of its window past the monotone ones (band_wave: the window is cut at the last
-// monotone row).  One workgroup per slice: row minima over the directions, then a running minimum over the rows.
-// whole_tail (A/B, XSW_TAIL_GLOBAL=1): every row >= mono[i] holds the minimum over ALL the rows past the monotone ones.
-__global__ __launch_bounds__(256) void k_tail_min(const double *__restrict__ dense, int n_w, int n_phi, const int *__restrict__ mono,
+// Tail minima (band_wave's tail cut): tail[i][k][p] = the smallest value of slice i in rows >= mono[i] over the directions
+// p .. p + 2^k - 1 (clipped to the axis), k = 0 .. XSW_TAIL_LEVELS - 1 -- a sparse table, so that the minimum over a window's
+// directions [a, b] is min(tail[k][a], tail[k][b - 2^k + 1]) with 2^k <= b - a + 1 < 2^(k+1) -- and level XSW_TAIL_LEVELS holds
+// the minimum over ALL directions (windows wider than 2^XSW_TAIL_LEVELS - 1).  +inf where every row is monotone.  A pixel whose
+// band ends below the minimum of its window's directions has no candidate in the rows past the monotone ones.
+// One workgroup per slice.  whole_tail (A/B, XSW_TAIL_GLOBAL=1): every level holds the all-directions minimum.
+__global__ __launch_bounds__(256) void k_tail_min(const double *__restrict__ dense, int n_w, int n_phi, int phi_pad, const int *__restrict__ mono,
                                                   double *__restrict__ tail, int whole_tail)
 {
     const int i = blockIdx.x, m = mono[i];
     const double *sl = dense + (size_t)i * n_w * n_phi;
-    double *out = tail + (size_t)i * n_w;
+    double *out = tail + (size_t)i * (XSW_TAIL_LEVELS + 1) * phi_pad;
     const double inf = __builtin_inf();
-    for (int r = threadIdx.x; r < n_w; r += blockDim.x) {
+    for (int p = threadIdx.x; p < phi_pad; p += blockDim.x) {
         double lo = inf;
-        if (r >= m)
-            for (int p = 0; p < n_phi; ++p) lo = fmin(lo, sl[(size_t)r * n_phi + p]);
-        out[r] = lo;
+        if (p < n_phi)
+            for (int r = m; r < n_w; ++r) lo = fmin(lo, sl[(size_t)r * n_phi + p]);
+        out[p] = lo;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double run = inf;
-        for (int r = 0; r < n_w; ++r) { run = fmin(run, out[r]); out[r] = run; }
-        if (whole_tail)
-            for (int r = m; r < n_w; ++r) out[r] = run;
+    for (int k = 1; k < XSW_TAIL_LEVELS; ++k) {
+        const double *prev = out + (size_t)(k - 1) * phi_pad;
+        double *cur = out + (size_t)k * phi_pad;
+        const int h = 1 << (k - 1);
+        for (int p = threadIdx.x; p < phi_pad; p += blockDim.x) cur[p] = fmin(prev[p], p + h < phi_pad ? prev[p + h] : inf);
+        __syncthreads();
+    }
+    __shared__ double slo[256];
+    double lo = inf;
+    for (int p = threadIdx.x; p < n_phi; p += blockDim.x) lo = fmin(lo, out[p]);
+    slo[threadIdx.x] = lo;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) slo[threadIdx.x] = fmin(slo[threadIdx.x], slo[threadIdx.x + st]);
+        __syncthreads();
+    }
+    const double all = slo[0];
+    for (int p = threadIdx.x; p < phi_pad; p += blockDim.x) out[(size_t)XSW_TAIL_LEVELS * phi_pad + p] = all;
+    if (whole_tail) {
+        __syncthreads();
+        for (int k = 0; k < XSW_TAIL_LEVELS; ++k)
+            for (int p = threadIdx.x; p < phi_pad; p += blockDim.x) out[(size_t)k * phi_pad + p] = all;
     }
 }
 
