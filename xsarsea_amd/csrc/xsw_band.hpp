@@ -68,11 +68,19 @@ namespace xsw {
 #ifndef XSW_BAND_HI_MASK
 #define XSW_BAND_HI_MASK 1
 #endif
+// Hand-over caps of the long-run role (runtime values: KArgs::run_max / run_max_cut / sweep_max, environment XSW_RUN_MAX /
+// XSW_RUN_MAX_CUT / XSW_SWEEP_MAX for A/B runs; profiles/sweep_run_caps.sh).  Measured on the hard scenes of DESIGN 7c
+// (64 / 24 / 64 -> 128 / 64 / 128 -> 256 / 256 / 256, Mpx/s): a-priori x 0.3 299 -> 418 -> 415, x 0.6 985 -> 1082 -> 1089,
+// x 1.6 755 -> 815 -> 768, x 2.5 159 -> 194 -> 221, incidence 17..33 deg x 1.6 269 -> 377 -> 376; the benchmark scene
+// 10 148 -> 10 080 -> 9 928 (a few 1e4 very long runs more for k_invert_band2, while k_invert_list's time there is a latency floor).
 #ifndef XSW_LONG_RUN_MAX
-#define XSW_LONG_RUN_MAX 64
+#define XSW_LONG_RUN_MAX 128     // rows of band along the a-priori direction beyond which a pixel skips k_invert_band2 (straight to the list)
 #endif
 #ifndef XSW_LONG_RUN_MAX_CUT
-#define XSW_LONG_RUN_MAX_CUT 24  // ... of a window that was cut at the last monotone row (its band lies on the flat top)
+#define XSW_LONG_RUN_MAX_CUT 64  // ... of a window that was cut at the last monotone row (its band lies on the flat top)
+#endif
+#ifndef XSW_SWEEP_MAX
+#define XSW_SWEEP_MAX 128        // rows a direction may hold in k_invert_band2's batched sweep before the pixel is left to k_invert_list
 #endif
 #ifndef XSW_BAND_SEEDED
 #define XSW_BAND_SEEDED 1  // first ray seeded from the inverse-row table (co_window_lanes)
@@ -132,7 +140,8 @@ __device__ __forceinline__ double ld_co(const char *__restrict__ base, unsigned 
 template <int S, int K, bool COUNT, bool BITONIC, bool BATCH = false>
 __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig, int lane,
                                              const BandSlot *slots /* this wave's [64], sorted by class */, int *res /* [64], by slot */,
-                                             int first, int count /* slots [first, first + count) -> segments 0 .. count-1 */, unsigned &cand)
+                                             int first, int count /* slots [first, first + count) -> segments 0 .. count-1 */, unsigned &cand,
+                                             int sweep_max = XSW_BAND_MAX /* BATCH: rows a direction may hold (KArgs::sweep_max) */)
 {
     const double inf = __builtin_inf();
     const int q = lane / S, sl = lane & (S - 1);
@@ -221,7 +230,7 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
             // the GMF): the sweep is a chain of dependent load round trips -- take the rows XSW_BAND_BATCH at a time, all loads
             // of a batch in flight before the first is scored.  (k_invert_band's runs are 1-3 rows: batching costs there.)
 #pragma unroll 1
-            for (int t0 = 0; t0 < XSW_BAND_MAX; t0 += XSW_BAND_BATCH) {
+            for (int t0 = 0; t0 < sweep_max; t0 += XSW_BAND_BATCH) {
                 unsigned long long left[K], any_left = 0ULL;
 #pragma unroll
                 for (int j = 0; j < K; ++j) { left[j] = ballot64(t0 < nrow[j]); any_left |= left[j]; }
@@ -280,7 +289,7 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
             }
         }
         }
-        const bool any = nmax > (BITONIC ? XSW_BAND2_MAX : XSW_BAND_MAX);
+        const bool any = nmax > (BITONIC ? XSW_BAND2_MAX : ((BATCH && S >= XSW_BAND_BATCH_S) ? sweep_max : XSW_BAND_MAX));
         overflow = overflow || any;  // rows left after XSW_BAND_MAX trips
         if (K == 1 && S != 64) bip = ip[0];
     }
@@ -433,7 +442,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                 }
                 // (a run beyond XSW_LONG_RUN_MAX rows -- the flat top of a saturating GMF -- would overflow k_invert_band2's sweep
                 // after costing it the most: such a pixel goes straight to the general kernel)
-                if (eligb && run > (w_hi_e < W.w_hi ? XSW_LONG_RUN_MAX_CUT : XSW_LONG_RUN_MAX)) {
+                if (eligb && run > (w_hi_e < W.w_hi ? A.run_max_cut : A.run_max)) {
                     myc = NC;
                     eligb = false;
                     if (ROLE == 2) skip = true;
@@ -497,7 +506,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
         auto run = [&](auto seg, auto kk, int c) {
             constexpr int S = decltype(seg)::value, K = decltype(kk)::value;
             for (int p = 0; p < ncls[c]; p += 64 / S)
-                co_band_pass<S, K, COUNT, BITONIC, ROLE == 2>(L, A.inv_dsig_co, lane, slots, res_, first[c] + p, min(64 / S, ncls[c] - p), cand);
+                co_band_pass<S, K, COUNT, BITONIC, ROLE == 2>(L, A.inv_dsig_co, lane, slots, res_, first[c] + p, min(64 / S, ncls[c] - p), cand, ROLE == 2 ? A.sweep_max : XSW_BAND_MAX);
         };
         using two = std::integral_constant<int, 2>;
         using three = std::integral_constant<int, 3>;

@@ -99,6 +99,8 @@ struct KArgs {
     // the whole raster.
     unsigned long long *mask_g, *mask_b;
     int long_run;               // k_invert_band, ROLE 1: rows along the a-priori direction from which a pixel is handed to k_invert_band2
+    int run_max, run_max_cut;   // ... and beyond which it goes straight to the list (run_max_cut: windows cut at the last monotone row)
+    int sweep_max;              // k_invert_band2's long-run role: rows a direction may hold before the pixel is left to k_invert_list
     long long n, lines, samples;
     double dsig_co, inv_dsig_co, dsig_cr_scalar;
     int is_db, dual_select;
@@ -307,19 +309,40 @@ __device__ __forceinline__ double exact_J_cr(double wc, double lutv, double s, d
 
 // Full (wspd x phi) sweep in the reference's arithmetic with numpy.argmin semantics (first minimum;
 // a NaN anywhere wins, first NaN).  Wave-cooperative, every argument wave-uniform.  Any LUT.
+// Lanes = directions (chunks of 64), XSW_EXACT_ROWS rows per trip with all their loads in flight before the first score (a
+// scan of one dependent load per trip is a chain of ~1500 memory round trips: 1.5 ms for ONE pixel, which was the whole of
+// k_invert_list's time on the benchmark scene -- a dozen such pixels, one wave each).  The order of the visits does not
+// matter: the running minimum is lexicographic in (J, flat index).
+#ifndef XSW_EXACT_ROWS
+#define XSW_EXACT_ROWS 4
+#endif
 __device__ __forceinline__ int exact_scan_co(const DevTables &L, int i_inc, double s, double a, double b,
                                           double dsig, int lane)
 {
     const double *__restrict__ slice = L.co + (size_t)i_inc * L.n_w * L.phi_pad;
     double bestJ = __builtin_inf();
     int bestI = 0x7fffffff, nanI = 0x7fffffff;
-    for (int iw = 0; iw < L.n_w; ++iw) {
-        const double w = L.w[iw];
-        for (int ip = lane; ip < L.n_phi; ip += 64) {
-            double J = exact_J_co(w, L.cphi[ip], L.sphi[ip], slice[(size_t)iw * L.phi_pad + ip], s, a, b, dsig);
-            int flat = iw * L.n_phi + ip;
-            if (J != J) nanI = min(nanI, flat);
-            else if (J < bestJ || bestI == 0x7fffffff) { bestJ = J; bestI = flat; }
+    for (int ip0 = 0; ip0 < L.n_phi; ip0 += 64) {  // wave-uniform
+        const int ip = ip0 + lane;
+        const bool valid = ip < L.n_phi;
+        const int ipc = valid ? ip : 0;
+        const double c = L.cphi[ipc], sn = L.sphi[ipc];
+        const double *__restrict__ col = slice + ipc;
+#pragma unroll 1
+        for (int iw0 = 0; iw0 < L.n_w; iw0 += XSW_EXACT_ROWS) {
+            double v[XSW_EXACT_ROWS];
+#pragma unroll
+            for (int u = 0; u < XSW_EXACT_ROWS; ++u) v[u] = col[(size_t)min(iw0 + u, L.n_w - 1) * L.phi_pad];
+#pragma unroll
+            for (int u = 0; u < XSW_EXACT_ROWS; ++u) {
+                const int iw = iw0 + u;
+                if (iw < L.n_w && valid) {  // (iw: wave-uniform)
+                    const double J = exact_J_co(L.w[iw], c, sn, v[u], s, a, b, dsig);
+                    const int flat = iw * L.n_phi + ip;
+                    if (J != J) nanI = min(nanI, flat);
+                    else if (J < bestJ || (J == bestJ && flat < bestI) || bestI == 0x7fffffff) { bestJ = J; bestI = flat; }
+                }
+            }
         }
     }
     nanI = wave_min_i(nanI);
