@@ -68,7 +68,9 @@ def exact_J(w, cphi, sphi, lut_val, s, a, b, dsig):
 
 
 def pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig):
-    """Returns (i_wspd, i_phi, n_evaluated) for one pixel; slice_wp is the (n_w, n_phi) dB slice."""
+    """Returns (i_wspd, i_phi, n_evaluated) for one pixel; slice_wp is the (n_w, n_phi) dB slice.  (One ray: the general
+    kernel takes the smallest score of three since the end of round 3, XSW_STRIP_RAYS -- any score seen is a valid bound, the
+    three-ray form is the one band_pruned_argmin spells out.)"""
     n_w, n_phi = slice_wp.shape
     if phi_180:
         b = abs(b)

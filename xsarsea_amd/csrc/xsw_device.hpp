@@ -482,7 +482,7 @@ __device__ __forceinline__ CoWindow box_from_jub(const DevTables &L, double mag,
 // the windows from 18.4 x 25.2 to 16.2 x 22.8 (directions x speeds) for two short bisections more per pixel
 // (measured, band kernel at 20000^2: 1 ray 93.9 ms; 3 full rays 85.3; side rays seeded, 4 / 3 steps 84.5 / 83.9; 5 and 7 rays 87.7 / 88.8).
 #ifndef XSW_STRIP_RAYS
-#define XSW_STRIP_RAYS 1  // rays of the upper bound in the general kernel (invert_strip)
+#define XSW_STRIP_RAYS 3  // rays of the upper bound in the general kernel (invert_strip): 1 -> 3 rays takes 3-12 % off k_invert_list on the hard scenes (windows a quarter smaller for two short bisections per wave)
 #endif
 #ifndef XSW_RAY_SIDE_STEPS
 #define XSW_RAY_SIDE_STEPS 2
@@ -1245,7 +1245,7 @@ __device__ __forceinline__ void invert_strip(const DevTables &L, const KArgs &A,
         W = co_window_lanes<XSW_STRIP_RAYS, 2>(L, P, A.inv_dsig_co, fabs(A.dsig_co), loose);
         if (loose) P.flags &= ~F_CO_FINITE;  // -> exact_scan_co
         const unsigned long long fin_m = __ballot((P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0);
-        cand += (unsigned)__popcll(fin_m) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)));
+        cand += (unsigned)__popcll(fin_m) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)) + (XSW_STRIP_RAYS - 1) * 2 * XSW_RAY_SIDE_STEPS);
         if (L.co_off32) {
             const int ncols_p = W.ip_hi - W.ip_lo + 1;
             const bool elig = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0;
