@@ -714,6 +714,9 @@ static int launch_invert(xsw_ctx *c, const KArgs &A, int algo, const LaunchCtl &
             }
         }
         if (lc.timing) timing_mark(c);
+#ifdef XSW_LIST_CLOCK  // experiments: k_invert_list alone counts into the statistics buffer (xsw_stats_read), see the kernel
+        if (!B.stats) { (void)hipMemsetAsync(c->d_stats, 0, 4 * sizeof(unsigned long long), lc.stream); B.stats = c->d_stats; }
+#endif
         if (mono) hipLaunchKernelGGL((k_invert_list<T, TO, false>), dim3(list_blocks), dim3(256), 0, lc.stream, c->T, B);
         else hipLaunchKernelGGL((k_invert_list<T, TO, true>), dim3(list_blocks), dim3(256), 0, lc.stream, c->T, B);
         if (lc.timing) timing_mark(c);

@@ -1390,7 +1390,14 @@ __global__ __launch_bounds__(256, XSW_LIST_WAVES) void k_invert_list(DevTables L
         const long long k = c * ppw + lane;
         const bool in = lane < ppw && k < nlist;
         const long long i = (long long)A.list[in ? k : nlist - 1];
+#ifdef XSW_LIST_CLOCK  // experiments: the slowest wave pass of the list (10 ns ticks << 40 | its first pixel) in stats[3]
+        const unsigned long long t0 = wall_clock64();
+#endif
         invert_strip<T, TO, 1, CR>(L, A, i, in, lane);
+#ifdef XSW_LIST_CLOCK
+        const unsigned long long dt = wall_clock64() - t0;
+        if (lane == 0 && A.stats) atomicMax(&A.stats[3], (dt << 40) | ((unsigned long long)i & 0xFFFFFFFFFFULL));
+#endif
     }
     if (count > (long long)A.list_cap) {
         // the pixels that did not fit into the list are marked in mask_g (one bit per pixel, a word per strip): the marked pixels
