@@ -148,7 +148,7 @@ def band_radius(j_ub, dsig):
     return abs(dsig) * np.sqrt(j_ub) * (1.0 + 1e-6) + 1e-9
 
 
-def band_pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig, max_len=16, tail_cut=True):
+def band_pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig, max_len=16, tail_cut=True, tail_sweep=0):
     """Like pruned_argmin, with the band rule on top of the disc window.  Returns (i_wspd, i_phi, n_evaluated, used_band);
     falls back to pruned_argmin when the window leaves the monotone rows, a band is longer than max_len, or the screening
     cannot decide (the device then re-does the pixel with the window sweep)."""
@@ -205,7 +205,13 @@ def band_pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig, 
         # every LUT value of the rows >= mono in the window's directions lies above s + d, so none of those rows is in the band:
         # their sigma0 term alone exceeds J_ub.  (tail_cut="whole": the minimum over all the directions, the first form.)  The window is cut at the last monotone row and the band rule applies to what is left.
         w_hi = mono - 1
-    if w_hi >= mono or w_hi < w_lo or ip_hi - ip_lo + 1 > 64:
+    tail_rows = []
+    if w_hi >= mono and tail_sweep and mono >= 1 and w_hi - mono + 1 <= tail_sweep:
+        # Tail sweep (round 3; k_invert_band2): the band does reach the rows past the monotone ones.  The band rule still holds
+        # on the monotone part; the rows mono .. w_hi are all kept as candidates (every one belongs to the window).
+        tail_rows = list(range(max(mono, w_lo), w_hi + 1))
+        w_hi = mono - 1
+    if w_hi >= mono or (w_hi < w_lo and not tail_rows) or ip_hi - ip_lo + 1 > 64:
         return fallback()
     cand = []
     for ip in range(ip_lo, ip_hi + 1):
@@ -226,6 +232,9 @@ def band_pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig, 
             u = 2.0 * (ah * cphi[ip] + bh * sphi[ip])
             cand.append((wh[r] * (wh[r] - u) + (c[r] * inv + sn) ** 2, r, ip))
             r += 1
+        for r in tail_rows:
+            u = 2.0 * (ah * cphi[ip] + bh * sphi[ip])
+            cand.append((wh[r] * (wh[r] - u) + (c[r] * inv + sn) ** 2, r, ip))
     assert cand, "the ray's best candidate always lies in the band"
     js = np.array([c[0] for c in cand])
     gmin = js.min()

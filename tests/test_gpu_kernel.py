@@ -726,22 +726,26 @@ def test_band2_rise_then_fall_columns(list_cap):
 
 def test_tail_cut_keeps_saturating_windows_in_the_band_kernels():
     """Round 3: a window that reaches past the monotone rows of its slice stays with the band rule when no LUT value up there can
-    be in the band (L.tail_min, tests/prune_model.py: tail_cut).  Same four scenes, fresh processes: results == the exhaustive
-    sweep with and without the cut (XSW_NO_TAIL_CUT=1 is the A/B switch), and with the cut fewer pixels of the a-priori x 1.6
-    scene are left to the general kernel (this small scene: 3127 against 3680; the 8e7-pixel scenes of DESIGN 7c: 6 % against 22 %)."""
+    be in the band (L.tail_min, tests/prune_model.py: tail_cut), and otherwise keeps it on its monotone part while
+    k_invert_band2 sweeps the rows past it in full (tail sweep).  Same four scenes, fresh processes: results == the exhaustive
+    sweep with both, without the sweep (XSW_TAIL_SWEEP=0) and without either (XSW_NO_TAIL_CUT=1), and each step leaves fewer
+    pixels of the a-priori x 1.6 scene to the general kernel."""
     import subprocess
     import sys
     from conftest import REPO
     listed = {}
-    for off in (False, True):
-        env = {k: v for k, v in os.environ.items() if k not in ("XSW_LONG_RUN", "XSW_BAND2", "XSW_NO_TAIL_CUT", "XSW_LIST_CAP_TEST")}
-        if off:
+    for mode in ("both", "cut", "none"):
+        env = {k: v for k, v in os.environ.items() if k not in ("XSW_LONG_RUN", "XSW_BAND2", "XSW_NO_TAIL_CUT", "XSW_LIST_CAP_TEST", "XSW_TAIL_SWEEP")}
+        if mode != "both":
+            env["XSW_TAIL_SWEEP"] = "0"
+        if mode == "none":
             env["XSW_NO_TAIL_CUT"] = "1"
         r = subprocess.run([sys.executable, "-c", _BAND2_SCRIPT.format(repo=REPO)], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         rows = [l.split() for l in r.stdout.splitlines() if l.startswith("RESULT")]
         assert len(rows) == 4
         for _, scale, diff, launches, _b2, n_list in rows:
-            assert int(diff) == 0, f"scale {scale}, cut off={off}: {diff} values differ from the exhaustive sweep"
-            listed[(off, float(scale))] = int(n_list)
-    assert listed[(False, 1.6)] < listed[(True, 1.6)] and listed[(False, 2.5)] <= listed[(True, 2.5)], listed
+            assert int(diff) == 0, f"scale {scale}, {mode}: {diff} values differ from the exhaustive sweep"
+            listed[(mode, float(scale))] = int(n_list)
+    assert listed[("both", 1.6)] < listed[("cut", 1.6)] < listed[("none", 1.6)], listed
+    assert listed[("both", 2.5)] < listed[("cut", 2.5)] <= listed[("none", 2.5)], listed

@@ -139,6 +139,15 @@ def test_tail_cut_keeps_saturating_windows_with_the_band_rule(kind):
                                             max_len=64, tail_cut=False)[3]
         used_whole += pm.band_pruned_argmin(co[ii], w_ax, phi_ax, cphi, sphi, p.phi_180, s[i], anc[i].real, anc[i].imag, 0.1,
                                             max_len=64, tail_cut="whole")[3]
+    # tail sweep (k_invert_band2): windows the cut cannot take keep the band rule on their monotone part, the rows past it are all
+    # candidates: same argmin, and more pixels stay with the band rule still
+    used_sweep = 0
+    for i in range(n):
+        ii = np.argmin(np.abs(inc_ax - inc[i]))
+        r = pm.band_pruned_argmin(co[ii], w_ax, phi_ax, cphi, sphi, p.phi_180, s[i], anc[i].real, anc[i].imag, 0.1, max_len=64, tail_sweep=256)
+        assert (r[0], r[1]) == (idx[i, 0], idx[i, 1]), (kind, "tail sweep", i, r, idx[i])
+        used_sweep += r[3]
+    assert used_sweep > used_cut, (used_sweep, used_cut)
     if kind == "cmod5n":  # and the minimum over the window's own directions cuts more windows than the one over all directions
         assert used_cut > used_whole > used_plain + 0.05 * n, (used_cut, used_whole, used_plain)
     else:  # the rolled-off top falls back below every observed sigma0: the cut must never fire there

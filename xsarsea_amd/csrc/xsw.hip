@@ -676,6 +676,8 @@ static int launch_invert(xsw_ctx *c, const KArgs &A, int algo, const LaunchCtl &
         static const int run_max_cut_env = getenv("XSW_RUN_MAX_CUT") ? atoi(getenv("XSW_RUN_MAX_CUT")) : XSW_LONG_RUN_MAX_CUT;
         static const int sweep_max_env = getenv("XSW_SWEEP_MAX") ? std::max(4, atoi(getenv("XSW_SWEEP_MAX")) & ~3) : XSW_SWEEP_MAX;  // whole batches of 4 rows
         B.run_max = run_max_env; B.run_max_cut = run_max_cut_env; B.sweep_max = sweep_max_env;
+        static const int tail_max_env = getenv("XSW_TAIL_SWEEP") ? std::min(std::max(0, atoi(getenv("XSW_TAIL_SWEEP"))), 30000) : XSW_TAIL_SWEEP;
+        B.tail_max = (wide2 && c->T.tail_min) ? tail_max_env : 0;  // the long-run role of k_invert_band2 only
         // strip masks: what the consumers walk when a list overflows (only the marked pixels instead of the whole raster)
         static const bool masks_off = getenv("XSW_NO_STRIP_MASKS") != nullptr;  // A/B measurements and the tests of the old route
         const size_t nstrips = (size_t)(strips_per_line * A.lines);

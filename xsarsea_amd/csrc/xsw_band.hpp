@@ -82,6 +82,11 @@ namespace xsw {
 #ifndef XSW_SWEEP_MAX
 #define XSW_SWEEP_MAX 128        // rows a direction may hold in k_invert_band2's batched sweep before the pixel is left to k_invert_list
 #endif
+#ifndef XSW_TAIL_SWEEP
+#define XSW_TAIL_SWEEP 256  // rows past the monotone ones a window may hold for k_invert_band2's tail sweep (KArgs::tail_max; 0: off;
+                            // environment XSW_TAIL_SWEEP).  Measured (Mpx/s, 0 / 96 / 192 / 400 rows): a-priori x 1.6 1107 / 1186 / 1193 / 1191,
+                            // x 2.5 252 / 331 / 394 / 396, incidence 17..33 deg x 1.6 421 / 473 / 570 / 560, 17..25 deg 2460 / 2654 / 2612 / 2651
+#endif
 #ifndef XSW_BAND_SEEDED
 #define XSW_BAND_SEEDED 1  // first ray seeded from the inverse-row table (co_window_lanes)
 #endif
@@ -149,6 +154,10 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
     const int owner = valid ? first + q : lane;  // slot index (idle segment: any slot, its contents are overridden below)
     BandSlot B = slots[owner];
     if (!valid) { B.inc_bin = 0; B.rows = 0; B.ipn = 0; B.bin_hi = -1; }  // idle segment: harmless addresses, nothing scored
+    // ROLE 2 slots carry the TAIL of the window in the upper half of bin_hi: rows w_hi + 1 .. w_hi + tail_n lie past the slice's
+    // monotone rows (w_hi = the last monotone row) and are swept in full, after the band rows of the monotone part (band_wave)
+    const int tail_n = (!BITONIC && BATCH) ? (int)((unsigned)B.bin_hi >> 16) : 0;
+    if (!BITONIC && BATCH) B.bin_hi = (int)(short)(B.bin_hi & 0xffff);
     const int B_ip_lo = B.ipn & 0xffff, B_ncols = (int)((unsigned)B.ipn >> 16);
     const int B_vcols = BITONIC ? 2 * B_ncols : B_ncols;  // virtual columns
     const int w_lo = B.rows & 0xffff, w_hi = B.rows >> 16;
@@ -181,6 +190,7 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
     for (int ch = 0; ch < nchunks; ++ch) {
         bool act[K], fall[K];
         int ip[K], r[K], nrow[K];
+        int n1[K], gap[K];  // CHORD (ROLE 2): rows of the first run (band rows of the monotone part), and the jump to the tail's first row
         unsigned off0[K];
         double U[K];
 #pragma unroll
@@ -214,8 +224,15 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
                 const int c_lo = (int)ceil(fmax(xc - xh, -4.0)), c_hi = (int)floor(fmin(xc + xh, 40000.0));
                 r[j] = max(r[j], min(c_lo, L.n_w));
                 last = disc < 0.0 ? r[j] - 1 : min(last, c_hi);
+                // the tail (rows past the monotone ones, every one a candidate), clipped to the same chord
+                const int r2 = max(max(w_hi + 1, w_lo), min(c_lo, L.n_w)), last2 = disc < 0.0 ? r2 - 1 : min(w_hi + tail_n, c_hi);
+                n1[j] = max(last - r[j] + 1, 0);
+                gap[j] = r2 - (r[j] + n1[j]);
+                nrow[j] = act[j] ? n1[j] + max(last2 - r2 + 1, 0) : 0;
+            } else {
+                n1[j] = 0x7fffffff; gap[j] = 0;
+                nrow[j] = act[j] ? last - r[j] + 1 : 0;
             }
-            nrow[j] = act[j] ? last - r[j] + 1 : 0;
             nmax = max(nmax, nrow[j]);
         }
         if (BITONIC && nmax > XSW_BAND2_MAX) {
@@ -241,7 +258,11 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
                     double v[XSW_BAND_BATCH];
                     int rc[XSW_BAND_BATCH];
 #pragma unroll
-                    for (int u = 0; u < XSW_BAND_BATCH; ++u) { rc[u] = min(r[j] + t0 + u, w_hi); v[u] = ld_co(base, off0[j], rc[u], rowB); }
+                    for (int u = 0; u < XSW_BAND_BATCH; ++u) {
+                        const int tt = t0 + u;
+                        rc[u] = CHORD ? min(r[j] + tt + (tt >= n1[j] ? gap[j] : 0), w_hi + tail_n) : min(r[j] + tt, w_hi);
+                        v[u] = ld_co(base, off0[j], rc[u], rowB);
+                    }
 #pragma unroll
                     for (int u = 0; u < XSW_BAND_BATCH; ++u) {
                         const bool inb = t0 + u < nrow[j] && (XSW_BAND_NO_VCHECK || (v[u] >= thr_lo && v[u] <= thr_hi));
@@ -377,7 +398,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
             // the directions: CMOD5.N saturates and then falls back slowly, so this is the common case of an a-priori wind well
             // above the one sigma0 points to; upwind and crosswind saturate several dB apart, hence per direction).  Those rows
             // cannot hold the argmin (their sigma0 term alone exceeds J_ub): the window is cut at the last monotone row.
-            int w_hi_e = W.w_hi;
+            int w_hi_e = W.w_hi, tail_n = 0;
             if (!BITONIC && L.tail_min) {
                 const bool fin1 = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0;
                 const int mono1 = L.mono_rows[fin1 ? P.i_inc : 0];
@@ -386,11 +407,16 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                     const double *tk = L.tail_min + ((size_t)P.i_inc * (XSW_TAIL_LEVELS + 1) + k) * L.phi_pad;
                     const double lo = fmin(tk[W.ip_lo], tk[k < XSW_TAIL_LEVELS ? W.ip_hi - (1 << k) + 1 : W.ip_lo]);
                     if (P.s_co + W.band_d < lo) w_hi_e = mono1 - 1;
+                    // TAIL SWEEP (ROLE 1 / 2): the band does reach up there -- the flat top of a saturating GMF under speckle: the
+                    // pixels that used to cost k_invert_list the most (whole windows of 1e4 candidates, one pixel at a time).  The
+                    // band rule still holds on the monotone part; the rows past it, at most A.tail_max, are swept in full by
+                    // k_invert_band2 (clipped to the disc's chord like every row there): the window is cut and the tail noted.
+                    else if (ROLE != 0 && mono1 >= 1 && W.w_hi - mono1 + 1 <= A.tail_max) { tail_n = W.w_hi - mono1 + 1; w_hi_e = mono1 - 1; }
                 }
             }
             const int nrows_p = w_hi_e - W.w_lo + 1;
             ncols_p = W.ip_hi - W.ip_lo + 1;
-            const bool need = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0 && !loose && ncols_p >= 1 && nrows_p >= 1;
+            const bool need = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0 && !loose && ncols_p >= 1 && (nrows_p >= 1 || tail_n > 0);
             if (ROLE == 2 && strip_walk) skip = !need || !(w_hi_e < L.mono_rows[need ? P.i_inc : 0]);  // everything k_invert_band did not hand over
             if (BITONIC) {
                 eligb = need && L.bitonic_ok[need ? P.i_inc : 0] != 0;  // every column of the slice rises, then falls
@@ -439,15 +465,16 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                         return min(rb - 1, w_hi_e) - max(ra, W.w_lo) + 1;
                     };
                     run = run_at(P.ipr);  // (the window's first and last directions as well: hands over 3.5x the pixels for 2 ms less here, 4 ms more there)
+                    if (tail_n > 0) run = max(run, 0) + tail_n;
                 }
                 // (a run beyond XSW_LONG_RUN_MAX rows -- the flat top of a saturating GMF -- would overflow k_invert_band2's sweep
                 // after costing it the most: such a pixel goes straight to the general kernel)
-                if (eligb && run > (w_hi_e < W.w_hi ? A.run_max_cut : A.run_max)) {
+                if (eligb && run > ((w_hi_e < W.w_hi && tail_n == 0) ? A.run_max_cut : A.run_max)) {
                     myc = NC;
                     eligb = false;
                     if (ROLE == 2) skip = true;
                 }
-                const bool handed = eligb && run >= A.long_run;
+                const bool handed = eligb && (run >= A.long_run || tail_n > 0);  // (a tail is k_invert_band2's whatever its length)
                 if (ROLE == 1 && handed) {  // the second band kernel's
                     myc = NC;
                     eligb = false;
@@ -488,6 +515,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                 b.ah = ah; b.bh = bh; b.m2 = ah * ah + bh * bh;
                 b.inc_bin = P.i_inc | (bin << 16); b.rows = W.w_lo | (w_hi_e << 16); b.ipn = W.ip_lo | (ncols_p << 16);
                 b.bin_hi = bhi < XSW_INV_BINS ? bhi : (BITONIC ? XSW_INV_BINS /* the tabulated +inf threshold */ : -1);
+                if (ROLE == 2) b.bin_hi = (b.bin_hi & 0xffff) | (tail_n << 16);  // co_band_pass: rows past the monotone ones
                 slots[pos] = b;
 #ifdef XSW_TIMING_STAGE1_ONLY
                 res_[pos] = 0;   // (timing build: pretend the pass decided, so that nothing floods the work list)
