@@ -672,10 +672,6 @@ static int launch_invert(xsw_ctx *c, const KArgs &A, int algo, const LaunchCtl &
         const bool band2 = bitonic2 || wide2;
         if (band2) { B.list_b_count = lc.list + 1; B.list_b = lc.list + 16 + lc.list_cap; B.list_b_cap = B.list_cap; }
         B.long_run = long_run_env;
-        static const int run_max_env = getenv("XSW_RUN_MAX") ? atoi(getenv("XSW_RUN_MAX")) : XSW_LONG_RUN_MAX;
-        static const int run_max_cut_env = getenv("XSW_RUN_MAX_CUT") ? atoi(getenv("XSW_RUN_MAX_CUT")) : XSW_LONG_RUN_MAX_CUT;
-        static const int sweep_max_env = getenv("XSW_SWEEP_MAX") ? std::max(4, atoi(getenv("XSW_SWEEP_MAX")) & ~3) : XSW_SWEEP_MAX;  // whole batches of 4 rows
-        B.run_max = run_max_env; B.run_max_cut = run_max_cut_env; B.sweep_max = sweep_max_env;
         static const int tail_max_env = getenv("XSW_TAIL_SWEEP") ? std::min(std::max(0, atoi(getenv("XSW_TAIL_SWEEP"))), 30000) : XSW_TAIL_SWEEP;
         B.tail_max = (wide2 && c->T.tail_min) ? tail_max_env : 0;  // the long-run role of k_invert_band2 only
         // strip masks: what the consumers walk when a list overflows (only the marked pixels instead of the whole raster)

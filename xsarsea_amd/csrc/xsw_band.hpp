@@ -68,8 +68,9 @@ namespace xsw {
 #ifndef XSW_BAND_HI_MASK
 #define XSW_BAND_HI_MASK 1
 #endif
-// Hand-over caps of the long-run role (runtime values: KArgs::run_max / run_max_cut / sweep_max, environment XSW_RUN_MAX /
-// XSW_RUN_MAX_CUT / XSW_SWEEP_MAX for A/B runs; profiles/sweep_run_caps.sh).  Measured on the hard scenes of DESIGN 7c
+// Hand-over caps of the long-run role.  Compile-time: as runtime arguments (the A/B sweep below ran that way) they cost
+// k_invert_band 0.3 ms of 33.7 in stage 1; profiles/sweep_run_caps.sh builds its variants with -D flags instead.
+// Measured on the hard scenes of DESIGN 7c
 // (64 / 24 / 64 -> 128 / 64 / 128 -> 256 / 256 / 256, Mpx/s): a-priori x 0.3 299 -> 418 -> 415, x 0.6 985 -> 1082 -> 1089,
 // x 1.6 755 -> 815 -> 768, x 2.5 159 -> 194 -> 221, incidence 17..33 deg x 1.6 269 -> 377 -> 376; the benchmark scene
 // 10 148 -> 10 080 -> 9 928 (a few 1e4 very long runs more for k_invert_band2, while k_invert_list's time there is a latency floor).
@@ -145,9 +146,9 @@ __device__ __forceinline__ double ld_co(const char *__restrict__ base, unsigned 
 template <int S, int K, bool COUNT, bool BITONIC, bool BATCH = false>
 __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig, int lane,
                                              const BandSlot *slots /* this wave's [64], sorted by class */, int *res /* [64], by slot */,
-                                             int first, int count /* slots [first, first + count) -> segments 0 .. count-1 */, unsigned &cand,
-                                             int sweep_max = XSW_BAND_MAX /* BATCH: rows a direction may hold (KArgs::sweep_max) */)
+                                             int first, int count /* slots [first, first + count) -> segments 0 .. count-1 */, unsigned &cand)
 {
+    constexpr int sweep_max = (BATCH && S >= XSW_BAND_BATCH_S) ? XSW_SWEEP_MAX : XSW_BAND_MAX;  // rows a direction may hold
     const double inf = __builtin_inf();
     const int q = lane / S, sl = lane & (S - 1);
     const bool valid = q < count;
@@ -310,7 +311,7 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
             }
         }
         }
-        const bool any = nmax > (BITONIC ? XSW_BAND2_MAX : ((BATCH && S >= XSW_BAND_BATCH_S) ? sweep_max : XSW_BAND_MAX));
+        const bool any = nmax > (BITONIC ? XSW_BAND2_MAX : sweep_max);
         overflow = overflow || any;  // rows left after XSW_BAND_MAX trips
         if (K == 1 && S != 64) bip = ip[0];
     }
@@ -398,7 +399,8 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
             // the directions: CMOD5.N saturates and then falls back slowly, so this is the common case of an a-priori wind well
             // above the one sigma0 points to; upwind and crosswind saturate several dB apart, hence per direction).  Those rows
             // cannot hold the argmin (their sigma0 term alone exceeds J_ub): the window is cut at the last monotone row.
-            int w_hi_e = W.w_hi, tail_n = 0;
+            int w_hi_e = W.w_hi;
+            bool has_tail = false;  // the rows w_hi_e + 1 .. W.w_hi are the window's tail (below)
             if (!BITONIC && L.tail_min) {
                 const bool fin1 = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0;
                 const int mono1 = L.mono_rows[fin1 ? P.i_inc : 0];
@@ -411,12 +413,12 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                     // pixels that used to cost k_invert_list the most (whole windows of 1e4 candidates, one pixel at a time).  The
                     // band rule still holds on the monotone part; the rows past it, at most A.tail_max, are swept in full by
                     // k_invert_band2 (clipped to the disc's chord like every row there): the window is cut and the tail noted.
-                    else if (ROLE != 0 && mono1 >= 1 && W.w_hi - mono1 + 1 <= A.tail_max) { tail_n = W.w_hi - mono1 + 1; w_hi_e = mono1 - 1; }
+                    else if (ROLE != 0 && mono1 >= 1 && W.w_hi - mono1 + 1 <= A.tail_max) { has_tail = true; w_hi_e = mono1 - 1; }
                 }
             }
             const int nrows_p = w_hi_e - W.w_lo + 1;
             ncols_p = W.ip_hi - W.ip_lo + 1;
-            const bool need = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0 && !loose && ncols_p >= 1 && (nrows_p >= 1 || tail_n > 0);
+            const bool need = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0 && !loose && ncols_p >= 1 && (nrows_p >= 1 || has_tail);
             if (ROLE == 2 && strip_walk) skip = !need || !(w_hi_e < L.mono_rows[need ? P.i_inc : 0]);  // everything k_invert_band did not hand over
             if (BITONIC) {
                 eligb = need && L.bitonic_ok[need ? P.i_inc : 0] != 0;  // every column of the slice rises, then falls
@@ -465,16 +467,17 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                         return min(rb - 1, w_hi_e) - max(ra, W.w_lo) + 1;
                     };
                     run = run_at(P.ipr);  // (the window's first and last directions as well: hands over 3.5x the pixels for 2 ms less here, 4 ms more there)
-                    if (tail_n > 0) run = max(run, 0) + tail_n;
+                    if (has_tail) run = max(run, 0) + (W.w_hi - w_hi_e);  // the tail's rows count as run
                 }
                 // (a run beyond XSW_LONG_RUN_MAX rows -- the flat top of a saturating GMF -- would overflow k_invert_band2's sweep
                 // after costing it the most: such a pixel goes straight to the general kernel)
-                if (eligb && run > ((w_hi_e < W.w_hi && tail_n == 0) ? A.run_max_cut : A.run_max)) {
+                // (without the cap on tail pixels: a-priori x 1.6 1189 -> 963 Mpx/s, x 2.5 377 -> 204: k_invert_band2 drowns in them)
+                if (eligb && run > ((w_hi_e < W.w_hi && !has_tail) ? XSW_LONG_RUN_MAX_CUT : XSW_LONG_RUN_MAX)) {
                     myc = NC;
                     eligb = false;
                     if (ROLE == 2) skip = true;
                 }
-                const bool handed = eligb && (run >= A.long_run || tail_n > 0);  // (a tail is k_invert_band2's whatever its length)
+                const bool handed = eligb && (run >= A.long_run || has_tail);  // (a tail is k_invert_band2's whatever the run's length)
                 if (ROLE == 1 && handed) {  // the second band kernel's
                     myc = NC;
                     eligb = false;
@@ -515,7 +518,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                 b.ah = ah; b.bh = bh; b.m2 = ah * ah + bh * bh;
                 b.inc_bin = P.i_inc | (bin << 16); b.rows = W.w_lo | (w_hi_e << 16); b.ipn = W.ip_lo | (ncols_p << 16);
                 b.bin_hi = bhi < XSW_INV_BINS ? bhi : (BITONIC ? XSW_INV_BINS /* the tabulated +inf threshold */ : -1);
-                if (ROLE == 2) b.bin_hi = (b.bin_hi & 0xffff) | (tail_n << 16);  // co_band_pass: rows past the monotone ones
+                if (ROLE == 2) b.bin_hi = (b.bin_hi & 0xffff) | ((has_tail ? W.w_hi - w_hi_e : 0) << 16);  // co_band_pass: rows past the monotone ones
                 slots[pos] = b;
 #ifdef XSW_TIMING_STAGE1_ONLY
                 res_[pos] = 0;   // (timing build: pretend the pass decided, so that nothing floods the work list)
@@ -534,7 +537,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
         auto run = [&](auto seg, auto kk, int c) {
             constexpr int S = decltype(seg)::value, K = decltype(kk)::value;
             for (int p = 0; p < ncls[c]; p += 64 / S)
-                co_band_pass<S, K, COUNT, BITONIC, ROLE == 2>(L, A.inv_dsig_co, lane, slots, res_, first[c] + p, min(64 / S, ncls[c] - p), cand, ROLE == 2 ? A.sweep_max : XSW_BAND_MAX);
+                co_band_pass<S, K, COUNT, BITONIC, ROLE == 2>(L, A.inv_dsig_co, lane, slots, res_, first[c] + p, min(64 / S, ncls[c] - p), cand);
         };
         using two = std::integral_constant<int, 2>;
         using three = std::integral_constant<int, 3>;

@@ -99,9 +99,7 @@ struct KArgs {
     // the whole raster.
     unsigned long long *mask_g, *mask_b;
     int long_run;               // k_invert_band, ROLE 1: rows along the a-priori direction from which a pixel is handed to k_invert_band2
-    int run_max, run_max_cut;   // ... and beyond which it goes straight to the list (run_max_cut: windows cut at the last monotone row)
-    int sweep_max;              // k_invert_band2's long-run role: rows a direction may hold before the pixel is left to k_invert_list
-    int tail_max;               // ... and rows past the monotone ones a window may hold to be swept there (tail sweep; 0: never)
+    int tail_max;               // rows past the monotone ones a window may hold for k_invert_band2's tail sweep (0: never)
     long long n, lines, samples;
     double dsig_co, inv_dsig_co, dsig_cr_scalar;
     int is_db, dual_select;
