@@ -16,6 +16,11 @@
 // scan, any LUT): window outside the monotone rows, non-finite inputs, near-ties, bands longer than XSW_BAND_MAX rows, cross-pol
 // pixels the interval rule cannot decide.  Keeping the rare, register-hungry paths out of k_invert_band is what lets it run at
 // 8 waves per SIMD.
+// A window that reaches PAST the monotone rows (an a-priori wind above the truth, sigma0 near the GMF's saturation) is still
+// the band kernels' in two cases (band_wave, stage 1): no row up there can be in the band (TAIL CUT: L.tail_min, a sparse table
+// of per-direction minima of the rows past the monotone ones), or there are few enough of them (TAIL SWEEP: the band rule on
+// the monotone part, the rows past it swept in full by k_invert_band2).  A work list that overflows is continued in a STRIP
+// MASK (KArgs::mask_g / mask_b: one bit per pixel), so that its consumer takes exactly the pixels meant.
 //
 // Finding the interval: a monotone column is inverted ONCE, at LUT install (L.inv_rows: for 2048 dB thresholds per incidence
 // slice, the first row of every direction at or above the threshold; xsw_lutbuild.hpp).  The largest threshold <= s - d
