@@ -375,15 +375,18 @@ def host_path_figure(inc, s_vv, anc, samples, lines_host=5000):
 
 def hard_scene_figures(ctx, _lib, stream, device, samples, algo, lines_hs=4000):
     """The benchmark scene is the friendly case for an exact branch-and-bound: its a-priori wind is the truth + 1.5 m/s, so the
-    bound is tight and ~50 of 90 319 candidates are scored.  Two scenes where it is not, on a 4000-line band through the
+    bound is tight and ~50 of 90 319 candidates are scored.  Three scenes where it is not, on a 4000-line band through the
     cyclone of the same generator (always reported, never part of `value`): the a-priori wind scaled by 0.6 (the feasible
-    set is an arc of the sigma0 contour: hundreds of candidates per pixel genuinely score below the bound), and incidences
-    17..33 deg (CMOD5.N saturates and turns over inside many search windows).  Results stay exact (tests, campaigns)."""
+    set is an arc of the sigma0 contour: hundreds of candidates per pixel genuinely score below the bound) and by 1.6 (the
+    windows reach into the saturated rows of CMOD5.N), and incidences 17..33 deg (CMOD5.N saturates and turns over inside
+    many search windows).  Results stay exact (tests, campaigns; profiles/hard_scenes.py --verify compares ten such scenes
+    with the exhaustive sweep)."""
     out = {}
     lines_hs = int(lines_hs)
     o = torch.empty((lines_hs, samples), dtype=torch.complex64, device=device)
     for key, inc_range, scale, what in (("friendly_band", (30.0, 46.0), 1.0, "the benchmark scene's own lines 8000..12000 (through the cyclone)"),
                                         ("ancillary_x0.6", (30.0, 46.0), 0.6, "a-priori wind = 0.6 x truth + noise, incidence 30..46 deg"),
+                                        ("ancillary_x1.6", (30.0, 46.0), 1.6, "a-priori wind = 1.6 x truth + noise, incidence 30..46 deg (windows into the GMF's saturated rows)"),
                                         ("incidence_17_33", (17.0, 33.0), 1.0, "incidence 17..33 deg, a-priori wind = truth + noise")):
         inc, s_vv, anc = make_scene(lines_hs, samples, 20000, 8000, 20260320 + 7, device, inc_range=inc_range, anc_scale=scale)
         torch.cuda.synchronize()
