@@ -1383,8 +1383,15 @@ __global__ __launch_bounds__(256, XSW_LIST_WAVES) void k_invert_list(DevTables L
 #ifndef XSW_LIST_PX
 #define XSW_LIST_PX 16
 #endif
-    // a long list (a LUT or scene the band rule rarely applies to) fills the waves instead: 64 pixels per wave
-    const int ppw = nlist >= 64LL * nwaves ? 64 : XSW_LIST_PX;  // measured at 2.3e5 pixels: 16 per wave 2.6 ms, 64 per wave 3.5 ms
+    // a long list (a LUT or scene the band rule rarely applies to) fills the waves instead: 64 pixels per wave (measured at 2.3e5
+    // pixels: 16 per wave 2.6 ms, 64 per wave 3.5 ms); a SHORT list is spread over all the waves of the grid -- 1, 2, 4, 8 pixels
+    // per wave: what is left on a short list are the heaviest windows of the scene (1e4 candidates each), and a wave takes its
+    // pixels one after the other, so 16 of them in one wave were the whole of this kernel's time on the benchmark scene
+    int ppw = 64;
+    if (nlist < 64LL * nwaves) {
+        ppw = 1;
+        while (ppw < XSW_LIST_PX && (long long)ppw * nwaves < nlist) ppw <<= 1;
+    }
     for (long long c = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); c * ppw < nlist; c += nwaves) {  // wave-uniform
         const long long k = c * ppw + lane;
         const bool in = lane < ppw && k < nlist;
