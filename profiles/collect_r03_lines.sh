@@ -22,5 +22,5 @@ timeout -k 10 400 python3 tests/campaign_pruned_vs_exhaustive.py > $O/campaign_p
 tail -1 $O/campaign_pruned_vs_exhaustive.txt
 timeout -k 10 300 python3 tests/campaign_dual_pruned_vs_exact.py > $O/campaign_dual_pruned_vs_exact.txt 2>> $O/bench.err || exit 1
 tail -1 $O/campaign_dual_pruned_vs_exact.txt
-XSW_RANDOM_CASES=${XSW_RANDOM_CASES:-20000} timeout -k 10 500 python3 -m pytest tests/test_gpu_kernel.py -m gpu -q -k random_configurations > $O/random_soak.txt 2>&1 || exit 1
+XSW_RANDOM_CASES=${XSW_RANDOM_CASES:-12000} timeout -k 10 500 python3 -m pytest tests/test_gpu_kernel.py -m gpu -q -k random_configurations > $O/random_soak.txt 2>&1 || exit 1
 tail -1 $O/random_soak.txt
