@@ -356,3 +356,147 @@ def chord_rows(ah, bh, cphi_e, sphi_e, thr_lo, thr_hi, inv_dsig, w0, inv_wstep):
     inv_whs = 2.0 * inv_wstep
     xc, xh = (uh - 0.5 * w0) * inv_whs, h * inv_whs + CHORD_MRG
     return int(np.ceil(max(xc - xh, -4.0))), int(np.floor(min(xc + xh, 40000.0)))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Block pyramid (round 4, `co_block_search` of the general kernel): a bound from the TABLE side, for the pixels whose a-priori
+# wind does not confine the search (sigma0 outliers: windows covering the whole grid; windows past the monotone rows with long
+# runs).  The slice is cut into blocks of BLK_R speed rows x BLK_C directions; per block the smallest and largest LUT value
+# (float32, rounded outward; xsw_lutbuild.hpp: k_block_minmax) and per BAND of `band_rows(n_phi)` block rows the same over all
+# directions (k_band_minmax).  For a pixel,
+#     LB(block) = (max(0, lo - s, s - hi) / dsig)^2 + (distance of m/2 to the block's polar cell in half-speed units)^2
+# is a lower bound of J = Jsig + Jwind over the block's candidates: BOTH terms bound together, where the window (disc) and the
+# band rule bound each term separately.  Any LUT (no monotonicity), any s.  A block is skipped when LB (deflated) exceeds the
+# best score known (the ray's J_ub, then the running minimum of the sweep); a candidate of a skipped block scores strictly
+# above an examined one in the reference's arithmetic, so it cannot be the argmin and cannot tie with it.
+BLK_R, BLK_C = 4, 16
+
+
+def f32_down(x):
+    y = np.float32(x)
+    return y if float(y) <= x else np.nextafter(y, np.float32(-np.inf))
+
+
+def f32_up(x):
+    y = np.float32(x)
+    return y if float(y) >= x else np.nextafter(y, np.float32(np.inf))
+
+
+def block_tables(slice_wp):
+    """(lo, hi) float32 [nbr, nbc]: outward-rounded min / max of every BLK_R x BLK_C block of the (n_w, n_phi) slice."""
+    n_w, n_phi = slice_wp.shape
+    nbr, nbc = -(-n_w // BLK_R), -(-n_phi // BLK_C)
+    lo, hi = np.empty((nbr, nbc), np.float32), np.empty((nbr, nbc), np.float32)
+    for br in range(nbr):
+        for bc in range(nbc):
+            blk = slice_wp[br * BLK_R:(br + 1) * BLK_R, bc * BLK_C:(bc + 1) * BLK_C]
+            lo[br, bc], hi[br, bc] = f32_down(float(blk.min())), f32_up(float(blk.max()))
+    return lo, hi
+
+
+def band_rows(n_phi):
+    """Block rows per band = the block rows one wave trip of 64 lanes covers (lane = block): 64 // nbc, at least 1."""
+    return max(1, 64 // (-(-n_phi // BLK_C)))
+
+
+def band_tables(lo, hi, n_phi):
+    g = band_rows(n_phi)
+    nb = -(-lo.shape[0] // g)
+    return (np.array([lo[t * g:(t + 1) * g].min() for t in range(nb)], np.float32),
+            np.array([hi[t * g:(t + 1) * g].max() for t in range(nb)], np.float32))
+
+
+def sig_lb(lo, hi, s, inv_dsig):
+    d = max(0.0, float(lo) - s, s - float(hi))
+    return (d * abs(inv_dsig)) ** 2
+
+
+def radial_lb(mh, wha, whb):
+    """(| |c|/2 - |m|/2 |)^2 <= |c - m|^2 / 4 for every c with wha <= |c|/2 <= whb."""
+    r = max(0.0, wha - mh, mh - whb)
+    return r * r
+
+
+def cell_wind_lb(ah, bh, wha, whb, ca, sa, cb, sb, span_deg):
+    """Lower bound of |c/2 - m/2|^2 over the polar cell  wha <= |c|/2 <= whb,  direction between the unit vectors (ca, sa) and
+    (cb, sb) (counter-clockwise from a to b, span_deg < 170): the radial bound, and -- when m lies outside the cell's angular
+    sector -- the squared distance to the nearer edge segment.  m = 2 (ah, bh)."""
+    m2 = ah * ah + bh * bh
+    mh = np.sqrt(m2)
+    lb = radial_lb(mh, wha, whb)
+    if not (span_deg < 170.0):
+        return lb
+    tol = 1e-9 * (mh + 1e-300)
+    inside = (ca * bh - sa * ah >= -tol) and (ah * sb - bh * cb >= -tol)  # cross(ea, m) >= 0 and cross(m, eb) >= 0
+    if inside:
+        return lb
+    pm = max(ah * ca + bh * sa, ah * cb + bh * sb)  # |m/2| cos(angle to the nearer edge)
+    t = min(max(pm, wha), whb)
+    return max(lb, m2 + t * (t - 2.0 * pm))
+
+
+def block_keep(lb, j_ub, m2):
+    """A block (band) is examined unless its lower bound, deflated for the rounding of its own arithmetic, exceeds the bound."""
+    return not (lb * (1.0 - 1e-8) > j_ub + 1e-8 * (1.0 + m2))
+
+
+def block_pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig, j_ub=np.inf, window=None, tables=None):
+    """The reference's argmin of one pixel by the block pyramid.  j_ub: any valid upper bound of the minimum of J (inf: none);
+    window = (w_lo, w_hi, ip_lo, ip_hi): only blocks that touch it are looked at (the disc's bounding box; None: the grid).
+    Returns (i_wspd, i_phi, blocks swept, bands kept)."""
+    n_w, n_phi = slice_wp.shape
+    if phi_180:
+        b = abs(b)
+    lo, hi = tables if tables is not None else block_tables(slice_wp)
+    blo, bhi = band_tables(lo, hi, n_phi)
+    g = band_rows(n_phi)
+    nbr, nbc = lo.shape
+    inv = 1.0 / dsig
+    sn = -s * inv
+    ah, bh = 0.5 * a, 0.5 * b
+    m2 = ah * ah + bh * bh
+    mh = np.sqrt(m2)
+    wh = 0.5 * wspd
+    dphi = (phi[-1] - phi[0]) / (n_phi - 1)
+    w_lo, w_hi, ip_lo, ip_hi = window if window is not None else (0, n_w - 1, 0, n_phi - 1)
+    br_lo, br_hi, bc_lo, bc_hi = w_lo // BLK_R, w_hi // BLK_R, ip_lo // BLK_C, ip_hi // BLK_C
+
+    def lb_of(br, bc):
+        r0, r1 = br * BLK_R, min(br * BLK_R + BLK_R, n_w) - 1
+        c0, c1 = bc * BLK_C, min(bc * BLK_C + BLK_C, n_phi) - 1
+        return sig_lb(lo[br, bc], hi[br, bc], s, inv) + cell_wind_lb(ah, bh, wh[r0], wh[r1], cphi[c0], sphi[c0], cphi[c1], sphi[c1],
+                                                                       (c1 - c0) * dphi)
+
+    cand = {}  # flat -> screening score
+    state = {"jub": j_ub, "swept": 0, "bands": 0}
+
+    def sweep(br, bc):
+        state["swept"] += 1
+        for r in range(br * BLK_R, min(br * BLK_R + BLK_R, n_w)):
+            for c in range(bc * BLK_C, min(bc * BLK_C + BLK_C, n_phi)):
+                u = 2.0 * (ah * cphi[c] + bh * sphi[c])
+                js = wh[r] * (wh[r] - u) + (slice_wp[r, c] * inv + sn) ** 2
+                cand[r * n_phi + c] = js
+                state["jub"] = min(state["jub"], (js + m2) * (1.0 + 1e-9) + 1e-9)
+
+    for t in range(br_lo // g, br_hi // g + 1):
+        rows0, rows1 = t * g * BLK_R, min((t + 1) * g * BLK_R, n_w) - 1
+        lb1 = sig_lb(blo[t], bhi[t], s, inv) + radial_lb(mh, wh[rows0], wh[rows1])
+        if not block_keep(lb1, state["jub"], m2):
+            continue
+        state["bands"] += 1
+        for br in range(max(t * g, br_lo), min((t + 1) * g, nbr, br_hi + 1)):
+            for bc in range(bc_lo, bc_hi + 1):
+                if block_keep(lb_of(br, bc), state["jub"], m2):
+                    sweep(br, bc)
+    assert cand, "nothing examined: j_ub was not an upper bound of the minimum"
+    gmin = min(cand.values())
+    T = gmin + screening_eps(gmin, m2)
+    best = None
+    for flat, js in cand.items():
+        if js <= T:
+            iw, ip = divmod(flat, n_phi)
+            key = (exact_J(wspd[iw], cphi[ip], sphi[ip], slice_wp[iw, ip], s, a, b, dsig), flat)
+            if best is None or key < best:
+                best = key
+    return best[1] // n_phi, best[1] % n_phi, state["swept"], state["bands"]

@@ -5,10 +5,12 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
-SRC = os.path.join(HERE, "csrc", "xsw.hip")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("xsw.hip", "xsw_device.hpp", "xsw_exhaustive.hpp", "xsw_gmf.hpp", "xsw_nesz.hpp", "xsw_lutbuild.hpp", "xsw_band.hpp")] + [
-    os.path.join(REPO, "include", "xsw.h")]
+CSRC = os.path.join(HERE, "csrc")
+SRC = os.path.join(CSRC, "xsw.hip")          # context, LUT install, C ABI, the HBM-bound kernels
+SRC_TU = os.path.join(CSRC, "xsw_invert_tu.hip")  # the search kernels of one (input dtype, output dtype) pair: -DXSW_PAIR=0..3
+DEPS = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))] + [os.path.join(REPO, "include", "xsw.h")]
 LIB = os.environ.get("XSW_LIB") or os.path.join(HERE, "libxsw.so")  # XSW_LIB: experiment builds only
+OBJDIR = os.path.join(REPO, "build", "obj")
 ARCH = "gfx950"
 
 
@@ -27,16 +29,32 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
-    """Compile csrc/xsw.hip -> libxsw.so for gfx950.  -ffp-contract=off: the kernels decide exact
-    float64 orderings; FMAs appear only where written explicitly."""
+    """Compile csrc/*.hip -> libxsw.so for gfx950: five translation units side by side (xsw.hip + the search kernels of each
+    dtype pair), then one link.  -ffp-contract=off: the kernels decide exact float64 orderings; FMAs appear only where
+    written explicitly."""
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-I" + os.path.join(REPO, "include"), "-I" + os.path.join(HERE, "csrc"),
-           "-o", LIB, SRC, "-Wl,-rpath,/opt/rocm/lib"] + os.environ.get("XSW_EXTRA_FLAGS", "").split()  # experiment builds only
+    cc = hipcc()
+    extra = os.environ.get("XSW_EXTRA_FLAGS", "").split()  # experiment builds only
+    tag = os.path.basename(LIB).replace(".", "_")
+    os.makedirs(OBJDIR, exist_ok=True)
+    common = [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+              "-I" + os.path.join(REPO, "include"), "-I" + CSRC] + extra
+    jobs = [(SRC, os.path.join(OBJDIR, f"{tag}_main.o"), [])]
+    jobs += [(SRC_TU, os.path.join(OBJDIR, f"{tag}_pair{k}.o"), [f"-DXSW_PAIR={k}"]) for k in range(4)]
+    procs = []
+    for src, obj, defs in jobs:
+        cmd = common + defs + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    failed = [cmd for cmd, p in procs if p.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
+    link = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + [obj for _, obj, _ in jobs] + ["-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link))
+    subprocess.check_call(link)
     return LIB
 
 

@@ -1,0 +1,88 @@
+// Host-side types shared by the translation units of libxsw (xsw.hip: context, LUT install, C ABI; xsw_invert_tu.hip: the
+// kernel launches of one (input dtype, output dtype) pair each, compiled side by side).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "xsw.h"
+#include "xsw_device.hpp"
+
+#ifndef XSW_ARENA_KEEP
+#define XSW_ARENA_KEEP ((size_t)24 << 30)
+#endif
+struct xsw_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    xsw::DevTables T{};
+    std::vector<void *> co_allocs, cr_allocs;
+    bool have_co = false, have_cr = false;
+    unsigned long long *d_stats = nullptr;
+    bool stats_on = false;
+    bool timing_on = false;                 // xsw_timing_enable: HIP events around the kernels of every device-memory inversion
+    std::vector<hipEvent_t> timing_events;  // quadruples (start, after k_invert_band, after k_invert_band2, end) on the launch stream
+    unsigned *d_list = nullptr;  // hand-over k_invert_band -> k_invert_list: [0] = count, [16..] = pixel indices
+    size_t list_cap = 0;         // entries (context-owned, grown on demand: an eighth of the largest raster seen)
+    unsigned long long *d_masks = nullptr;  // strip masks (2 x mask_strips words, after the lists in the same allocation)
+    size_t mask_strips = 0;
+    double *d_ratio = nullptr;  // detrend ratio row (context-owned, grown on demand)
+    size_t ratio_cap = 0;
+    void *nesz_scratch = nullptr;  // xsw_nesz_flatten: column partials + means (context-owned, grown on demand)
+    size_t nesz_cap = 0;
+    // host-memory paths: worker w owns a stream, a page-locked staging buffer and a device staging buffer, all kept between calls
+    struct Worker { hipStream_t s = nullptr; char *pin = nullptr; size_t pin_cap = 0; char *dev = nullptr; size_t dev_cap = 0; };
+    std::vector<Worker> workers;
+    int host_threads = 0;  // 0: XSW_HOST_THREADS or 12
+    char *arena = nullptr;      // whole-raster device staging (xsw_nesz_flatten on host rasters; kept up to XSW_ARENA_KEEP bytes)
+    size_t arena_cap = 0;
+    std::vector<void *> host_allocs;  // xsw_host_alloc
+    // host copies of the output-forming tables (xsw_expand_codes on host memory; the expansion of the host-memory paths)
+    std::vector<double> h_sol, h_dual, h_wcr;
+    std::vector<float> h_sol32;
+    std::string err;
+};
+
+
+static inline void timing_mark(xsw_ctx *c)
+
+{
+    if (!c->timing_on) return;
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) == hipSuccess && hipEventRecord(e, c->stream) == hipSuccess) c->timing_events.push_back(e);
+    else c->timing_on = false;  // never half a quadruple
+}
+
+
+static inline int seterr(std::string &e, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    e = buf;
+    return code;
+}
+
+// Where an inversion launches: its stream and the work list that hands pixels from k_invert_band to k_invert_list (device
+// rasters: the context's; host rasters: the worker's own, so that the chunks of different workers run side by side).
+struct LaunchCtl {
+    hipStream_t stream;
+    unsigned *list;    // [0] = count, [16 ..] = entries; nullptr: one-kernel path
+    size_t list_cap;   // entries
+    bool timing;       // xsw_timing_enable events (context stream only)
+    unsigned long long *masks = nullptr;  // strip masks (KArgs::mask_g, then mask_b), mask_strips words each; nullptr: none
+    size_t mask_strips = 0;
+};
+
+
+// One (input dtype, output dtype) pair of the inversion launches per translation unit (xsw_invert_tu.hip, -DXSW_PAIR=0..3:
+// f32->f32, f32->f64, f64->f32, f64->f64), so that the four sets of kernel instantiations compile side by side.
+int xsw_launch_invert_ff(xsw_ctx *c, const xsw::KArgs &A, int algo, const LaunchCtl &lc, std::string &err);
+int xsw_launch_invert_fd(xsw_ctx *c, const xsw::KArgs &A, int algo, const LaunchCtl &lc, std::string &err);
+int xsw_launch_invert_df(xsw_ctx *c, const xsw::KArgs &A, int algo, const LaunchCtl &lc, std::string &err);
+int xsw_launch_invert_dd(xsw_ctx *c, const xsw::KArgs &A, int algo, const LaunchCtl &lc, std::string &err);

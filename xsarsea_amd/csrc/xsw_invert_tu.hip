@@ -1,0 +1,119 @@
+// The search kernels of ONE (input dtype, output dtype) pair and their launch logic (-DXSW_PAIR=0..3; xsarsea_amd/_build.py
+// compiles the four side by side and links them with xsw.hip into libxsw.so).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <string>
+
+#include "xsw_host.hpp"
+#include "xsw_band.hpp"
+#include "xsw_exhaustive.hpp"
+
+using namespace xsw;
+
+template <typename T, typename TO>
+static int launch_invert(xsw_ctx *c, const KArgs &A, int algo, const LaunchCtl &lc, std::string &err)
+{
+    // k_invert grid: 8 XCD lanes x ceil(columns/8) tile columns x line groups (see the kernel)
+    const long long strips_per_line = (A.samples + 63) / 64, line_groups = (A.lines + 3) / 4;
+    const long long nblocks = 8 * ((strips_per_line + 7) / 8) * line_groups;
+    if (nblocks > 0x7fffffffLL) return seterr(err, XSW_EINVAL, "raster too large for one launch");
+    const bool mono = !A.s_cr && !A.out_cr && !A.code_cr;
+    if (algo == XSW_ALGO_EXHAUSTIVE || algo == XSW_ALGO_EXHAUSTIVE_F64)
+        return launch_exhaustive<T, TO>(c->T, A, lc.stream, algo == XSW_ALGO_EXHAUSTIVE) == hipSuccess
+                   ? XSW_OK : seterr(err, XSW_EHIP, "exhaustive launch failed: %s", hipGetErrorString(hipGetLastError()));
+    // Two-kernel fast path: k_invert_band finishes every pixel the band rule decides (monotone LUT rows, finite inputs,
+    // unique minimum; cross-pol by the interval rule) and appends the rest to a work list; k_invert_list inverts those
+    // (all tiles, should the list overflow).
+    static const bool band_off = getenv("XSW_NO_BAND") != nullptr;  // experiments / A-B measurements only
+    if (algo == XSW_ALGO_PRUNED && !band_off && lc.list && A.s_co && c->T.prunable && c->T.mono_rows && c->T.inv_rows && c->T.co_off32 &&
+        (!A.s_cr || c->T.cr_monotone) && A.n < (1LL << 32)) {
+        KArgs B = A;
+        B.list_count = lc.list;
+        B.list = lc.list + 16;
+        B.list_cap = (unsigned)std::min<size_t>(lc.list_cap, 0xfffffff0u);
+        // list B (k_invert_band -> k_invert_band2) follows list G.  Long-run role (the default): a pixel whose band holds
+        // XSW_LONG_RUN (4) or more rows along the a-priori direction is handed to k_invert_band2 -- one such pixel holds up every
+        // pixel of its pass in k_invert_band, and where the a-priori wind is far from the sigma0 contour most pixels are such.
+        // XSW_LONG_RUN=0: never (k_invert_band sweeps every window; A/B measurements).  XSW_BAND2=1 (opt-in): the
+        // rise-then-fall rule instead.  The statistics instantiation sweeps every window in k_invert_band as well.
+        static const int long_run_env = getenv("XSW_LONG_RUN") ? std::max(0, atoi(getenv("XSW_LONG_RUN"))) : 4;
+        const bool bitonic2 = c->T.inv2 != nullptr && !A.stats, wide2 = !bitonic2 && long_run_env > 0 && !A.stats;
+        const bool band2 = bitonic2 || wide2;
+        if (band2) { B.list_b_count = lc.list + 1; B.list_b = lc.list + 16 + lc.list_cap; B.list_b_cap = B.list_cap; }
+        B.long_run = long_run_env;
+        static const int tail_max_env = getenv("XSW_TAIL_SWEEP") ? std::min(std::max(0, atoi(getenv("XSW_TAIL_SWEEP"))), 30000) : XSW_TAIL_SWEEP;
+        B.tail_max = (wide2 && c->T.tail_min) ? tail_max_env : 0;  // the long-run role of k_invert_band2 only
+        // strip masks: what the consumers walk when a list overflows (only the marked pixels instead of the whole raster)
+        static const bool masks_off = getenv("XSW_NO_STRIP_MASKS") != nullptr;  // A/B measurements and the tests of the old route
+        const size_t nstrips = (size_t)(strips_per_line * A.lines);
+        if (lc.masks && nstrips <= lc.mask_strips && !masks_off) {
+            B.mask_g = lc.masks; B.mask_b = lc.masks + nstrips;  // side by side: one reset (0.25 B per pixel)
+            if (hipMemsetAsync(lc.masks, 0, 2 * nstrips * sizeof(unsigned long long), lc.stream) != hipSuccess) return seterr(err, XSW_EHIP, "strip-mask reset failed");
+        }
+        if (hipMemsetAsync(lc.list, 0, 2 * sizeof(unsigned), lc.stream) != hipSuccess) return seterr(err, XSW_EHIP, "work-list reset failed");
+        const unsigned list_blocks = (unsigned)std::min<long long>(nblocks, 256 * 8);  // 8 waves per SIMD
+        // k_invert_band: x = XCD lane + 8 * line group, y = tile column inside the XCD's range (see the kernel)
+        const long long cols_per_xcd = (strips_per_line + 7) / 8;
+        const long long band_groups = (A.lines + XSW_BAND_WG_WAVES - 1) / XSW_BAND_WG_WAVES;
+        if (8 * band_groups > 0x7fffffffLL || cols_per_xcd > 65535) return seterr(err, XSW_EINVAL, "raster too large for one launch");
+        const dim3 band_grid((unsigned)(8 * band_groups), (unsigned)cols_per_xcd), band_block(64 * XSW_BAND_WG_WAVES);
+        if (lc.timing) timing_mark(c);
+        if (A.stats) {  // statistics instantiation (counts the scored candidates)
+            if (mono) hipLaunchKernelGGL((k_invert_band<T, TO, false, true>), band_grid, band_block, 0, lc.stream, c->T, B);
+            else hipLaunchKernelGGL((k_invert_band<T, TO, true, true>), band_grid, band_block, 0, lc.stream, c->T, B);
+        } else if (wide2) {
+            if (mono) hipLaunchKernelGGL((k_invert_band<T, TO, false, false, 1>), band_grid, band_block, 0, lc.stream, c->T, B);
+            else hipLaunchKernelGGL((k_invert_band<T, TO, true, false, 1>), band_grid, band_block, 0, lc.stream, c->T, B);
+        } else if (mono) {
+            hipLaunchKernelGGL((k_invert_band<T, TO, false, false>), band_grid, band_block, 0, lc.stream, c->T, B);
+        } else {
+            hipLaunchKernelGGL((k_invert_band<T, TO, true, false>), band_grid, band_block, 0, lc.stream, c->T, B);
+        }
+        if (lc.timing) timing_mark(c);
+        if (band2) {
+            const dim3 b2_grid((unsigned)std::min<long long>(nblocks, 256 * XSW_BAND2_WAVES));  // XSW_BAND2_WAVES waves per SIMD, 4-wave workgroups
+            if (bitonic2) {
+                if (mono) hipLaunchKernelGGL((k_invert_band2<T, TO, false, true>), b2_grid, band_block, 0, lc.stream, c->T, B);
+                else hipLaunchKernelGGL((k_invert_band2<T, TO, true, true>), b2_grid, band_block, 0, lc.stream, c->T, B);
+            } else {
+                if (mono) hipLaunchKernelGGL((k_invert_band2<T, TO, false, false>), b2_grid, band_block, 0, lc.stream, c->T, B);
+                else hipLaunchKernelGGL((k_invert_band2<T, TO, true, false>), b2_grid, band_block, 0, lc.stream, c->T, B);
+            }
+        }
+        if (lc.timing) timing_mark(c);
+#ifdef XSW_LIST_CLOCK  // experiments: k_invert_list alone counts into the statistics buffer (xsw_stats_read), see the kernel
+        if (!B.stats) { (void)hipMemsetAsync(c->d_stats, 0, 4 * sizeof(unsigned long long), lc.stream); B.stats = c->d_stats; }
+#endif
+        if (mono) hipLaunchKernelGGL((k_invert_list<T, TO, false>), dim3(list_blocks), dim3(256), 0, lc.stream, c->T, B);
+        else hipLaunchKernelGGL((k_invert_list<T, TO, true>), dim3(list_blocks), dim3(256), 0, lc.stream, c->T, B);
+        if (lc.timing) timing_mark(c);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return seterr(err, XSW_EHIP, "launch failed: %s", hipGetErrorString(e));
+        return XSW_OK;
+    }
+    if (algo == XSW_ALGO_PRUNED && mono)
+        hipLaunchKernelGGL((k_invert<T, TO, 1, false>), dim3((unsigned)nblocks), dim3(256), 0, lc.stream, c->T, A);
+    else if (algo == XSW_ALGO_PRUNED)
+        hipLaunchKernelGGL((k_invert<T, TO, 1>), dim3((unsigned)nblocks), dim3(256), 0, lc.stream, c->T, A);
+    else
+        hipLaunchKernelGGL((k_invert<T, TO, 3>), dim3((unsigned)nblocks), dim3(256), 0, lc.stream, c->T, A);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return seterr(err, XSW_EHIP, "launch failed: %s", hipGetErrorString(e));
+    return XSW_OK;
+}
+
+
+#ifndef XSW_PAIR
+#error "compile with -DXSW_PAIR=0..3"
+#endif
+#if XSW_PAIR == 0
+int xsw_launch_invert_ff(xsw_ctx *c, const KArgs &A, int algo, const LaunchCtl &lc, std::string &err) { return launch_invert<float, float>(c, A, algo, lc, err); }
+#elif XSW_PAIR == 1
+int xsw_launch_invert_fd(xsw_ctx *c, const KArgs &A, int algo, const LaunchCtl &lc, std::string &err) { return launch_invert<float, double>(c, A, algo, lc, err); }
+#elif XSW_PAIR == 2
+int xsw_launch_invert_df(xsw_ctx *c, const KArgs &A, int algo, const LaunchCtl &lc, std::string &err) { return launch_invert<double, float>(c, A, algo, lc, err); }
+#else
+int xsw_launch_invert_dd(xsw_ctx *c, const KArgs &A, int algo, const LaunchCtl &lc, std::string &err) { return launch_invert<double, double>(c, A, algo, lc, err); }
+#endif
