@@ -87,11 +87,13 @@ def cmod5n_torch(inc, v, phi_deg):
     return b0 * (1.0 + b1 * cosphi + b2 * (2.0 * cosphi * cosphi - 1.0)) ** 1.6
 
 
-def make_scene(lines, samples, total_lines, line0, seed, device, chunk=500, inc_range=(30.0, 46.0), anc_scale=1.0):
+def make_scene(lines, samples, total_lines, line0, seed, device, chunk=500, inc_range=(30.0, 46.0), anc_scale=1.0, outlier_frac=0.0):
     """SURVEY.md 8d generator: incidence ramp 30..46 deg, cyclone-like wind, ENL-100 speckle, ancillary =
     truth + smooth 1.5 m/s noise, 0.5 % NaN sigma0, first 8 samples NaN incidence.  float32/complex64.
     inc_range / anc_scale: the hard scenes of the bench line (near-range incidences where CMOD5.N saturates and turns over
-    inside the search windows; an a-priori wind that is `anc_scale` times the truth)."""
+    inside the search windows; an a-priori wind that is `anc_scale` times the truth).  outlier_frac: that share of the pixels,
+    in blobs of 16 x 16 pixels, has its sigma0 multiplied by 10 (+10 dB; half of the blobs) or by 31.6 (+15 dB): ships, land, ice,
+    rain cells -- sigma0 that no wind near the a-priori one explains."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     L, S = total_lines, samples
@@ -103,6 +105,12 @@ def make_scene(lines, samples, total_lines, line0, seed, device, chunk=500, inc_
     coarse = torch.randn((1, 2, ch, cw), generator=g, device=device, dtype=torch.float32) * 1.5
     noise = torch.nn.functional.interpolate(coarse, size=(max(lines, 1), samples), mode="bilinear", align_corners=True)[0]
     ss = torch.arange(samples, device=device, dtype=torch.float64)[None, :]
+    gain = None
+    if outlier_frac > 0.0:
+        bh, bw = lines // 16 + 1, samples // 16 + 1
+        u = torch.rand((bh, bw), generator=g, device=device)
+        gb = torch.where(u < 0.5 * outlier_frac, 10.0, torch.where(u < outlier_frac, 31.6, 1.0)).float()
+        gain = gb.repeat_interleave(16, 0).repeat_interleave(16, 1)[:lines, :samples]
     for l0 in range(0, lines, chunk):
         l1 = min(lines, l0 + chunk)
         ll = (torch.arange(l0, l1, device=device, dtype=torch.float64) + line0)[:, None]
@@ -114,6 +122,8 @@ def make_scene(lines, samples, total_lines, line0, seed, device, chunk=500, inc_
         sig = cmod5n_torch(inc_c, w_t, torch.rad2deg(dir_t))
         speckle = torch._standard_gamma(torch.full(sig.shape, 100.0, device=device, dtype=torch.float32), generator=g) / 100.0
         sig32 = (sig.float() * speckle)
+        if gain is not None:
+            sig32 = sig32 * gain[l0:l1]
         holes = torch.rand(sig.shape, generator=g, device=device) < 0.005
         sig32[holes] = float("nan")
         inc32 = inc_c.float().expand(l1 - l0, samples).clone()
@@ -384,11 +394,17 @@ def hard_scene_figures(ctx, _lib, stream, device, samples, algo, lines_hs=4000):
     out = {}
     lines_hs = int(lines_hs)
     o = torch.empty((lines_hs, samples), dtype=torch.complex64, device=device)
-    for key, inc_range, scale, what in (("friendly_band", (30.0, 46.0), 1.0, "the benchmark scene's own lines 8000..12000 (through the cyclone)"),
-                                        ("ancillary_x0.6", (30.0, 46.0), 0.6, "a-priori wind = 0.6 x truth + noise, incidence 30..46 deg"),
-                                        ("ancillary_x1.6", (30.0, 46.0), 1.6, "a-priori wind = 1.6 x truth + noise, incidence 30..46 deg (windows into the GMF's saturated rows)"),
-                                        ("incidence_17_33", (17.0, 33.0), 1.0, "incidence 17..33 deg, a-priori wind = truth + noise")):
-        inc, s_vv, anc = make_scene(lines_hs, samples, 20000, 8000, 20260320 + 7, device, inc_range=inc_range, anc_scale=scale)
+    for key, inc_range, scale, outl, what in (
+            ("friendly_band", (30.0, 46.0), 1.0, 0.0, "the benchmark scene's own lines 8000..12000 (through the cyclone)"),
+            ("sigma0_outliers_1pct", (30.0, 46.0), 1.0, 0.01, "the same lines with 1 % of the pixels (16 x 16 blobs) at sigma0 x 10 / x 31.6 (+10 / +15 dB: ships, land, rain cells)"),
+            ("sigma0_outliers_5pct", (30.0, 46.0), 1.0, 0.05, "the same lines with 5 % of the pixels at sigma0 x 10 / x 31.6"),
+            ("ancillary_x0.6", (30.0, 46.0), 0.6, 0.0, "a-priori wind = 0.6 x truth + noise, incidence 30..46 deg"),
+            ("ancillary_x0.3", (30.0, 46.0), 0.3, 0.0, "a-priori wind = 0.3 x truth + noise, incidence 30..46 deg"),
+            ("ancillary_x1.6", (30.0, 46.0), 1.6, 0.0, "a-priori wind = 1.6 x truth + noise, incidence 30..46 deg (windows into the GMF's saturated rows)"),
+            ("ancillary_x2.5", (30.0, 46.0), 2.5, 0.0, "a-priori wind = 2.5 x truth + noise, incidence 30..46 deg"),
+            ("incidence_17_33", (17.0, 33.0), 1.0, 0.0, "incidence 17..33 deg, a-priori wind = truth + noise"),
+            ("incidence_17_33_x1.6", (17.0, 33.0), 1.6, 0.0, "incidence 17..33 deg, a-priori wind = 1.6 x truth + noise")):
+        inc, s_vv, anc = make_scene(lines_hs, samples, 20000, 8000, 20260320 + 7, device, inc_range=inc_range, anc_scale=scale, outlier_frac=outl)
         torch.cuda.synchronize()
 
         def run():
@@ -412,7 +428,8 @@ def hard_scene_figures(ctx, _lib, stream, device, samples, algo, lines_hs=4000):
                     "k_invert_list_ms": round(tm["second_kernel_ms"] / max(tm["launches"], 1), 2),
                     "pixels_to_band2_frac": round(tm["last_band2_pixels"] / (lines_hs * samples), 5),
                     "pixels_left_to_the_list_frac": round(tm["last_list_pixels"] / (lines_hs * samples), 5),
-                    "evaluated_candidates_per_pixel": round(st["cand_co"] / max(st["pixels_co"], 1), 1)}
+                    "evaluated_candidates_per_pixel": round(st["cand_co"] / max(st["pixels_co"], 1), 1),
+                    "pixels_exact_fallback": int(st["pixels_exact"])}
         del inc, s_vv, anc
     return out
 

@@ -19,10 +19,11 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (make_scene, build_product_lut)
 from xsarsea_amd import _lib  # noqa: E402
 
-SCENES = (("friendly", (30.0, 46.0), 1.0), ("anc x0.6", (30.0, 46.0), 0.6), ("anc x0.3", (30.0, 46.0), 0.3),
-          ("anc x1.3", (30.0, 46.0), 1.3), ("anc x1.6", (30.0, 46.0), 1.6), ("anc x2.5", (30.0, 46.0), 2.5),
-          ("inc 17-33", (17.0, 33.0), 1.0), ("inc 17-33 anc x0.6", (17.0, 33.0), 0.6), ("inc 17-33 anc x1.6", (17.0, 33.0), 1.6),
-          ("inc 17-25", (17.0, 25.0), 1.0))
+SCENES = (("friendly", (30.0, 46.0), 1.0, 0.0), ("outliers 1%", (30.0, 46.0), 1.0, 0.01), ("outliers 5%", (30.0, 46.0), 1.0, 0.05),
+          ("anc x0.6", (30.0, 46.0), 0.6, 0.0), ("anc x0.3", (30.0, 46.0), 0.3, 0.0),
+          ("anc x1.3", (30.0, 46.0), 1.3, 0.0), ("anc x1.6", (30.0, 46.0), 1.6, 0.0), ("anc x2.5", (30.0, 46.0), 2.5, 0.0),
+          ("inc 17-33", (17.0, 33.0), 1.0, 0.0), ("inc 17-33 anc x0.6", (17.0, 33.0), 0.6, 0.0), ("inc 17-33 anc x1.6", (17.0, 33.0), 1.6, 0.0),
+          ("inc 17-25", (17.0, 25.0), 1.0, 0.0), ("inc 17-33 outliers 5%", (17.0, 33.0), 1.0, 0.05))
 
 
 def main():
@@ -40,10 +41,10 @@ def main():
     o = torch.empty((lines, samples), dtype=torch.complex64, device=device)
     o2 = torch.empty((lines, samples), dtype=torch.complex64, device=device) if args.verify else None
     only = set(args.only.split(",")) if args.only else None
-    for name, inc_range, scale in SCENES:
+    for name, inc_range, scale, outl in SCENES:
         if only and name not in only:
             continue
-        inc, s_vv, anc = bench.make_scene(lines, samples, 20000, 8000, 20260320 + 7, device, inc_range=inc_range, anc_scale=scale)
+        inc, s_vv, anc = bench.make_scene(lines, samples, 20000, 8000, 20260320 + 7, device, inc_range=inc_range, anc_scale=scale, outlier_frac=outl)
         torch.cuda.synchronize()
 
         def run(out, algo=_lib.ALGO_PRUNED):

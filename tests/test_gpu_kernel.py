@@ -749,3 +749,86 @@ def test_tail_cut_keeps_saturating_windows_in_the_band_kernels():
             listed[(mode, float(scale))] = int(n_list)
     assert listed[("both", 1.6)] < listed[("cut", 1.6)] < listed[("none", 1.6)], listed
     assert listed[("both", 2.5)] < listed[("cut", 2.5)] <= listed[("none", 2.5)], listed
+
+
+_BLOCKS_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {repo!r}); sys.path.insert(0, {repo!r} + "/tests")
+import torch
+from oracle import gmf, lut as olut
+from util import lut_dicts
+from test_gpu_kernel import synthetic_scene
+from xsarsea_amd import _lib
+dev = torch.device("cuda", 0)
+ctx = _lib.Context(0)
+lco = olut.to_lut("gmf_cmod5n")
+rng = np.random.default_rng(9)
+noisy = olut.Lut(lco.values[::50, ::2, ::2] + 0.2 * rng.standard_normal(lco.values[::50, ::2, ::2].shape), lco.incidence[::50], lco.wspd[::2],
+                 lco.phi[::2], "dB", "x", "co", "VV")
+for lut_name, lut in (("cmod5n", lco), ("noisy", noisy)):
+    ctx.upload_luts(co=lut_dicts(lut, None)[0])
+    for scene in ("outliers", "faroff", "ordinary"):
+        if lut_name == "noisy" and scene == "ordinary":
+            continue
+        inc, s_vv, _, _, anc = synthetic_scene(96, 700, np.float32, 71)
+        r = np.random.default_rng(3)
+        if scene == "outliers":  # ships / land / rain cells: sigma0 far above (and below) anything the a-priori wind explains
+            blob = r.random(inc.shape)
+            s_vv = np.where(blob < 0.04, s_vv * 10.0, s_vv)
+            s_vv = np.where((blob >= 0.04) & (blob < 0.08), s_vv * 31.6, s_vv)
+            s_vv = np.where((blob >= 0.08) & (blob < 0.10), s_vv * 1e3, s_vv)
+            s_vv = np.where((blob >= 0.10) & (blob < 0.12), s_vv * 1e-2, s_vv).astype(np.float32)
+        elif scene == "faroff":
+            sel = r.random(inc.shape) < 0.3
+            anc = np.where(sel, r.uniform(0, 60, inc.shape) * np.exp(1j * r.uniform(-np.pi, np.pi, inc.shape)), anc).astype(np.complex64)
+            anc[:, 100:110] *= 1e-6
+        t = [torch.from_numpy(a).to(dev) for a in (inc, s_vv, anc)]
+        out = torch.empty(inc.shape, dtype=torch.complex64, device=dev)
+        torch.cuda.synchronize()
+        ex = ctx.invert_host(inc, sigma0_co=s_vv, anc=anc, algo="exhaustive", out_dtype=np.complex64)
+        diff = 0
+        for with_stats in (False, True):  # the production chain, then the statistics instantiation (every window in k_invert_band)
+            out.zero_()
+            ctx.stats_enable(with_stats)
+            ctx.invert_raw(inc.shape[0], inc.shape[1], _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, t[0].data_ptr(), t[1].data_ptr(), None, None,
+                           t[2].data_ptr(), out.data_ptr(), None, algo=_lib.ALGO_PRUNED)
+            if with_stats:
+                st = ctx.stats()
+            ctx.synchronize()
+            diff += int(np.sum(out.cpu().numpy().view(np.int32) != ex[0].view(np.int32)))
+        ctx.stats_enable(False)
+        print("RESULT", lut_name, scene, diff, st["pixels_exact"], st["pixels_co"], st["cand_co"])
+"""
+
+
+@pytest.mark.parametrize("mode", ["default", "all-blocks", "all-blocks-one-kernel", "no-blocks", "small-list"])
+def test_block_pyramid_routes(mode):
+    """Round 4: the block pyramid of the general kernel (co_block_search: min / max per block of 4 speeds x 16 directions, a lower
+    bound of BOTH cost terms together) in a fresh process.  Scenes with sigma0 outliers (x10, x31.6, x1000, x0.01: ships, land,
+    rain cells -- their windows cover the whole grid, which used to mean the exact full scan), far-off and vanishing a-priori winds,
+    an ordinary scene; CMOD5.N and a noisy LUT without monotone columns (no band rule: every pixel goes through the general
+    kernel).  Results == the LDS-tiled exhaustive sweep on every pixel with the default threshold, with XSW_BLOCK_MIN=0 (every
+    cooperative search is a block search) also on the one-kernel path (XSW_NO_BAND=1), without the tables (XSW_NO_BLOCKS=1:
+    the round-3 routes) and with an overflowing work list; with the tables the exact full scan is left to a handful of pixels."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = {k: v for k, v in os.environ.items() if k not in ("XSW_BLOCK_MIN", "XSW_NO_BLOCKS", "XSW_NO_BAND", "XSW_LIST_CAP_TEST", "XSW_LONG_RUN")}
+    if mode.startswith("all-blocks"):
+        env["XSW_BLOCK_MIN"] = "0"
+    if mode == "all-blocks-one-kernel":
+        env["XSW_NO_BAND"] = "1"
+    if mode == "no-blocks":
+        env["XSW_NO_BLOCKS"] = "1"
+    if mode == "small-list":
+        env["XSW_LIST_CAP_TEST"] = "300"
+    r = subprocess.run([sys.executable, "-c", _BLOCKS_SCRIPT.format(repo=REPO)], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [l.split() for l in r.stdout.splitlines() if l.startswith("RESULT")]
+    assert len(rows) == 5, r.stdout
+    for _, lut_name, scene, diff, n_exact, n_co, _cand in rows:
+        assert int(diff) == 0, f"{mode} {lut_name} {scene}: {diff} values differ from the exhaustive sweep"
+        if mode != "no-blocks":  # near-ties are settled inside the block search: the exact full scan is for non-finite inputs only
+            assert int(n_exact) <= 2, (mode, lut_name, scene, n_exact)
+    if mode == "no-blocks":
+        assert int([r_ for r_ in rows if r_[1] == "cmod5n" and r_[2] == "outliers"][0][4]) > 100  # what the tables are for

@@ -324,3 +324,100 @@ def test_chord_rows_contain_the_disc(seed):
                 # ... and it is tight: at most two rows of slack at either end (the inflations are ~1e-6 of the radius)
                 kept = max(min(rows[1], n_w - 1) - max(rows[0], 0) + 1, 0)
                 assert kept <= inside.size + 4, (case, ip, mag, R, theta, rows, inside.size)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Round 4: the block pyramid (co_block_search of the general kernel; tests/prune_model.py: block_pruned_argmin)
+@pytest.mark.parametrize("seed", range(4))
+def test_block_cell_bound_is_a_lower_bound(seed):
+    """cell_wind_lb <= the smallest |c - m|^2 / 4 over the grid points of a block, whatever the axis (0..180, 0..360, -180..180,
+    coarse steps, spans beyond 170 deg fall back to the radial bound), also with m on a block edge, on a grid point, at the origin."""
+    rng = np.random.default_rng(100 + seed)
+    for case in range(400):
+        n_w, n_phi = int(rng.integers(2, 70)), int(rng.integers(2, 120))
+        w0, wstep = rng.choice([0.2, 0.5, 3.0]), rng.choice([0.1, 0.25, 1.0])
+        phi0 = rng.choice([0.0, 0.0, -180.0, 10.0])
+        span = rng.choice([180.0, 360.0, 90.0, 170.0, 359.0])
+        w_ax, phi_ax = w0 + wstep * np.arange(n_w), np.linspace(phi0, phi0 + span, n_phi)
+        cphi, sphi = np.cos(np.radians(phi_ax)), np.sin(np.radians(phi_ax))
+        dphi = span / (n_phi - 1)
+        kind = case % 4
+        if kind == 0:  # m on a grid point
+            mag, th = w_ax[rng.integers(0, n_w)], np.radians(phi_ax[rng.integers(0, n_phi)])
+        elif kind == 1:  # m at or near the origin
+            mag, th = rng.choice([0.0, 1e-12, 1e-3]), rng.uniform(-np.pi, np.pi)
+        else:
+            mag, th = rng.uniform(0, 1.4 * w_ax[-1]), rng.uniform(-np.pi, np.pi)
+        a, b = mag * np.cos(th), mag * np.sin(th)
+        ah, bh = 0.5 * a, 0.5 * b
+        cx, cy = 0.5 * w_ax[:, None] * cphi[None, :], 0.5 * w_ax[:, None] * sphi[None, :]
+        d2 = (cx - ah) ** 2 + (cy - bh) ** 2
+        for br in range(-(-n_w // pm.BLK_R)):
+            for bc in range(-(-n_phi // pm.BLK_C)):
+                r0, r1 = br * pm.BLK_R, min(br * pm.BLK_R + pm.BLK_R, n_w) - 1
+                c0, c1 = bc * pm.BLK_C, min(bc * pm.BLK_C + pm.BLK_C, n_phi) - 1
+                lb = pm.cell_wind_lb(ah, bh, 0.5 * w_ax[r0], 0.5 * w_ax[r1], cphi[c0], sphi[c0], cphi[c1], sphi[c1], (c1 - c0) * dphi)
+                true = d2[r0:r1 + 1, c0:c1 + 1].min()
+                assert lb * (1.0 - 1e-8) <= true + 1e-8 * (1.0 + ah * ah + bh * bh), (case, br, bc, lb, true)
+        mh = 0.5 * mag
+        assert pm.radial_lb(mh, 0.5 * w_ax[0], 0.5 * w_ax[-1]) <= d2.min() * (1 + 1e-12) + 1e-12
+
+
+@pytest.mark.parametrize("kind", ["cmod5n", "noisy", "rolloff", "wrap360"])
+def test_block_pyramid_finds_the_oracle_argmin(kind):
+    """block_pruned_argmin == the oracle on ordinary pixels and on the ones the a-priori side cannot bound: sigma0 10..30 dB
+    above the GMF (ships, land), sigma0 far below it, an a-priori wind of the wrong size or direction; with the ray's bound,
+    with no bound at all, and restricted to the disc's window.  Any LUT: noisy columns, a top that rolls off, a 0..360 axis."""
+    rng = np.random.default_rng({"cmod5n": 21, "noisy": 22, "rolloff": 23, "wrap360": 24}[kind])
+    phi_ax = np.linspace(0, 360, 145) if kind == "wrap360" else np.linspace(0, 180, 91)
+    inc_ax, w_ax = np.linspace(18, 44, 7), np.linspace(0.5, 59.5, 237)
+    co = 10 * np.log10(gmf.gmf_cmod5n(inc_ax[:, None, None], w_ax[None, :, None], phi_ax[None, None, :]) + 1e-15)
+    if kind == "noisy":
+        co = co + 0.1 * rng.standard_normal(co.shape)
+    elif kind == "rolloff":
+        co = co - 0.02 * np.maximum(w_ax[None, :, None] - 24.0, 0.0) ** 2
+    lco = olut.Lut(co, inc_ax, w_ax, phi_ax, "dB", "x", "co", "VV")
+    p = oinv.Prepared(lco, None)
+    n = 700
+    inc, wt, pt = rng.uniform(18, 46, n), rng.uniform(0.5, 35, n), rng.uniform(-180, 180, n)
+    lin = gmf.gmf_cmod5n(inc, wt, pt) * rng.gamma(100, 1 / 100, n)
+    lin[:150] *= 10.0 ** rng.uniform(1.0, 3.0, 150)   # outliers: +10 .. +30 dB
+    lin[150:200] *= 10.0 ** -rng.uniform(1.0, 3.0, 50)  # -10 .. -30 dB
+    s = oinv.to_db(lin)
+    anc = wt * np.exp(1j * np.deg2rad(pt)) + rng.normal(0, 1.5, n) + 1j * rng.normal(0, 1.5, n)
+    anc[100:300] = rng.uniform(0, 60, 200) * np.exp(1j * rng.uniform(-np.pi, np.pi, 200))  # a-priori wind far off
+    anc[300:320] *= 1e-6
+    nan = np.full(n, np.nan)
+    idx = cport.invert_numpy(p, inc, s, nan, nan, anc, return_idx=True, reference_layout=False)[2]
+    cphi, sphi = np.cos(np.radians(phi_ax)), np.sin(np.radians(phi_ax))
+    tabs = [pm.block_tables(co[i]) for i in range(len(inc_ax))]
+    n_w, n_phi = len(w_ax), len(phi_ax)
+    swept_bound, swept_free = [], []
+    for i in range(n):
+        ii = int(np.argmin(np.abs(inc_ax - inc[i])))
+        a, b = anc[i].real, anc[i].imag
+        be = abs(b) if p.phi_180 else b
+        # the ray's bound as the kernels form it: any real candidate's score, here the a-priori direction's column minimum
+        theta = np.degrees(np.arctan2(be, a))
+        if theta < phi_ax[0]:
+            theta += 360.0
+        ipr = int(np.clip(np.rint((theta - phi_ax[0]) / (phi_ax[1] - phi_ax[0])), 0, n_phi - 1))
+        jcol = pm.exact_J(w_ax, cphi[ipr], sphi[ipr], co[ii][:, ipr], s[i], a, be, 0.1)
+        j_ub = float(jcol.min()) * (1 + 1e-9) + 1e-9
+        r = pm.block_pruned_argmin(co[ii], w_ax, phi_ax, cphi, sphi, p.phi_180, s[i], a, b, 0.1, j_ub=j_ub, tables=tabs[ii])
+        assert (r[0], r[1]) == (idx[i, 0], idx[i, 1]), (kind, "bound", i, r, idx[i])
+        swept_bound.append(r[2])
+        if i % 5 == 0:  # no bound at all: the pyramid finds its own
+            r = pm.block_pruned_argmin(co[ii], w_ax, phi_ax, cphi, sphi, p.phi_180, s[i], a, b, 0.1, tables=tabs[ii])
+            assert (r[0], r[1]) == (idx[i, 0], idx[i, 1]), (kind, "free", i, r, idx[i])
+            swept_free.append(r[2])
+        if i % 3 == 0:  # inside the disc's window only
+            mag = float(np.hypot(a, be))
+            win = pm.search_window(mag, theta, j_ub, w_ax[0], (n_w - 1) / (w_ax[-1] - w_ax[0]), n_w, phi_ax[0], phi_ax[-1],
+                                   (n_phi - 1) / (phi_ax[-1] - phi_ax[0]), n_phi)
+            r = pm.block_pruned_argmin(co[ii], w_ax, phi_ax, cphi, sphi, p.phi_180, s[i], a, b, 0.1, j_ub=j_ub, window=win, tables=tabs[ii])
+            assert (r[0], r[1]) == (idx[i, 0], idx[i, 1]), (kind, "window", i, r, idx[i])
+    nblocks = -(-n_w // pm.BLK_R) * -(-n_phi // pm.BLK_C)
+    assert np.mean(swept_bound) < 0.08 * nblocks, (np.mean(swept_bound), nblocks)
+    # outliers alone (their windows are the whole grid): still a small part of the table
+    assert np.mean(swept_bound[:150]) < 0.15 * nblocks, np.mean(swept_bound[:150])

@@ -58,8 +58,28 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def _code_objects(lib, td):
+    """The gfx950 code objects inside libxsw.so: its .hip_fatbin section holds one offload bundle per translation unit."""
+    llvm = "/opt/rocm/lib/llvm/bin"
+    fat = os.path.join(td, "fat.bin")
+    subprocess.check_call([f"{llvm}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", lib, os.path.join(td, "unused.so")])
+    with open(fat, "rb") as f:
+        blob = f.read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m for m in range(len(blob)) if blob.startswith(magic, m)] if blob.count(magic) < 64 else []
+    out = []
+    for k, st in enumerate(starts):
+        piece, co = os.path.join(td, f"bundle{k}.bin"), os.path.join(td, f"dev{k}.co")
+        with open(piece, "wb") as f:
+            f.write(blob[st:starts[k + 1] if k + 1 < len(starts) else len(blob)])
+        subprocess.check_call([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o",
+                               f"--targets=hipv4-amdgcn-amd-amdhsa--{ARCH}", f"--input={piece}", f"--output={co}"])
+        out.append(co)
+    return out
+
+
 def kernel_resources(lib=None):
-    """Per-kernel register / LDS / scratch figures read from the gfx950 code object inside libxsw.so (the
+    """Per-kernel register / LDS / scratch figures read from the gfx950 code objects inside libxsw.so (the
     `amdhsa.kernels` metadata note: .vgpr_count, .agpr_count, .sgpr_count, .group_segment_fixed_size,
     .private_segment_fixed_size), plus the waves per SIMD the VGPR count allows (512 VGPRs per SIMD lane, allocation
     granule 8, at most 8 waves).  Returns a list of dicts sorted by kernel name."""
@@ -67,23 +87,23 @@ def kernel_resources(lib=None):
     import tempfile
     lib = lib or LIB
     llvm = "/opt/rocm/lib/llvm/bin"
-    with tempfile.TemporaryDirectory() as td:
-        fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "dev.co")
-        subprocess.check_call([f"{llvm}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", lib, os.path.join(td, "unused.so")])
-        subprocess.check_call([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o",
-                               f"--targets=hipv4-amdgcn-amd-amdhsa--{ARCH}", f"--input={fat}", f"--output={co}"])
-        notes = subprocess.check_output([f"{llvm}/llvm-readelf", "--notes", co], text=True)
-        try:
-            names = subprocess.check_output([f"{llvm}/llvm-cxxfilt"] + re.findall(r"\.name:\s+(\S+)", notes), text=True).splitlines()
-        except (OSError, subprocess.CalledProcessError):
-            names = re.findall(r"\.name:\s+(\S+)", notes)
     out = []
-    for blk, name in zip(re.split(r"\n\s+- (?=\.agpr_count)", notes)[1:], names):
-        g = lambda key: int(re.search(rf"\.{key}:\s+(\d+)", blk).group(1))
-        vg, ag = g("vgpr_count"), g("agpr_count")
-        alloc = -(-max(vg + ag, 1) // 8) * 8
-        out.append(dict(kernel=name, vgpr=vg, agpr=ag, sgpr=g("sgpr_count"), lds_bytes=g("group_segment_fixed_size"),
-                        scratch_bytes=g("private_segment_fixed_size"), waves_per_simd_by_vgpr=min(8, 512 // alloc)))
+    with tempfile.TemporaryDirectory() as td:
+        for co in _code_objects(lib, td):
+            notes = subprocess.check_output([f"{llvm}/llvm-readelf", "--notes", co], text=True)
+            raw = re.findall(r"\.name:\s+(\S+)", notes)
+            if not raw:
+                continue
+            try:
+                names = subprocess.check_output([f"{llvm}/llvm-cxxfilt"] + raw, text=True).splitlines()
+            except (OSError, subprocess.CalledProcessError):
+                names = raw
+            for blk, name in zip(re.split(r"\n\s+- (?=\.agpr_count)", notes)[1:], names):
+                g = lambda key: int(re.search(rf"\.{key}:\s+(\d+)", blk).group(1))
+                vg, ag = g("vgpr_count"), g("agpr_count")
+                alloc = -(-max(vg + ag, 1) // 8) * 8
+                out.append(dict(kernel=name, vgpr=vg, agpr=ag, sgpr=g("sgpr_count"), lds_bytes=g("group_segment_fixed_size"),
+                                scratch_bytes=g("private_segment_fixed_size"), waves_per_simd_by_vgpr=min(8, 512 // alloc)))
     return sorted(out, key=lambda d: d["kernel"])
 
 

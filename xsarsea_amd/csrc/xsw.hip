@@ -361,6 +361,27 @@ static int install_co(xsw_ctx *c, const xsw_lut *l, const double *d_dense)
             }
             if (e == hipSuccess) { T.inv_rows = d_inv; T.inv_grid = d_grid; }
         }
+        // block pyramid of the general kernel (co_block_search): min / max per block of XSW_BLK_R x XSW_BLK_C candidates and per
+        // band of blk_g block rows (6 MB at the default size).  Absent (allocation failure, XSW_NO_BLOCKS=1: A/B measurements and
+        // the tests of the old routes): the general kernel sweeps windows and falls back to the exact scan as before.
+        T.blk = nullptr; T.bandmm = nullptr;
+        T.nbr = (nW + XSW_BLK_R - 1) / XSW_BLK_R; T.nbc = (nP + XSW_BLK_C - 1) / XSW_BLK_C;
+        T.blk_g = std::max(1, 64 / T.nbc); T.nbands = (T.nbr + T.blk_g - 1) / T.blk_g;
+        static const bool blocks_off = getenv("XSW_NO_BLOCKS") != nullptr;
+        if (e == hipSuccess && !blocks_off && (long long)nI * T.nbr * T.nbc < (1LL << 31)) {
+            float2 *d_blk = nullptr, *d_band = nullptr;
+            const long long nblk = (long long)nI * T.nbr * T.nbc, nband = (long long)nI * T.nbands;
+            hipError_t e2 = hipMalloc((void **)&d_blk, (size_t)nblk * sizeof(float2) + 64);
+            if (e2 == hipSuccess) { c->co_allocs.push_back(d_blk); e2 = hipMalloc((void **)&d_band, (size_t)nband * sizeof(float2) + 64); }
+            if (e2 == hipSuccess) {
+                c->co_allocs.push_back(d_band);
+                hipLaunchKernelGGL(k_block_minmax, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, c->stream, d_dense, nI, nW, nP, T.nbr, T.nbc, d_blk);
+                hipLaunchKernelGGL(k_band_minmax, dim3((unsigned)((nband + 255) / 256)), dim3(256), 0, c->stream, d_blk, nI, T.nbr, T.nbc, T.blk_g, T.nbands, d_band);
+                e2 = hipGetLastError();
+            }
+            if (e2 == hipSuccess) { T.blk = d_blk; T.bandmm = d_band; }
+            else (void)hipGetLastError();
+        }
         // the same for columns that rise and then fall (k_invert_band2; 755 MB at the default size).  OFF unless XSW_BAND2=1:
         // measured in round 3, the windows that leave the monotone rows sit on the flat top of the saturating GMF, where a
         // band of +-d dB is tens of rows long -- the rule prunes little there and k_invert_band2 hands most of its pixels on
@@ -485,6 +506,7 @@ static int install_co(xsw_ctx *c, const xsw_lut *l, const double *d_dense)
                   (l->phi[nP - 1] - l->phi[0]) <= 360.0 + 1e-9 && lut_finite)
                      ? 1 : 0;
     T.co_off32 = ((uint64_t)nI * nW + 260) * (uint64_t)ppad * 8u < ((uint64_t)1 << 32) ? 1 : 0;
+    T.blk_span_ok = (nP > 1 && (XSW_BLK_C - 1) * (l->phi[nP - 1] - l->phi[0]) / (nP - 1) < 170.0) ? 1 : 0;
     // transposed slices for the ray scan
     double *dT = nullptr;
     HIPCHK(c, hipMalloc((void **)&dT, (size_t)nI * nP * wpad * sizeof(double) + 512 * sizeof(double)));

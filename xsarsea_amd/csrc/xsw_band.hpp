@@ -423,7 +423,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
             }
             const int nrows_p = w_hi_e - W.w_lo + 1;
             ncols_p = W.ip_hi - W.ip_lo + 1;
-            const bool need = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0 && !loose && ncols_p >= 1 && (nrows_p >= 1 || has_tail);
+            const bool need = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0 && ncols_p >= 1 && (nrows_p >= 1 || has_tail);
             if (ROLE == 2 && strip_walk) skip = !need || !(w_hi_e < L.mono_rows[need ? P.i_inc : 0]);  // everything k_invert_band did not hand over
             if (BITONIC) {
                 eligb = need && L.bitonic_ok[need ? P.i_inc : 0] != 0;  // every column of the slice rises, then falls

@@ -60,6 +60,13 @@ struct DevTables {
     const unsigned short *inv2;      // [n_inc][2][XSW_INV_BINS + 1][phi_pad]   (null: not built)
     const double *inv_grid2;         // [n_inc][3]
     const int *bitonic_ok;           // [n_inc]
+    // block pyramid (co_block_search): blk[i][br][bc] = {min, max} of the LUT over speed rows [XSW_BLK_R br, +XSW_BLK_R) x directions
+    // [XSW_BLK_C bc, +XSW_BLK_C) of slice i, float32 rounded outward; bandmm[i][t] the same over block rows [blk_g t, +blk_g), every
+    // direction (blk_g = the block rows one wave trip covers, one lane per block).  Null: not built.
+    const float2 *blk;     // [n_inc][nbr][nbc]
+    const float2 *bandmm;  // [n_inc][nbands]
+    int nbr, nbc, blk_g, nbands;
+    int blk_span_ok;       // a block spans less than 170 deg of direction: the sector bound of co_block_search holds
     double w0, inv_wstep, phi0, phi_last, inv_dphi;
     double wstep_half;  // 0.5 / inv_wstep (host: one IEEE division instead of one per wave and pass)
     double inv_nphi;    // 1 / n_phi: flat index -> (row, direction) without an integer division
@@ -100,6 +107,7 @@ struct KArgs {
     unsigned long long *mask_g, *mask_b;
     int long_run;               // k_invert_band, ROLE 1: rows along the a-priori direction from which a pixel is handed to k_invert_band2
     int tail_max;               // rows past the monotone ones a window may hold for k_invert_band2's tail sweep (0: never)
+    int block_min;              // general kernel: windows of at least this many candidates are searched by the block pyramid (co_block_search)
     long long n, lines, samples;
     double dsig_co, inv_dsig_co, dsig_cr_scalar;
     int is_db, dual_select;
@@ -110,7 +118,8 @@ struct KArgs {
 enum : unsigned { K_CODE_NAN_RE = 0xFFFFFFFFu /* (nan, 0) */, K_CODE_NAN = 0xFFFFFFFEu /* (nan, nan) */,
                   K_CODE_PICK_CO = 0x40000000u, K_CODE_NO_INDEX = 0x3FFFFFFFu };
 
-enum : int { F_NEED_CO = 1, F_NEED_CR = 2, F_EARLY_NAN = 4, F_CO_FINITE = 8, F_CR_RAW_NAN = 16 /* band kernel: a raw cross-pol input is NaN */ };
+enum : int { F_NEED_CO = 1, F_NEED_CR = 2, F_EARLY_NAN = 4, F_CO_FINITE = 8, F_CR_RAW_NAN = 16 /* band kernel: a raw cross-pol input is NaN */,
+             F_CO_LOOSE = 32 /* general kernel: finite inputs, but a bound far above the scale of the scores: block pyramid, no forward differences */ };
 
 // ------------------------------------------------------------------------------------------------
 // wave64 helpers
@@ -599,7 +608,8 @@ __device__ __forceinline__ double tag16(double J, int keep_mask /* 0xffff0000, i
 __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, double s, double a, double b, int w_lo,
                                              int w_hi, int ip_lo, int ip_hi, int geom, int mdiv, double dsig,
                                              double inv_dsig, int lane, unsigned &cand, bool &went_exact,
-                                             bool relayout = false /* geom was made for a narrower segment */)
+                                             bool relayout = false /* geom was made for a narrower segment */,
+                                             bool *defer = nullptr /* non-null: what would take the exact full scan is reported here instead (-1 returned) */)
 {
     const double inf = __builtin_inf(), BIG = 1e300;
     const double ah = 0.5 * a, bh = 0.5 * b, m2 = ah * ah + bh * bh, sn = -s * inv_dsig;
@@ -608,6 +618,7 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
     // nrows/ncols <= 0 cannot happen in exact arithmetic (stay safe).  More than XSW_MAX_FD_TRIPS trips: the forward
     // differences would accumulate too much rounding error (see co_window_lanes) -> exact full scan.
     if (nrows <= 0 || ncols <= 0 || (geom >> 8) > XSW_MAX_FD_TRIPS) {
+        if (defer) { *defer = true; return -1; }
         went_exact = true;
         return exact_scan_co(L, i_inc, s, a, b, dsig, lane);
     }
@@ -672,6 +683,7 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
     const double gmin = wave_min_d(best);
     const double T = gmin + 1e-9 * (1.0 + fabs(gmin) + m2);
     if (__ballot(second <= T) != 0ULL || !(gmin < 0.5 * BIG)) {
+        if (defer) { *defer = true; return -1; }
         went_exact = true;
         return exact_scan_co(L, i_inc, s, a, b, dsig, lane);
     }
@@ -694,6 +706,162 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
         }
     }
     return eI;
+}
+
+// Stage 2 from the TABLE side, `co_block_search` (round 4; tests/prune_model.py: block_pruned_argmin is its executable
+// specification): WAVE-COOPERATIVE, one pixel at a time, every argument wave-uniform.  For the pixels whose a-priori wind does
+// not confine the search -- sigma0 outliers (ships, land, rain cells: the disc covers the whole grid), windows of thousands of
+// candidates, near-ties -- and for ANY LUT (no monotone columns needed).  The slice is cut into blocks of XSW_BLK_R speed rows x
+// XSW_BLK_C directions (64 candidates: one per lane) with their min / max LUT value tabulated at install (L.blk, float32 rounded
+// outward), and into bands of L.blk_g block rows over all directions (L.bandmm).  For a block,
+//     LB = (max(0, lo - s, s - hi) / dsig)^2 + (distance of m/2 to the block's polar cell, half-speed units)^2
+// bounds J = Jsig + Jwind from below over its candidates -- BOTH terms together, where the window and the band rule bound each
+// term on its own: a sigma0 contour that runs through the disc far from m is excluded.  Level 1: one lane per band (radial
+// distance only), the most promising band first; level 2: one lane per block of a kept band; level 3: a kept block is swept,
+// one candidate per lane, scores formed directly (no forward differences: no limit on the window).  The bound tightens with
+// the running minimum.  A block is skipped when its deflated LB exceeds the best score known, so each of its candidates scores
+// strictly above an examined one in the reference's arithmetic: it can neither be the argmin nor tie with it.  Settle as
+// everywhere: a unique candidate within eps of the screening minimum is the argmin; otherwise the kept blocks are swept once
+// more and every candidate within eps is re-scored in the reference's operation order (lowest flat index wins ties).
+#ifndef XSW_BLK_R
+#define XSW_BLK_R 4
+#endif
+#ifndef XSW_BLK_C
+#define XSW_BLK_C 16
+#endif
+static_assert(XSW_BLK_R * XSW_BLK_C == 64, "one candidate of a block per lane");
+__device__ __forceinline__ int co_block_search(const DevTables &L, int i_inc, double s, double a, double b, double jub_in, int w_lo, int w_hi,
+                                               int ip_lo, int ip_hi, double dsig, double inv_dsig, int lane, unsigned &cand, bool &went_exact)
+{
+    constexpr int R = XSW_BLK_R, C = XSW_BLK_C;
+    const double inf = __builtin_inf();
+    const double ah = 0.5 * a, bh = 0.5 * b, m2 = ah * ah + bh * bh, mh = sqrt(m2), sn = -s * inv_dsig, ainv = fabs(inv_dsig);
+    const double wh0 = 0.5 * L.w0, whs = L.wstep_half;
+    const double slack = 1e-8 * (1.0 + m2), tol = 1e-9 * mh + 1e-300;
+    const double *__restrict__ slice = L.co + (size_t)i_inc * L.n_w * L.phi_pad;
+    const float2 *__restrict__ blk = L.blk + (size_t)i_inc * L.nbr * L.nbc;
+    const float2 *__restrict__ bnd = L.bandmm + (size_t)i_inc * L.nbands;
+    w_lo = max(w_lo, 0); w_hi = min(max(w_hi, w_lo), L.n_w - 1); ip_lo = max(ip_lo, 0); ip_hi = min(max(ip_hi, ip_lo), L.n_phi - 1);
+    const int br_lo = w_lo / R, br_hi = w_hi / R, bc_lo = ip_lo / C, bc_hi = ip_hi / C, ncb = bc_hi - bc_lo + 1;
+    const int G = L.blk_g, tb_lo = br_lo / G, tb_hi = br_hi / G;
+    const int lr = lane / C, lc = lane - lr * C;  // this lane's candidate inside a block
+    double jub = jub_in;
+    double best = inf, second = inf;  // pass 0: screening scores; pass 1: best = exact score of the lexicographic minimum
+    int bflat = 0x7fffffff;
+    double T = inf;  // pass 1: candidates with a screening score <= T are re-scored exactly
+    int result = -1;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        unsigned nsw = 0;
+#pragma unroll 1
+        for (int t0 = tb_lo; t0 <= tb_hi; t0 += 64) {  // level 1: one lane per band
+            const int t = t0 + lane;
+            const bool tv = t <= tb_hi;
+            double lb1 = inf;
+            {
+                const int tc = min(t, L.nbands - 1);
+                const float2 mm = bnd[tc];
+                const int r0 = tc * G * R, r1 = min((tc + 1) * G * R, L.n_w) - 1;
+                const double wha = fma((double)r0, whs, wh0), whb = fma((double)r1, whs, wh0);
+                const double dsg = fmax(0.0, fmax((double)mm.x - s, s - (double)mm.y)) * ainv;
+                const double rad = fmax(0.0, fmax(wha - mh, mh - whb));
+                lb1 = tv ? fma(dsg, dsg, rad * rad) : inf;
+            }
+            unsigned long long todo = __ballot(tv && !(lb1 * (1.0 - 1e-8) > jub + slack));
+            if (todo == 0ULL) continue;
+            int first = -1;
+            if (pass == 0) {  // the most promising band first: its best candidate tightens the bound for all the others
+                const double mn = wave_min_d(tv ? lb1 : 1e308);
+                first = __ffsll((long long)(__ballot(tv && lb1 == mn) & todo)) - 1;
+            }
+            while (todo) {
+                const int l = first >= 0 ? first : __ffsll((long long)todo) - 1;
+                first = -1;
+                todo &= ~(1ULL << l);
+                if (rd_lane_d(lb1, l) * (1.0 - 1e-8) > jub + slack) continue;  // the bound has tightened since the ballot
+                const int tband = t0 + l;
+                const int brA = max(tband * G, br_lo), brB = min(min((tband + 1) * G, L.nbr), br_hi + 1);  // block rows [brA, brB)
+                const int nblk = (brB - brA) * ncb;
+#pragma unroll 1
+                for (int k0 = 0; k0 < nblk; k0 += 64) {  // level 2: one lane per block of the band (inside the window)
+                    const int idx = k0 + lane;
+                    const bool bv = idx < nblk;
+                    const int dr = bv ? idx / ncb : 0, dc = bv ? idx - dr * ncb : 0;
+                    const int br = brA + dr, bc = bc_lo + dc;
+                    const int r0 = br * R, r1 = min(r0 + R, L.n_w) - 1, c0 = bc * C, c1 = min(c0 + C, L.n_phi) - 1;
+                    const float2 mm = blk[br * L.nbc + bc];
+                    const double wha = fma((double)r0, whs, wh0), whb = fma((double)r1, whs, wh0);
+                    const double dsg = fmax(0.0, fmax((double)mm.x - s, s - (double)mm.y)) * ainv;
+                    const double rad = fmax(0.0, fmax(wha - mh, mh - whb));
+                    double lbw = rad * rad;
+                    if (L.blk_span_ok) {
+                        const double2 ea = ((const double2 *)L.csphi)[c0], eb = ((const double2 *)L.csphi)[c1];
+                        const bool inside = (ea.x * bh - ea.y * ah >= -tol) && (ah * eb.y - bh * eb.x >= -tol);
+                        const double pmx = fmax(ah * ea.x + bh * ea.y, ah * eb.x + bh * eb.y);
+                        const double tt = fmin(fmax(pmx, wha), whb);
+                        const double e2 = m2 + tt * (tt - 2.0 * pmx);
+                        lbw = inside ? lbw : fmax(lbw, e2);
+                    }
+                    const double lb2 = fma(dsg, dsg, lbw);
+                    unsigned long long kept = __ballot(bv && !(lb2 * (1.0 - 1e-8) > jub + slack));
+                    while (kept) {
+                        const int kl = __ffsll((long long)kept) - 1;
+                        kept &= kept - 1;
+                        if (rd_lane_d(lb2, kl) * (1.0 - 1e-8) > jub + slack) continue;
+                        // level 3: the block's 64 candidates, one per lane
+                        const int row = rd_lane_i(br, kl) * R + lr, dir = rd_lane_i(bc, kl) * C + lc;
+                        const bool ok = row < L.n_w && dir < L.n_phi;
+                        const int rowc = min(row, L.n_w - 1), dirc = min(dir, L.n_phi - 1);
+                        const double v = slice[(size_t)rowc * L.phi_pad + dirc];
+                        const double2 cs = ((const double2 *)L.csphi)[dirc];
+                        const double U = 2.0 * (ah * cs.x + bh * cs.y);
+                        const double wh = fma((double)rowc, whs, wh0);
+                        const double dd = fma(v, inv_dsig, sn);
+                        double J = fma(dd, dd, wh * (wh - U));
+                        J = ok ? J : inf;
+                        const int flat = rowc * L.n_phi + dirc;
+                        ++nsw;
+                        if (pass == 0) {
+                            second = vmin(second, vmax(J, best));
+                            bflat = J < best ? flat : bflat;
+                            best = vmin(best, J);
+                            if (nsw <= 2u || (nsw & 3u) == 0u) {
+                                const double g = wave_min_d(best);
+                                if (g < 1e300) jub = fmin(jub, (g + m2) * (1.0 + 1e-9) + 1e-9);
+                            }
+                        } else if (J <= T) {  // exact re-scoring, numpy's first-minimum rule
+                            const double Je = exact_J_co(L.w[rowc], cs.x, cs.y, v, s, a, b, dsig);
+                            if (Je < best || (Je == best && flat < bflat)) { best = Je; bflat = flat; }
+                        }
+                    }
+                    if (pass == 0 && nsw) {
+                        const double g = wave_min_d(best);
+                        if (g < 1e300) jub = fmin(jub, (g + m2) * (1.0 + 1e-9) + 1e-9);
+                    }
+                }
+            }
+        }
+        cand += nsw * 64u;
+        if (pass == 0) {
+            const double gmin = wave_min_d(best);
+            if (!(gmin < 1e300)) break;  // nothing scored (cannot happen: jub_in bounds a real candidate): exact scan below
+            T = gmin + 1e-9 * (1.0 + fabs(gmin) + m2);
+            const unsigned long long amb = __ballot(second <= T), surv = __ballot(best <= T);
+            if (amb == 0ULL && __popcll(surv) == 1) { result = rd_lane_i(bflat, __ffsll((long long)surv) - 1); break; }
+            // a near-tie: every candidate within eps of the minimum is re-scored in the reference's operation order (pass 1)
+            jub = (T + m2) * (1.0 + 1e-9) + 1e-9;
+            best = inf;
+            bflat = 0x7fffffff;
+        } else {
+            wave_argmin(best, bflat);
+            if (bflat != 0x7fffffff) result = bflat;
+        }
+    }
+    if (result < 0) {
+        went_exact = true;
+        result = exact_scan_co(L, i_inc, s, a, b, dsig, lane);
+    }
+    return result;
 }
 
 // Stage 2 for narrow windows, `co_seg_pass<S>`: the wave takes 64/S pixels at a time, one per segment of S lanes
@@ -1242,7 +1410,7 @@ __device__ __forceinline__ void invert_strip(const DevTables &L, const KArgs &A,
     if (use_prune && todo) {
         bool loose = false;
         W = co_window_lanes<XSW_STRIP_RAYS, 2>(L, P, A.inv_dsig_co, fabs(A.dsig_co), loose);
-        if (loose) P.flags &= ~F_CO_FINITE;  // -> exact_scan_co
+        if (loose) P.flags = (P.flags & ~F_CO_FINITE) | (L.blk ? F_CO_LOOSE : 0);  // no forward differences for it: block pyramid (exact scan without the tables)
         const unsigned long long fin_m = __ballot((P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0);
         cand += (unsigned)__popcll(fin_m) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)) + (XSW_STRIP_RAYS - 1) * 2 * XSW_RAY_SIDE_STEPS);
         if (L.co_off32) {
@@ -1273,13 +1441,24 @@ __device__ __forceinline__ void invert_strip(const DevTables &L, const KArgs &A,
         const int uf = rd_lane_i(P.flags, p);
         const int u_iinc = rd_lane_i(P.i_inc, p);
         const double us = rd_lane_d(P.s_co, p), ua = rd_lane_d(P.a_re, p), ub = rd_lane_d(P.b_eff, p);
-        int flat;
+        int flat = -1;
         bool went_exact = false;
-        if (use_prune && (uf & F_CO_FINITE))
-            flat = co_box_search(L, u_iinc, us, ua, ub, rd_lane_i(W.w_lo, p), rd_lane_i(W.w_hi, p), rd_lane_i(W.ip_lo, p),
-                                 rd_lane_i(W.ip_hi, p), rd_lane_i(W.geom, p), rd_lane_i(W.mdiv, p), A.dsig_co, A.inv_dsig_co, lane, cand, went_exact,
-                                 ((relay >> p) & 1ULL) != 0);
-        else {
+        if (use_prune && (uf & (F_CO_FINITE | F_CO_LOOSE))) {
+            const int wl = rd_lane_i(W.w_lo, p), wh = rd_lane_i(W.w_hi, p), il = rd_lane_i(W.ip_lo, p), ih = rd_lane_i(W.ip_hi, p);
+            // the block pyramid (bounds from the table side) takes the large windows, the pixels whose bound is loose, and what the
+            // window sweep cannot settle (near-ties, more trips than its forward differences allow)
+            bool blocks = L.blk != nullptr && ((uf & F_CO_LOOSE) != 0 || (long long)(wh - wl + 1) * (ih - il + 1) >= (long long)A.block_min);
+            if (!blocks) {
+                bool defer = false;
+                flat = co_box_search(L, u_iinc, us, ua, ub, wl, wh, il, ih, rd_lane_i(W.geom, p), rd_lane_i(W.mdiv, p), A.dsig_co, A.inv_dsig_co, lane, cand,
+                                     went_exact, ((relay >> p) & 1ULL) != 0, L.blk ? &defer : nullptr);
+                blocks = defer;
+            }
+            if (blocks) {
+                const double rs = rd_lane_d(W.band_d, p) * fabs(A.inv_dsig_co);  // >= sqrt(J_ub) (co_window_lanes)
+                flat = co_block_search(L, u_iinc, us, ua, ub, rs * rs * (1.0 + 1e-12), wl, wh, il, ih, A.dsig_co, A.inv_dsig_co, lane, cand, went_exact);
+            }
+        } else {
             flat = exact_scan_co(L, u_iinc, us, ua, ub, A.dsig_co, lane);
             went_exact = true;
             cand += (unsigned)(L.n_w * L.n_phi);

@@ -12,9 +12,14 @@
 
 using namespace xsw;
 
+#ifndef XSW_BLOCK_MIN
+#define XSW_BLOCK_MIN 1024
+#endif
+
 template <typename T, typename TO>
-static int launch_invert(xsw_ctx *c, const KArgs &A, int algo, const LaunchCtl &lc, std::string &err)
+static int launch_invert(xsw_ctx *c, const KArgs &A_in, int algo, const LaunchCtl &lc, std::string &err)
 {
+    KArgs A = A_in;
     // k_invert grid: 8 XCD lanes x ceil(columns/8) tile columns x line groups (see the kernel)
     const long long strips_per_line = (A.samples + 63) / 64, line_groups = (A.lines + 3) / 4;
     const long long nblocks = 8 * ((strips_per_line + 7) / 8) * line_groups;
@@ -26,6 +31,8 @@ static int launch_invert(xsw_ctx *c, const KArgs &A, int algo, const LaunchCtl &
     // Two-kernel fast path: k_invert_band finishes every pixel the band rule decides (monotone LUT rows, finite inputs,
     // unique minimum; cross-pol by the interval rule) and appends the rest to a work list; k_invert_list inverts those
     // (all tiles, should the list overflow).
+    static const int block_min_env = getenv("XSW_BLOCK_MIN") ? std::max(0, atoi(getenv("XSW_BLOCK_MIN"))) : XSW_BLOCK_MIN;
+    A.block_min = block_min_env;  // windows of at least this many candidates: block pyramid (general kernel)
     static const bool band_off = getenv("XSW_NO_BAND") != nullptr;  // experiments / A-B measurements only
     if (algo == XSW_ALGO_PRUNED && !band_off && lc.list && A.s_co && c->T.prunable && c->T.mono_rows && c->T.inv_rows && c->T.co_off32 &&
         (!A.s_cr || c->T.cr_monotone) && A.n < (1LL << 32)) {

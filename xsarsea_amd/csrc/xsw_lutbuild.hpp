@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #include "xsw_gmf.hpp"
+#include "xsw_device.hpp"
 
 namespace xsw {
 
@@ -170,6 +171,48 @@ __global__ __launch_bounds__(256) void k_inv_rows(const double *__restrict__ den
         while (r < m && col[(size_t)r * n_phi] < thr) ++r;
         out[(size_t)b * phi_pad] = (unsigned short)r;
     }
+}
+
+// ---- block pyramid (co_block_search, xsw_device.hpp): min / max of the LUT per block of XSW_BLK_R speed rows x XSW_BLK_C
+// directions, float32 rounded OUTWARD (a bound must never be tighter than the table), and per band of `g` block rows over all
+// directions.  One thread per block / per band.
+__global__ __launch_bounds__(256) void k_block_minmax(const double *__restrict__ dense, int n_inc, int n_w, int n_phi, int nbr, int nbc,
+                                                      float2 *__restrict__ blk)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n_inc * nbr * nbc) return;
+    const int bc = (int)(t % nbc), br = (int)((t / nbc) % nbr), i = (int)(t / ((long long)nbc * nbr));
+    const double *sl = dense + (size_t)i * n_w * n_phi;
+    double lo = __builtin_inf(), hi = -__builtin_inf();
+    for (int r = br * XSW_BLK_R; r < min(br * XSW_BLK_R + XSW_BLK_R, n_w); ++r)
+        for (int c = bc * XSW_BLK_C; c < min(bc * XSW_BLK_C + XSW_BLK_C, n_phi); ++c) {
+            const double v = sl[(size_t)r * n_phi + c];
+            lo = fmin(lo, v);
+            hi = fmax(hi, v);
+        }
+    float2 o;
+    o.x = __double2float_rd(lo);
+    o.y = __double2float_ru(hi);
+    blk[t] = o;
+}
+__global__ __launch_bounds__(256) void k_band_minmax(const float2 *__restrict__ blk, int n_inc, int nbr, int nbc, int g, int nbands,
+                                                     float2 *__restrict__ band)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n_inc * nbands) return;
+    const int tb = (int)(t % nbands), i = (int)(t / nbands);
+    const float2 *b = blk + (size_t)i * nbr * nbc;
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+    for (int br = tb * g; br < min((tb + 1) * g, nbr); ++br)
+        for (int bc = 0; bc < nbc; ++bc) {
+            const float2 v = b[br * nbc + bc];
+            lo = fminf(lo, v.x);
+            hi = fmaxf(hi, v.y);
+        }
+    float2 o;
+    o.x = lo;
+    o.y = hi;
+    band[t] = o;
 }
 
 // ---- rise-then-fall columns (k_invert_band2): peak rows, the slice's shape flag, and the two inverse tables
