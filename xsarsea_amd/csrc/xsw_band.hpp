@@ -477,7 +477,10 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                 // (a run beyond XSW_LONG_RUN_MAX rows -- the flat top of a saturating GMF -- would overflow k_invert_band2's sweep
                 // after costing it the most: such a pixel goes straight to the general kernel)
                 // (without the cap on tail pixels: a-priori x 1.6 1189 -> 963 Mpx/s, x 2.5 377 -> 204: k_invert_band2 drowns in them)
-                if (eligb && run > ((w_hi_e < W.w_hi && !has_tail) ? XSW_LONG_RUN_MAX_CUT : XSW_LONG_RUN_MAX)) {
+                // (and a WIDE window with a long run -- sigma0 far above what any wind near the a-priori one explains: every direction
+                // searched, bands on the saturated top -- costs k_invert_band2 run x chunks of 128 directions trips: beyond
+                // A.area_max band candidates (run x directions) the general kernel's block pyramid is cheaper)
+                if (eligb && (run > ((w_hi_e < W.w_hi && !has_tail) ? XSW_LONG_RUN_MAX_CUT : XSW_LONG_RUN_MAX) || run * ncols_p > A.area_max)) {
                     myc = NC;
                     eligb = false;
                     if (ROLE == 2) skip = true;

@@ -107,6 +107,7 @@ struct KArgs {
     unsigned long long *mask_g, *mask_b;
     int long_run;               // k_invert_band, ROLE 1: rows along the a-priori direction from which a pixel is handed to k_invert_band2
     int tail_max;               // rows past the monotone ones a window may hold for k_invert_band2's tail sweep (0: never)
+    int area_max;               // k_invert_band, ROLE 1: band candidates (run x directions) beyond which a pixel skips k_invert_band2 (general kernel instead)
     int block_min;              // general kernel: windows of at least this many candidates are searched by the block pyramid (co_block_search)
     long long n, lines, samples;
     double dsig_co, inv_dsig_co, dsig_cr_scalar;

@@ -12,6 +12,9 @@
 
 using namespace xsw;
 
+#ifndef XSW_B2_AREA
+#define XSW_B2_AREA 8192  // measured (profiles/sweep_b2_area.sh, Mpx/s at 1e6 / 8192 / 4096 / 2048): outliers 5 % 695 / 2063 / 2151 / 2252, a-priori x 0.3 422 / 441 / 495 / 304, x 2.5 406 / 407 / 356 / 223
+#endif
 #ifndef XSW_BLOCK_MIN
 #define XSW_BLOCK_MIN 1024
 #endif
@@ -50,6 +53,8 @@ static int launch_invert(xsw_ctx *c, const KArgs &A_in, int algo, const LaunchCt
         const bool band2 = bitonic2 || wide2;
         if (band2) { B.list_b_count = lc.list + 1; B.list_b = lc.list + 16 + lc.list_cap; B.list_b_cap = B.list_cap; }
         B.long_run = long_run_env;
+        static const int area_max_env = getenv("XSW_B2_AREA") ? std::max(1, atoi(getenv("XSW_B2_AREA"))) : XSW_B2_AREA;
+        B.area_max = c->T.blk ? area_max_env : 0x7fffffff;  // (without the block tables the general kernel has nothing better to offer)
         static const int tail_max_env = getenv("XSW_TAIL_SWEEP") ? std::min(std::max(0, atoi(getenv("XSW_TAIL_SWEEP"))), 30000) : XSW_TAIL_SWEEP;
         B.tail_max = (wide2 && c->T.tail_min) ? tail_max_env : 0;  // the long-run role of k_invert_band2 only
         // strip masks: what the consumers walk when a list overflows (only the marked pixels instead of the whole raster)
