@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define XSW_VERSION 2
+#define XSW_VERSION 3
 
 enum { XSW_F32 = 0, XSW_F64 = 1 };           /* raster element type (complex rasters: c64 / c128) */
 enum { XSW_MEM_HOST = 0, XSW_MEM_DEVICE = 1,
@@ -170,10 +170,12 @@ int xsw_lut_upload(xsw_ctx *ctx, const xsw_lut *co, const xsw_lut *cr);
 /* Replaces _invert_from_model_numpy (windspeed.py:132-331).  Asynchronous on the context's stream
  * when mem == XSW_MEM_DEVICE; synchronous (returns with outputs filled) for host memory.
  * XSW_ALGO_PRUNED on a LUT whose columns rise monotonically with wind speed (every built-in GMF over most of its rows) runs
- * as three launches: k_invert_band decides the pixels its band rule can and hands those whose band holds a long run of rows
+ * as four launches: k_invert_band decides the pixels its band rule can and hands those whose band holds a long run of rows
  * along the a-priori direction (XSW_LONG_RUN = 4 or more: one such pixel would hold up every pixel of its pass) to
- * k_invert_band2, which sweeps long runs only (rows in batches, clipped to the chord of the search disc); k_invert_list does
- * the rest from a work list owned by the context (two lists of 4 bytes per EIGHTH pixel of the largest raster seen, plus two
+ * k_invert_band2, which sweeps long runs only (rows in batches, clipped to the chord of the search disc); the finite pixels the
+ * band rule is not for (windows past the monotone rows of the LUT, bands of thousands of candidates, sigma0 outliers) go to
+ * k_invert_blocks, a branch-and-bound over min / max tables of LUT blocks that bounds both cost terms together; k_invert_list does
+ * the rest from a work list owned by the context (three lists of 4 bytes per EIGHTH pixel of the largest raster seen, plus two
  * strip masks of one bit per pixel; a scene that hands on more than an eighth of its pixels overflows a list, which the
  * consumer answers by walking the strips of the raster and taking exactly the pixels marked in the mask; if the lists cannot
  * be allocated the one-kernel path runs); any other LUT, and XSW_ALGO_EXACT, take the general kernel.  Environment XSW_LONG_RUN=0 takes k_invert_band2 out of the chain (A/B measurements).  (Environment XSW_BAND2=1
@@ -210,6 +212,8 @@ typedef struct {
     int64_t last_list_pixels;/* pixels the most recent launch left to k_invert_list                   */
     double band2_kernel_ms;  /* k_invert_band2 (the pixels with long runs of band rows, between the two), summed   */
     int64_t last_band2_pixels;/* pixels the most recent launch handed to k_invert_band2              */
+    double blocks_kernel_ms; /* XSW_VERSION >= 3: k_invert_blocks (block pyramid, after k_invert_band2), summed */
+    int64_t last_blocks_pixels;/* pixels the most recent launch handed to k_invert_blocks             */
 } xsw_timing;
 int xsw_timing_enable(xsw_ctx *ctx, int on);
 int xsw_timing_read(xsw_ctx *ctx, xsw_timing *out);

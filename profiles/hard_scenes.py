@@ -62,10 +62,11 @@ def main():
         st = ctx.stats()
         ctx.stats_enable(False)
         n = max(tm["launches"], 1)
-        b, b2, ls = tm["first_kernel_ms"] / n, tm["band2_kernel_ms"] / n, tm["second_kernel_ms"] / n
+        b, b2, bl, ls = tm["first_kernel_ms"] / n, tm["band2_kernel_ms"] / n, tm["blocks_kernel_ms"] / n, tm["second_kernel_ms"] / n
         px = lines * samples
-        line = (f"{name:<22s} band {b:8.2f} ms  band2 {b2:8.2f} ms ({100 * tm['last_band2_pixels'] / px:6.2f} %)  list {ls:8.2f} ms"
-                f"  -> {px / (b + b2 + ls) / 1e3:8.0f} Mpx/s  listed {100 * tm['last_list_pixels'] / px:6.2f} %"
+        line = (f"{name:<22s} band {b:8.2f} ms  band2 {b2:8.2f} ms ({100 * tm['last_band2_pixels'] / px:6.2f} %)"
+                f"  blocks {bl:8.2f} ms ({100 * tm['last_blocks_pixels'] / px:6.2f} %)  list {ls:8.2f} ms"
+                f"  -> {px / (b + b2 + bl + ls) / 1e3:8.0f} Mpx/s  listed {100 * tm['last_list_pixels'] / px:6.2f} %"
                 f"  cand/px {st['cand_co'] / max(st['pixels_co'], 1):8.1f}  exact {st.get('pixels_exact', 0)}")
         if args.verify:
             run(o)

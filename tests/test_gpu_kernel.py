@@ -801,7 +801,7 @@ for lut_name, lut in (("cmod5n", lco), ("noisy", noisy)):
 """
 
 
-@pytest.mark.parametrize("mode", ["default", "all-blocks", "all-blocks-one-kernel", "no-blocks", "small-list"])
+@pytest.mark.parametrize("mode", ["default", "all-blocks", "all-blocks-one-kernel", "no-blocks", "small-list", "no-blocks-kernel"])
 def test_block_pyramid_routes(mode):
     """Round 4: the block pyramid of the general kernel (co_block_search: min / max per block of 4 speeds x 16 directions, a lower
     bound of BOTH cost terms together) in a fresh process.  Scenes with sigma0 outliers (x10, x31.6, x1000, x0.01: ships, land,
@@ -813,7 +813,7 @@ def test_block_pyramid_routes(mode):
     import subprocess
     import sys
     from conftest import REPO
-    env = {k: v for k, v in os.environ.items() if k not in ("XSW_BLOCK_MIN", "XSW_NO_BLOCKS", "XSW_NO_BAND", "XSW_LIST_CAP_TEST", "XSW_LONG_RUN")}
+    env = {k: v for k, v in os.environ.items() if k not in ("XSW_BLOCK_MIN", "XSW_NO_BLOCKS", "XSW_NO_BAND", "XSW_LIST_CAP_TEST", "XSW_LONG_RUN", "XSW_NO_BLOCKS_KERNEL")}
     if mode.startswith("all-blocks"):
         env["XSW_BLOCK_MIN"] = "0"
     if mode == "all-blocks-one-kernel":
@@ -822,6 +822,8 @@ def test_block_pyramid_routes(mode):
         env["XSW_NO_BLOCKS"] = "1"
     if mode == "small-list":
         env["XSW_LIST_CAP_TEST"] = "300"
+    if mode == "no-blocks-kernel":
+        env["XSW_NO_BLOCKS_KERNEL"] = "1"
     r = subprocess.run([sys.executable, "-c", _BLOCKS_SCRIPT.format(repo=REPO)], env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-2000:]
     rows = [l.split() for l in r.stdout.splitlines() if l.startswith("RESULT")]

@@ -56,6 +56,9 @@ STAGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int32, ctype
 STAGE_INC, STAGE_SIGMA0_CO, STAGE_SIGMA0_CR, STAGE_DSIG_CR, STAGE_ANC = range(5)
 
 
+ABI_VERSION = 3  # include/xsw.h: XSW_VERSION
+
+
 class Stats(ctypes.Structure):
     _fields_ = [("pixels_co", ctypes.c_uint64), ("cand_co", ctypes.c_uint64), ("pixels_exact", ctypes.c_uint64),
                 ("pixels_cr", ctypes.c_uint64)]
@@ -63,7 +66,8 @@ class Stats(ctypes.Structure):
 
 class Timing(ctypes.Structure):
     _fields_ = [("launches", ctypes.c_int64), ("first_kernel_ms", ctypes.c_double), ("second_kernel_ms", ctypes.c_double),
-                ("last_list_pixels", ctypes.c_int64), ("band2_kernel_ms", ctypes.c_double), ("last_band2_pixels", ctypes.c_int64)]
+                ("last_list_pixels", ctypes.c_int64), ("band2_kernel_ms", ctypes.c_double), ("last_band2_pixels", ctypes.c_int64),
+                ("blocks_kernel_ms", ctypes.c_double), ("last_blocks_pixels", ctypes.c_int64)]
 
 
 _cdll = None
@@ -131,8 +135,8 @@ def load():
         lib.xsw_host_alloc.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
         lib.xsw_host_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.xsw_set_host_threads.argtypes = [ctypes.c_void_p, ctypes.c_int]
-        if lib.xsw_version() != 2:
-            raise XswError(f"{_build.LIB} is version {lib.xsw_version()}, this package binds version 2: rebuild it")
+        if lib.xsw_version() != ABI_VERSION:
+            raise XswError(f"{_build.LIB} is version {lib.xsw_version()}, this package binds version {ABI_VERSION}: rebuild it")
         _cdll = lib
     return _cdll
 

@@ -200,22 +200,26 @@ extern "C" int xsw_timing_read(xsw_ctx *c, xsw_timing *out)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     out->launches = 0;
-    out->first_kernel_ms = out->second_kernel_ms = out->band2_kernel_ms = 0.0;
+    out->first_kernel_ms = out->second_kernel_ms = out->band2_kernel_ms = out->blocks_kernel_ms = 0.0;
     out->last_band2_pixels = 0;
     out->last_list_pixels = 0;
+    out->last_blocks_pixels = 0;
     if (c->d_list) {
-        unsigned cnt[2] = {0, 0};
+        unsigned cnt[3] = {0, 0, 0};
         HIPCHK(c, hipMemcpy(cnt, c->d_list, sizeof cnt, hipMemcpyDeviceToHost));
         out->last_list_pixels = (int64_t)cnt[0];
         out->last_band2_pixels = (int64_t)cnt[1];
+        out->last_blocks_pixels = (int64_t)cnt[2];
     }
-    for (size_t k = 0; k + 4 <= c->timing_events.size(); k += 4) {
-        float a = 0.f, b = 0.f, d = 0.f;
+    for (size_t k = 0; k + 5 <= c->timing_events.size(); k += 5) {  // start, after k_invert_band, k_invert_band2, k_invert_blocks, k_invert_list
+        float a = 0.f, b = 0.f, bl = 0.f, d = 0.f;
         HIPCHK(c, hipEventElapsedTime(&a, c->timing_events[k], c->timing_events[k + 1]));
         HIPCHK(c, hipEventElapsedTime(&b, c->timing_events[k + 1], c->timing_events[k + 2]));
-        HIPCHK(c, hipEventElapsedTime(&d, c->timing_events[k + 2], c->timing_events[k + 3]));
+        HIPCHK(c, hipEventElapsedTime(&bl, c->timing_events[k + 2], c->timing_events[k + 3]));
+        HIPCHK(c, hipEventElapsedTime(&d, c->timing_events[k + 3], c->timing_events[k + 4]));
         out->first_kernel_ms += a;
         out->band2_kernel_ms += b;
+        out->blocks_kernel_ms += bl;
         out->second_kernel_ms += d;
         out->launches += 1;
     }
@@ -627,10 +631,10 @@ static void ensure_list(xsw_ctx *c, long long n, long long lines)
     c->d_masks = nullptr;
     c->list_cap = c->mask_strips = 0;
     static const bool no_list = getenv("XSW_FAIL_LIST_ALLOC") != nullptr;  // tests: the allocation-failure route
-    // lists G and B, then the two strip masks (0.25 B per pixel)
-    if (!no_list && hipMalloc((void **)&c->d_list, (2 * want + 16) * sizeof(unsigned) + 2 * want_strips * sizeof(unsigned long long)) == hipSuccess) {
+    // lists G, B and C, then the two strip masks (0.25 B per pixel)
+    if (!no_list && hipMalloc((void **)&c->d_list, (3 * want + 16) * sizeof(unsigned) + 2 * want_strips * sizeof(unsigned long long)) == hipSuccess) {
         c->list_cap = want;
-        c->d_masks = (unsigned long long *)(c->d_list + 16 + 2 * want);
+        c->d_masks = (unsigned long long *)(c->d_list + 16 + 3 * want);
         c->mask_strips = want_strips;
     } else { c->d_list = nullptr; (void)hipGetLastError(); }
 }
@@ -928,7 +932,7 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
                  o_cc = o_anc + (a->anc ? pad(max_px * es * 2) : 0), o_ccr = o_cc + (want_co ? pad(max_px * 4) : 0),
                  o_end = o_ccr + (want_cr ? pad(max_px * 4) : 0);
     const size_t list_cap = std::max<size_t>(max_px / 4, 1 << 14) & ~(size_t)1, mask_strips = strips_for((long long)max_px, lines_per_chunk);
-    const size_t o_masks = o_end + pad((2 * list_cap + 16) * sizeof(unsigned)), dev_bytes = o_masks + 2 * mask_strips * sizeof(unsigned long long);  // lists G and B, strip masks
+    const size_t o_masks = o_end + pad((3 * list_cap + 16) * sizeof(unsigned)), dev_bytes = o_masks + 2 * mask_strips * sizeof(unsigned long long);  // lists G, B and C, strip masks
     const int dtype = a->dtype, out_dtype = a->out_dtype;
     static const bool prof = getenv("XSW_HOST_PROFILE") != nullptr;  // phase times of the pipeline on stderr (experiments)
     std::atomic<long long> t_stage{0}, t_gpu{0}, t_expand{0}, t_reserve{0};

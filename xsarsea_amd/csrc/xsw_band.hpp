@@ -362,6 +362,73 @@ __device__ __forceinline__ void mask_mark(unsigned long long *__restrict__ mask,
     }
 }
 
+// What every wave of the band kernels (and of k_invert_blocks) ends with, one pixel per lane: the cross-pol search
+// (windspeed.py:252-269; interval rule only, host: L.cr_monotone), the hand-over of the pixels that are still undecided -- to_b:
+// list B (k_invert_band2), to_c: list C (k_invert_blocks), everything else and whatever did not fit: list G (k_invert_list), or the
+// list's strip mask once it is full -- and the store of the decided ones.
+// flags / my_flat: the lane's pixel class and winning flat index (-1: no co-pol answer yet).  strip: the wave's pixels are strip
+// `strip` of the raster (lane = sample); -1: listed pixels.
+template <typename T, typename TO, bool CR, bool COUNT>
+__device__ __forceinline__ void wave_tail(const DevTables &L, const KArgs &A, long long i, bool in, int lane, int flags, int my_flat, bool to_b, bool to_c,
+                                          long long strip, unsigned cand)
+{
+    const double nan = __builtin_nan("");
+    int my_icr = -1;
+    const bool need_co = (flags & F_NEED_CO) != 0;
+    bool unresolved = in && need_co && my_flat < 0;  // not eligible, or undecided by its pass
+
+    // ---- cross-pol search (windspeed.py:252-269), one pixel per lane, interval rule only (host: L.cr_monotone)
+    bool need_cr = false;
+    if (CR && A.s_cr) {
+        const double inc = ld<T>(A.inc, i);
+        const T x = ((const T *)A.s_cr)[i];
+        const double s_cr = to_db(x, A.is_db);
+        const double dsig = A.dsig_cr ? (double)((const T *)A.dsig_cr)[i] : (double)(T)(x * (T)0 + (T)A.dsig_cr_scalar);
+        need_cr = in && !(flags & (F_EARLY_NAN | F_CR_RAW_NAN)) && s_cr == s_cr && dsig == dsig;
+        const bool here = need_cr && !unresolved;
+        const int i_inc_cr = here ? nearest_index(L.inc_cr, L.n_inc_cr, inc, L.inc_cr_uniform != 0, L.inc_cr0, L.inv_inccrstep) : 0;
+        const double aco = (here && need_co) ? L.abs_co[my_flat] : nan;  // np.abs(wind_co), table [n_w][n_phi]
+        bool undecided = here;
+        const bool done = L.inv_cr ? search_cr_scan(L, here, i_inc_cr, s_cr, dsig, need_co, aco, my_icr, undecided)
+                                   : search_cr_interval(L, here, i_inc_cr, s_cr, dsig, need_co, aco, my_icr, undecided);
+        unresolved = unresolved || (need_cr && (undecided || !done));
+        if (need_cr) flags |= F_NEED_CR;
+    }
+    if (COUNT && A.stats) {
+        const unsigned long long done_co = __ballot(in && need_co && my_flat >= 0), done_cr = __ballot(need_cr && !unresolved);
+        if (lane == 0) {
+            atomicAdd(&A.stats[0], (unsigned long long)__popcll(done_co));
+            atomicAdd(&A.stats[1], (unsigned long long)cand);
+            atomicAdd(&A.stats[3], (unsigned long long)__popcll(done_cr));
+        }
+    }
+    // hand the undecided pixels over (a pixel that does not fit into its list goes on list G; one that does not fit there either
+    // is marked in the list's strip mask -- KArgs::mask_g / mask_b, zeroed before every launch, touched only when a list overflows --
+    // and the consumer takes the list, then the marked pixels)
+    bool drop_b = false, drop_c = false;
+    if (A.list_b) drop_b = list_append(A.list_b_count, A.list_b, A.list_b_cap, unresolved && to_b, i, lane);
+    if (A.list_c) drop_c = list_append(A.list_c_count, A.list_c, A.list_c_cap, unresolved && to_c && !to_b, i, lane);
+    const bool for_c = A.list_c != nullptr && to_c && !to_b && !drop_c;
+    const bool drop_g = list_append(A.list_count, A.list, A.list_cap, unresolved && !to_b && !for_c, i, lane);
+    if (A.mask_g) {
+        if (A.list_b) mask_mark(A.mask_b, drop_b, i, strip, A.samples, lane);
+        mask_mark(A.mask_g, drop_g, i, strip, A.samples, lane);
+    }
+    if (in) {
+        if (!unresolved) {
+            Pixel Q;  // what store_pixel reads: flags and the ancillary wind (reloaded: not kept live through the passes)
+            Q.flags = flags;
+            Q.a_re = nan; Q.a_im = nan;
+            if (A.anc) {
+                typename Cx<T>::type z = ((const typename Cx<T>::type *)A.anc)[i];
+                Q.a_re = (double)z.x;
+                Q.a_im = (double)z.y;
+            }
+            store_pixel<TO, CR>(L, A, i, Q, my_flat, my_icr);
+        }
+    }
+}
+
 // One wave's 64 pixels (lane l: pixel i, `in` = the lane has one) through stage 1, the band passes, the cross-pol phase and the
 // store.  Body of k_invert_band (tiles of the raster) and k_invert_band2 (pixels of a work list, BITONIC rule).
 // COUNT = true: the statistics instantiation (xsw_stats_enable): candidates are counted per pass; its own kernel so that the
@@ -383,6 +450,8 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
     bool skip = false;        // ROLE 2 walking every strip (list B overflowed): not one of the long-run pixels this kernel is for
     bool to_bitonic = false;  // left to the second band kernel: its window leaves the monotone rows of a rise-then-fall slice
                               // (XSW_BAND2=1), or -- ROLE 1 -- its band holds a long run of rows
+    bool to_c = false;        // left to k_invert_blocks (list C): a finite pixel the band rule is not for -- its window leaves the monotone
+                              // rows, or its band holds more rows / candidates than k_invert_band2 takes
     {
         // ---- stage 1, one pixel per lane: classify, incidence bin, upper bound along the a-priori direction, window
         Pixel P;
@@ -430,6 +499,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
             } else {
                 eligb = need && w_hi_e < L.mono_rows[need ? P.i_inc : 0];  // the window stays inside the monotone rows
                 to_bitonic = need && !eligb && L.inv2 != nullptr && L.bitonic_ok[P.i_inc] != 0;
+                if (ROLE != 2) to_c = need && !eligb && !to_bitonic;
             }
             if (COUNT) cand += (unsigned)__popcll(__ballot(eligb)) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)) + (XSW_BAND_RAYS - 1) * 2 * XSW_RAY_SIDE_STEPS);
             // class of a window by its number of (virtual) columns n: the smallest of 4, 6, 8, 12, ..., 96, 128 that holds it, i.e. S lanes
@@ -484,6 +554,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                     myc = NC;
                     eligb = false;
                     if (ROLE == 2) skip = true;
+                    if (ROLE == 1) to_c = true;
                 }
                 const bool handed = eligb && (run >= A.long_run || has_tail);  // (a tail is k_invert_band2's whatever the run's length)
                 if (ROLE == 1 && handed) {  // the second band kernel's
@@ -570,63 +641,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
         skip = skip || (flags & F_NEED_CO) == 0;
         in = in && !skip;
     }
-    const bool need_co = (flags & F_NEED_CO) != 0;
-    bool unresolved = in && need_co && my_flat < 0;  // not eligible, or undecided by its pass
-
-    // ---- cross-pol search (windspeed.py:252-269), one pixel per lane, interval rule only (host: L.cr_monotone)
-    bool need_cr = false;
-    if (CR && A.s_cr) {
-        const double inc = ld<T>(A.inc, i);
-        const T x = ((const T *)A.s_cr)[i];
-        const double s_cr = to_db(x, A.is_db);
-        const double dsig = A.dsig_cr ? (double)((const T *)A.dsig_cr)[i] : (double)(T)(x * (T)0 + (T)A.dsig_cr_scalar);
-        need_cr = in && !(flags & (F_EARLY_NAN | F_CR_RAW_NAN)) && s_cr == s_cr && dsig == dsig;
-        const bool here = need_cr && !unresolved;
-        const int i_inc_cr = here ? nearest_index(L.inc_cr, L.n_inc_cr, inc, L.inc_cr_uniform != 0, L.inc_cr0, L.inv_inccrstep) : 0;
-        const double aco = (here && need_co) ? L.abs_co[my_flat] : nan;  // np.abs(wind_co), table [n_w][n_phi]
-        bool undecided = here;
-        const bool done = L.inv_cr ? search_cr_scan(L, here, i_inc_cr, s_cr, dsig, need_co, aco, my_icr, undecided)
-                                   : search_cr_interval(L, here, i_inc_cr, s_cr, dsig, need_co, aco, my_icr, undecided);
-        unresolved = unresolved || (need_cr && (undecided || !done));
-        if (need_cr) flags |= F_NEED_CR;
-    }
-    if (COUNT && A.stats) {
-        const unsigned long long done_co = __ballot(in && need_co && my_flat >= 0), done_cr = __ballot(need_cr && !unresolved);
-#ifdef XSW_DEBUG_REASONS  // pixels_exact := not-eligible count | undecided-by-pass count << 32 (experiments only)
-        const unsigned long long noel = __ballot(in && need_co && !(pos >= 0)), und = __ballot(in && need_co && (pos >= 0) && my_flat < 0);
-        if (lane == 0) atomicAdd(&A.stats[2], (unsigned long long)__popcll(noel) | ((unsigned long long)__popcll(und) << 32));
-#endif
-        if (lane == 0) {
-            atomicAdd(&A.stats[0], (unsigned long long)__popcll(done_co));
-            atomicAdd(&A.stats[1], (unsigned long long)cand);
-            atomicAdd(&A.stats[3], (unsigned long long)__popcll(done_cr));
-        }
-    }
-    // hand the undecided pixels over: a window that left the monotone rows of a rise-then-fall slice goes to k_invert_band2 (list
-    // B, the band rule on both branches of the columns), everything else -- and what k_invert_band2 cannot decide -- to k_invert_list
-    const bool to_b = !BITONIC && A.list_b && to_bitonic;
-    // (a pixel that does not fit into its list is marked in the list's strip mask instead: the consumer takes the list, then the
-    // marked pixels -- KArgs::mask_g / mask_b, zeroed before every launch, touched only when a list overflows)
-    bool drop_b = false;
-    if (!BITONIC && A.list_b) drop_b = list_append(A.list_b_count, A.list_b, A.list_b_cap, unresolved && to_b, i, lane);
-    const bool drop_g = list_append(A.list_count, A.list, A.list_cap, unresolved && !to_b, i, lane);
-    if (A.mask_g) {
-        if (!BITONIC && A.list_b) mask_mark(A.mask_b, drop_b, i, strip, A.samples, lane);
-        mask_mark(A.mask_g, drop_g, i, strip, A.samples, lane);
-    }
-    if (in) {
-        if (!unresolved) {
-            Pixel Q;  // what store_pixel reads: flags and the ancillary wind (reloaded: not kept live through the passes)
-            Q.flags = flags;
-            Q.a_re = nan; Q.a_im = nan;
-            if (A.anc) {
-                typename Cx<T>::type z = ((const typename Cx<T>::type *)A.anc)[i];
-                Q.a_re = (double)z.x;
-                Q.a_im = (double)z.y;
-            }
-            store_pixel<TO, CR>(L, A, i, Q, my_flat, my_icr);
-        }
-    }
+    wave_tail<T, TO, CR, COUNT>(L, A, i, in, lane, flags, my_flat, !BITONIC && A.list_b != nullptr && to_bitonic, to_c, strip, cand);
 }
 
 template <typename T, typename TO, bool CR, bool COUNT, int ROLE = 0>

@@ -1,0 +1,324 @@
+// `k_invert_blocks` (round 4): the block pyramid of co_block_search (xsw_device.hpp; tests/prune_model.py: block_pruned_argmin)
+// with FOUR pixels per wave at a time, one per 16-lane segment -- the kernel for the pixels the band rule does not pay for:
+// windows that leave the monotone rows of the LUT, bands that hold thousands of candidates (an a-priori wind far from the sigma0
+// contour), sigma0 outliers whose window is the whole grid.  k_invert_band appends them to list C.
+//
+// Why segments: one such search is a chain of dependent round trips (band bounds -> block bounds -> candidates) with little
+// arithmetic in between; a wave that walks its pixels one after the other (k_invert_list) waits for memory most of the time and
+// pays the fixed cost of every step -- ballots, reductions, scalar control -- per pixel.  With a pixel per segment the steps of
+// four searches share that cost and keep four times the loads in flight; a block of XSW_BLK_R = 4 speed rows x XSW_BLK_C = 16
+// directions is exactly one segment wide (lane = direction, four rows per lane: four more loads in flight).
+//
+// One pass (co_seg16_pass), per segment:
+//   level 1   (windows of more than XSW_SEG_DIRECT blocks)  lower bound of every band of L.blk_g block rows the window touches;
+//   round 1   the blocks of the most promising band (or of the whole window, when it is small) are bounded, the kept ones queued
+//             in LDS and swept: the running minimum tightens the bound;
+//   round 2   the bands that survive the tightened bound: their blocks bounded, queued, swept;
+//   settle    a unique candidate within eps of the segment's screening minimum is the reference's argmin; anything else
+//             (near-ties, a queue that overflowed, more than 64 bands) leaves the pixel to k_invert_list, whose wave-wide block
+//             search re-scores near-ties in the reference's operation order.
+// The bounds, their deflation and the exactness argument are co_block_search's.
+#pragma once
+#include "xsw_band.hpp"
+
+namespace xsw {
+
+#ifndef XSW_SEGQ_CAP
+#define XSW_SEGQ_CAP 128  // kept blocks a segment may queue per round (8192 candidates); more: the pixel is left to k_invert_list
+#endif
+#ifndef XSW_SEG_DIRECT
+#define XSW_SEG_DIRECT 96  // windows of at most this many blocks are bounded block by block, without the band level
+#endif
+#ifndef XSW_BLOCKS_WAVES
+#define XSW_BLOCKS_WAVES 4
+#endif
+static_assert(XSW_BLK_R == 4 && XSW_BLK_C == 16, "a block is one 16-lane segment wide, four rows per lane");
+
+struct SegQEntry { int brbc; float lb; };  // block row | block column << 16; its lower bound, rounded down
+
+__device__ __forceinline__ unsigned seg_bits(unsigned long long m, int q) { return (unsigned)(m >> (q * 16)) & 0xffffu; }
+
+// lower bound of J over block (br, bc) of a slice: the sigma0 term from the block's {min, max}, the wind term from the distance
+// of m/2 to the block's polar cell (co_block_search; tests/prune_model.py: sig_lb + cell_wind_lb)
+__device__ __forceinline__ double block_lb(const DevTables &L, float2 mm, int br, int bc, double s, double ainv, double ah, double bh, double m2,
+                                           double mh, double tol, double wh0, double whs)
+{
+    const int r0 = min(br * XSW_BLK_R, L.n_w - 1), r1 = min(br * XSW_BLK_R + XSW_BLK_R, L.n_w) - 1;
+    const int c0 = min(bc * XSW_BLK_C, L.n_phi - 1), c1 = min(bc * XSW_BLK_C + XSW_BLK_C, L.n_phi) - 1;
+    const double wha = fma((double)r0, whs, wh0), whb = fma((double)max(r1, r0), whs, wh0);
+    const double dsg = fmax(0.0, fmax((double)mm.x - s, s - (double)mm.y)) * ainv;
+    const double rad = fmax(0.0, fmax(wha - mh, mh - whb));
+    double lbw = rad * rad;
+    if (L.blk_span_ok) {
+        const double2 ea = ((const double2 *)L.csphi)[c0], eb = ((const double2 *)L.csphi)[max(c1, c0)];
+        const bool inside = (ea.x * bh - ea.y * ah >= -tol) && (ah * eb.y - bh * eb.x >= -tol);
+        const double pmx = fmax(ah * ea.x + bh * ea.y, ah * eb.x + bh * eb.y);
+        const double tt = fmin(fmax(pmx, wha), whb);
+        const double e2 = m2 + tt * (tt - 2.0 * pmx);
+        lbw = inside ? lbw : fmax(lbw, e2);
+    }
+    return fma(dsg, dsg, lbw);
+}
+
+// Up to four pending pixels of the wave (lane l owns pixel l: P_*), one per segment.  Decided pixels: my_flat of the owner lane;
+// the others are flagged in `redo`.
+__device__ __forceinline__ void co_seg16_pass(const DevTables &L, double inv_dsig, int lane, double P_s, double P_a, double P_b, double P_bd, int P_iinc,
+                                              int P_rows, int P_dirs, unsigned long long &pend, SegQEntry *__restrict__ qlds /* this wave's [4][XSW_SEGQ_CAP] */,
+                                              int &my_flat, unsigned long long &redo, unsigned &cand)
+{
+    constexpr int R = XSW_BLK_R, C = XSW_BLK_C, CAP = XSW_SEGQ_CAP;
+    const double inf = __builtin_inf();
+    const int q = lane >> 4, sl = lane & 15;
+    int o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        o[k] = pend ? (__ffsll((long long)pend) - 1) : -1;
+        if (pend) pend &= pend - 1;
+    }
+    int own = o[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) own = (q == k) ? o[k] : own;
+    const bool valid = own >= 0;
+    const int src = valid ? own : 0;
+    const double s = __shfl(P_s, src), a = __shfl(P_a, src), b = __shfl(P_b, src), bd = __shfl(P_bd, src);
+    const int i_inc = __shfl(P_iinc, src);
+    const unsigned rows = (unsigned)__shfl(P_rows, src), dirs = (unsigned)__shfl(P_dirs, src);
+    const double ah = 0.5 * a, bh = 0.5 * b, m2 = ah * ah + bh * bh, mh = sqrt(m2), sn = -s * inv_dsig, ainv = fabs(inv_dsig);
+    const double wh0 = 0.5 * L.w0, whs = L.wstep_half;
+    const double slack = 1e-8 * (1.0 + m2), tol = 1e-9 * mh + 1e-300;
+    const double rs = bd * ainv;  // >= sqrt(J_ub) (co_window_lanes: band_d = |dsig| sqrt(J_ub), inflated)
+    double jub = rs * rs * (1.0 + 1e-12);
+    const int w_lo = (int)(rows & 0xffffu), w_hi = min(max((int)(rows >> 16), w_lo), L.n_w - 1);
+    const int ip_lo = (int)(dirs & 0xffffu), ip_hi = min(max((int)(dirs >> 16), ip_lo), L.n_phi - 1);
+    const int br_lo = w_lo / R, br_hi = w_hi / R, bc_lo = ip_lo / C, bc_hi = ip_hi / C, ncb = bc_hi - bc_lo + 1;
+    const int nbw = (br_hi - br_lo + 1) * ncb;
+    const float inv_ncb = 1.0f / (float)ncb;
+    const int G = L.blk_g, tb_lo = br_lo / G, nbd = br_hi / G - tb_lo + 1;
+    const bool bandmode = valid && nbw > XSW_SEG_DIRECT;
+    bool bad = bandmode && nbd > 64;  // (LUTs of thousands of speed rows: the wave-wide search of k_invert_list)
+    const char *__restrict__ base = (const char *)L.co;
+    const unsigned rowB = (unsigned)L.phi_pad * 8u, slice0 = (unsigned)(i_inc * L.n_w) * rowB;
+    const float2 *__restrict__ blk = L.blk + (size_t)i_inc * L.nbr * L.nbc;
+    const float2 *__restrict__ bnd = L.bandmm + (size_t)i_inc * L.nbands;
+    SegQEntry *__restrict__ qseg = qlds + q * CAP;
+
+    double best = inf, second = inf;
+    int bflat = 0;
+    int qn = 0;
+    bool ovf = false;
+
+    // level 1, one lane per band (band tb_lo + 16 j + sl): the segment's most promising band (mask = false), or the set of bands
+    // the current bound keeps (mask = true), as a bit mask relative to tb_lo
+    const int nj = (wave_max_i(bandmode && !bad ? nbd : 0) + 15) >> 4;  // wave-uniform, <= 4
+    auto level1 = [&](bool mask, int &first, unsigned long long &bands) {
+        double lb1[4];
+        bool tv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lb1[j] = inf;
+            tv[j] = false;
+            if (j >= nj) continue;  // wave-uniform
+            const int t = 16 * j + sl;
+            tv[j] = bandmode && !bad && t < nbd;
+            const int tc = min(tb_lo + t, L.nbands - 1);
+            const float2 mm = bnd[tv[j] ? tc : 0];
+            const int r0 = tc * G * R, r1 = min((tc + 1) * G * R, L.n_w) - 1;
+            const double wha = fma((double)r0, whs, wh0), whb = fma((double)r1, whs, wh0);
+            const double dsg = fmax(0.0, fmax((double)mm.x - s, s - (double)mm.y)) * ainv;
+            const double rad = fmax(0.0, fmax(wha - mh, mh - whb));
+            lb1[j] = tv[j] ? fma(dsg, dsg, rad * rad) : inf;
+        }
+        if (!mask) {
+            double mn = 1e308;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mn = vmin(mn, tv[j] ? lb1[j] : 1e308);
+            mn = seg_min_d<16>(mn);
+            first = -1;
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {
+                if (j >= nj) continue;
+                const unsigned bits = seg_bits(ballot64(tv[j] && lb1[j] == mn), q);
+                first = bits ? 16 * j + (__ffs((int)bits) - 1) : first;
+            }
+        } else {
+            bands = 0ULL;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j >= nj) continue;
+                const unsigned bits = seg_bits(ballot64(tv[j] && !(lb1[j] * (1.0 - 1e-8) > jub + slack)), q);
+                bands |= (unsigned long long)bits << (16 * j);
+            }
+        }
+    };
+    // the block rows [curA, ...) and the number of blocks curN of band t (relative to tb_lo) inside the window
+    auto band_range = [&](int t, int &curA, int &curN) {
+        curA = max((tb_lo + t) * G, br_lo);
+        curN = (min(min((tb_lo + t + 1) * G, L.nbr), br_hi + 1) - curA) * ncb;
+    };
+    // bounds the blocks of the segment's current band, then of the bands left in `bands`, 16 per step; the kept ones are queued
+    auto bound_blocks = [&](int curA, int curN, unsigned long long bands) {
+        int k0 = 0;
+        while (ballot64(k0 < curN) != 0ULL) {
+            const int idx = k0 + sl;
+            const bool bv = idx < curN;
+            const int dr = bv ? (int)(((float)idx + 0.5f) * inv_ncb) : 0, dc = bv ? idx - dr * ncb : 0;
+            const int br = curA + dr, bc = bc_lo + dc;
+            const float2 mm = blk[bv ? br * L.nbc + bc : 0];
+            const double lb = block_lb(L, mm, br, bc, s, ainv, ah, bh, m2, mh, tol, wh0, whs);
+            const bool keep = bv && !(lb * (1.0 - 1e-8) > jub + slack);
+            const unsigned kb = seg_bits(ballot64(keep), q);
+            const int at = qn + __popc(kb & ((1u << sl) - 1u));
+            if (keep && at < CAP) {
+                SegQEntry e;
+                e.brbc = br | (bc << 16);
+                e.lb = __double2float_rd(lb);
+                qseg[at] = e;
+            }
+            const int nq = qn + __popc(kb);
+            ovf = ovf || nq > CAP;
+            qn = min(nq, CAP);
+            k0 += 16;
+            if (k0 >= curN && bands != 0ULL) {  // the segment's next band
+                const int t = __ffsll((long long)bands) - 1;
+                bands &= bands - 1;
+                band_range(t, curA, curN);
+                k0 = 0;
+            }
+        }
+    };
+    // sweeps the queued blocks: lane = direction, four speed rows per lane; the running minimum tightens the bound
+    auto sweep_queue = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int jmax = wave_max_i(qn);
+#pragma unroll 1
+        for (int j = 0; j < jmax; ++j) {
+            const SegQEntry e = qseg[min(j, CAP - 1)];
+            const bool act = j < qn && !((double)e.lb * (1.0 - 1e-8) > jub + slack);
+            const unsigned long long am = ballot64(act);
+            if (am == 0ULL) continue;
+            const int br = e.brbc & 0xffff, bc = (int)((unsigned)e.brbc >> 16);
+            const int dir = bc * C + sl, dirc = act ? min(dir, L.n_phi - 1) : 0;
+            const bool okd = act && dir < L.n_phi;
+            const int row0 = act ? br * R : 0;
+            const unsigned off0 = slice0 + (unsigned)dirc * 8u;
+            double v[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) v[k] = ld_co(base, off0, min(row0 + k, L.n_w - 1), rowB);
+            const double2 cs = ((const double2 *)L.csphi)[dirc];
+            const double U = 2.0 * (ah * cs.x + bh * cs.y);
+            const int flat0 = row0 * L.n_phi + dirc;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const double wh = fma((double)(row0 + k), whs, wh0);
+                const double dd = fma(v[k], inv_dsig, sn);
+                double J = fma(dd, dd, wh * (wh - U));
+                J = (okd && row0 + k < L.n_w) ? J : inf;
+                second = vmin(second, vmax(J, best));
+                bflat = J < best ? flat0 + k * L.n_phi : bflat;
+                best = vmin(best, J);
+            }
+            const double g = seg_min_d<16>(best);
+            jub = (g < 1e300) ? fmin(jub, (g + m2) * (1.0 + 1e-9) + 1e-9) : jub;
+            cand += (unsigned)__popcll(am) * 4u;
+        }
+        qn = 0;
+        __builtin_amdgcn_wave_barrier();  // the queue is rewritten by the next round
+    };
+
+    // round 1: the most promising band (large windows), or the whole window
+    int first = -1, curA = br_lo, curN = (valid && !bandmode) ? nbw : 0;
+    unsigned long long bands = 0ULL;
+    if (nj > 0) {
+        level1(false, first, bands);
+        if (bandmode && !bad && first >= 0) band_range(first, curA, curN);
+    }
+    bound_blocks(curA, curN, 0ULL);
+    sweep_queue();
+    if (nj > 0) {  // round 2: the bands the tightened bound keeps
+        int dummy;
+        level1(true, dummy, bands);
+        if (first >= 0) bands &= ~(1ULL << first);
+        curN = 0;
+        if (bands != 0ULL) {
+            const int t = __ffsll((long long)bands) - 1;
+            bands &= bands - 1;
+            band_range(t, curA, curN);
+        }
+        bound_blocks(curA, curN, bands);
+        sweep_queue();
+    }
+
+    // settle, per segment
+    const double gmin = seg_min_d<16>(best);
+    const double T = gmin + 1e-9 * (1.0 + fabs(gmin) + m2);
+    const unsigned long long amb = ballot64(valid && (second <= T || ovf || bad || !(gmin < 1e300))), surv = ballot64(valid && best <= T);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (o[k] < 0) continue;
+        const unsigned long long bits = 0xffffULL << (16 * k), sv = surv & bits;
+        if ((amb & bits) != 0ULL || __popcll(sv) != 1) {
+            redo |= 1ULL << o[k];
+        } else {
+            const int flat = rd_lane_i(bflat, __ffsll((long long)sv) - 1);
+            if (lane == o[k]) my_flat = flat;
+        }
+    }
+}
+
+// One wave's (up to) 64 listed pixels: stage 1 as in the band kernels (classification, incidence bin, three-ray bound, window),
+// the segment passes, the cross-pol phase and the store (wave_tail: what is still undecided goes to k_invert_list's work list).
+template <typename T, typename TO, bool CR>
+__device__ __forceinline__ void blocks_wave(const DevTables &L, const KArgs &A, long long i, bool in, int lane, SegQEntry *__restrict__ qlds)
+{
+    int flags, my_flat = -1;
+    unsigned cand = 0;
+    {
+        Pixel P;
+        load_pixel<T, false>(L, A, i, in, P);
+        flags = P.flags;
+        if (CR && A.s_cr) {
+            const T x = ((const T *)A.s_cr)[i];
+            const T dr = A.dsig_cr ? ((const T *)A.dsig_cr)[i] : (T)0;
+            if (x != x || dr != dr) flags |= F_CR_RAW_NAN;
+        }
+        const bool fin = in && (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0;
+        unsigned long long pend = __ballot(fin), redo = 0ULL;
+        if (pend) {
+            bool loose = false;
+            const CoWindow W = co_window_lanes<XSW_BAND_RAYS, XSW_BAND_RAY_D, XSW_BAND_SEEDED != 0>(L, P, A.inv_dsig_co, fabs(A.dsig_co), loose);
+            const int rows = W.w_lo | (W.w_hi << 16), dirs = (int)((unsigned)W.ip_lo | ((unsigned)W.ip_hi << 16));
+            // (a bound so loose that its float32 square root overflowed: band_d = inf -- the wave-wide search handles it)
+            if (!(W.band_d < 1e300)) pend &= ~__ballot(fin && !(W.band_d < 1e300));
+            while (pend) co_seg16_pass(L, A.inv_dsig_co, lane, P.s_co, P.a_re, P.b_eff, W.band_d, P.i_inc, rows, dirs, pend, qlds, my_flat, redo, cand);
+        }
+    }
+    wave_tail<T, TO, CR, false>(L, A, i, in, lane, flags, my_flat, false, false, -1, cand);
+}
+
+// Third kernel of the chain: the pixels k_invert_band left on list C, 64 per wave (fewer when the list is short: the passes of
+// a wave take its pixels four at a time), fixed grid, every wave strides over the list.
+template <typename T, typename TO, bool CR>
+__global__ __launch_bounds__(256, XSW_BLOCKS_WAVES) void k_invert_blocks(DevTables L, KArgs A)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ SegQEntry qlds[4][4 * XSW_SEGQ_CAP];
+    const long long count = (long long)*A.list_c_count;
+    const long long nlist = count < (long long)A.list_c_cap ? count : (long long)A.list_c_cap;  // (what did not fit went to k_invert_list's list)
+    const long long nwaves = (long long)gridDim.x * 4;
+    int ppw = 64;
+    if (nlist < 64LL * nwaves) {
+        ppw = 4;
+        while (ppw < 64 && (long long)ppw * nwaves < nlist) ppw <<= 1;
+    }
+    for (long long c = (long long)blockIdx.x * 4 + wv; c * ppw < nlist; c += nwaves) {  // wave-uniform
+        const long long k = c * ppw + lane;
+        const bool in = lane < ppw && k < nlist;
+        const long long i = (long long)A.list_c[in ? k : nlist - 1];
+        blocks_wave<T, TO, CR>(L, A, i, in, lane, qlds[wv]);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace xsw

@@ -99,6 +99,8 @@ struct KArgs {
     unsigned list_cap;          // entries the list holds; the counter runs on past it (overflow: k_invert_list takes every tile)
     unsigned *list_b, *list_b_count;  // list B (nullable): pixels k_invert_band hands to k_invert_band2 (long runs of band rows; rise-then-fall columns)
     unsigned list_b_cap;
+    unsigned *list_c, *list_c_count;  // list C (nullable): finite pixels the band rule is not for, k_invert_band -> k_invert_blocks (block pyramid, four pixels per wave at a time)
+    unsigned list_c_cap;
     // one 64-bit word per strip of 64 samples (strip = line * ceil(samples / 64) + strip column; nullable): bit l of mask_g =
     // pixel l of the strip is left to k_invert_list, of mask_b = handed to k_invert_band2, and DID NOT FIT into the list.  Zeroed
     // before every launch; a producer ORs a pixel in only when its append falls past the list's capacity, the consumer takes

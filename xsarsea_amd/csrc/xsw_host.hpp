@@ -24,7 +24,7 @@ struct xsw_ctx {
     unsigned long long *d_stats = nullptr;
     bool stats_on = false;
     bool timing_on = false;                 // xsw_timing_enable: HIP events around the kernels of every device-memory inversion
-    std::vector<hipEvent_t> timing_events;  // quadruples (start, after k_invert_band, after k_invert_band2, end) on the launch stream
+    std::vector<hipEvent_t> timing_events;  // quintuples (start, after k_invert_band, k_invert_band2, k_invert_blocks, k_invert_list) on the launch stream
     unsigned *d_list = nullptr;  // hand-over k_invert_band -> k_invert_list: [0] = count, [16..] = pixel indices
     size_t list_cap = 0;         // entries (context-owned, grown on demand: an eighth of the largest raster seen)
     unsigned long long *d_masks = nullptr;  // strip masks (2 x mask_strips words, after the lists in the same allocation)
@@ -53,7 +53,7 @@ static inline void timing_mark(xsw_ctx *c)
     if (!c->timing_on) return;
     hipEvent_t e = nullptr;
     if (hipEventCreate(&e) == hipSuccess && hipEventRecord(e, c->stream) == hipSuccess) c->timing_events.push_back(e);
-    else c->timing_on = false;  // never half a quadruple
+    else c->timing_on = false;  // never half a quintuple
 }
 
 

@@ -8,6 +8,7 @@
 
 #include "xsw_host.hpp"
 #include "xsw_band.hpp"
+#include "xsw_blocks.hpp"
 #include "xsw_exhaustive.hpp"
 
 using namespace xsw;
@@ -52,6 +53,11 @@ static int launch_invert(xsw_ctx *c, const KArgs &A_in, int algo, const LaunchCt
         const bool bitonic2 = c->T.inv2 != nullptr && !A.stats, wide2 = !bitonic2 && long_run_env > 0 && !A.stats;
         const bool band2 = bitonic2 || wide2;
         if (band2) { B.list_b_count = lc.list + 1; B.list_b = lc.list + 16 + lc.list_cap; B.list_b_cap = B.list_cap; }
+        // list C (k_invert_band -> k_invert_blocks): the finite pixels the band rule is not for.  XSW_NO_BLOCKS_KERNEL=1: they stay on
+        // list G, i.e. with k_invert_list (A/B measurements and the tests of that route)
+        static const bool blocks_kernel_off = getenv("XSW_NO_BLOCKS_KERNEL") != nullptr;
+        const bool blocks3 = c->T.blk != nullptr && c->T.blk_span_ok && !bitonic2 && !blocks_kernel_off && c->T.n_w < 32768 && c->T.n_phi < 32768;
+        if (blocks3) { B.list_c_count = lc.list + 2; B.list_c = lc.list + 16 + 2 * lc.list_cap; B.list_c_cap = B.list_cap; }
         B.long_run = long_run_env;
         static const int area_max_env = getenv("XSW_B2_AREA") ? std::max(1, atoi(getenv("XSW_B2_AREA"))) : XSW_B2_AREA;
         B.area_max = c->T.blk ? area_max_env : 0x7fffffff;  // (without the block tables the general kernel has nothing better to offer)
@@ -64,7 +70,7 @@ static int launch_invert(xsw_ctx *c, const KArgs &A_in, int algo, const LaunchCt
             B.mask_g = lc.masks; B.mask_b = lc.masks + nstrips;  // side by side: one reset (0.25 B per pixel)
             if (hipMemsetAsync(lc.masks, 0, 2 * nstrips * sizeof(unsigned long long), lc.stream) != hipSuccess) return seterr(err, XSW_EHIP, "strip-mask reset failed");
         }
-        if (hipMemsetAsync(lc.list, 0, 2 * sizeof(unsigned), lc.stream) != hipSuccess) return seterr(err, XSW_EHIP, "work-list reset failed");
+        if (hipMemsetAsync(lc.list, 0, 3 * sizeof(unsigned), lc.stream) != hipSuccess) return seterr(err, XSW_EHIP, "work-list reset failed");
         const unsigned list_blocks = (unsigned)std::min<long long>(nblocks, 256 * 8);  // 8 waves per SIMD
         // k_invert_band: x = XCD lane + 8 * line group, y = tile column inside the XCD's range (see the kernel)
         const long long cols_per_xcd = (strips_per_line + 7) / 8;
@@ -93,6 +99,12 @@ static int launch_invert(xsw_ctx *c, const KArgs &A_in, int algo, const LaunchCt
                 if (mono) hipLaunchKernelGGL((k_invert_band2<T, TO, false, false>), b2_grid, band_block, 0, lc.stream, c->T, B);
                 else hipLaunchKernelGGL((k_invert_band2<T, TO, true, false>), b2_grid, band_block, 0, lc.stream, c->T, B);
             }
+        }
+        if (lc.timing) timing_mark(c);
+        if (blocks3) {
+            const dim3 bl_grid((unsigned)std::min<long long>(nblocks, 256 * XSW_BLOCKS_WAVES));
+            if (mono) hipLaunchKernelGGL((k_invert_blocks<T, TO, false>), bl_grid, dim3(256), 0, lc.stream, c->T, B);
+            else hipLaunchKernelGGL((k_invert_blocks<T, TO, true>), bl_grid, dim3(256), 0, lc.stream, c->T, B);
         }
         if (lc.timing) timing_mark(c);
 #ifdef XSW_LIST_CLOCK  // experiments: k_invert_list alone counts into the statistics buffer (xsw_stats_read), see the kernel
