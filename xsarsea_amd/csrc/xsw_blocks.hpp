@@ -24,7 +24,7 @@
 namespace xsw {
 
 #ifndef XSW_SEGQ_CAP
-#define XSW_SEGQ_CAP 128  // kept blocks a segment may queue per round (8192 candidates); more: the pixel is left to k_invert_list
+#define XSW_SEGQ_CAP 64  // kept blocks a segment queues before they are swept (and the bound tightened)
 #endif
 #ifndef XSW_SEG_DIRECT
 #define XSW_SEG_DIRECT 96  // windows of at most this many blocks are bounded block by block, without the band level
@@ -105,7 +105,6 @@ __device__ __forceinline__ void co_seg16_pass(const DevTables &L, double inv_dsi
     double best = inf, second = inf;
     int bflat = 0;
     int qn = 0;
-    bool ovf = false;
 
     // level 1, one lane per band (band tb_lo + 16 j + sl): the segment's most promising band (mask = false), or the set of bands
     // the current bound keeps (mask = true), as a bit mask relative to tb_lo
@@ -155,30 +154,31 @@ __device__ __forceinline__ void co_seg16_pass(const DevTables &L, double inv_dsi
         curA = max((tb_lo + t) * G, br_lo);
         curN = (min(min((tb_lo + t + 1) * G, L.nbr), br_hi + 1) - curA) * ncb;
     };
-    // bounds the blocks of the segment's current band, then of the bands left in `bands`, 16 per step; the kept ones are queued
-    auto bound_blocks = [&](int curA, int curN, unsigned long long bands) {
-        int k0 = 0;
-        while (ballot64(k0 < curN) != 0ULL) {
+    // bounds the blocks of the segment's current band [curA.., curN blocks, from block k0 on), then of the bands left in `bands`, 16
+    // per step; the kept ones are queued.  A segment whose queue is nearly full pauses (its position is kept): the queues are
+    // swept, the bound tightens, and bound_blocks is called again.
+    int curA = br_lo, curN = 0, k0 = 0;
+    unsigned long long bands = 0ULL;
+    auto bound_blocks = [&]() {
+        while (ballot64(k0 < curN && qn <= CAP - 16) != 0ULL) {
+            const bool go = k0 < curN && qn <= CAP - 16;
             const int idx = k0 + sl;
-            const bool bv = idx < curN;
+            const bool bv = go && idx < curN;
             const int dr = bv ? (int)(((float)idx + 0.5f) * inv_ncb) : 0, dc = bv ? idx - dr * ncb : 0;
             const int br = curA + dr, bc = bc_lo + dc;
             const float2 mm = blk[bv ? br * L.nbc + bc : 0];
             const double lb = block_lb(L, mm, br, bc, s, ainv, ah, bh, m2, mh, tol, wh0, whs);
             const bool keep = bv && !(lb * (1.0 - 1e-8) > jub + slack);
             const unsigned kb = seg_bits(ballot64(keep), q);
-            const int at = qn + __popc(kb & ((1u << sl) - 1u));
-            if (keep && at < CAP) {
+            if (keep) {
                 SegQEntry e;
                 e.brbc = br | (bc << 16);
                 e.lb = __double2float_rd(lb);
-                qseg[at] = e;
+                qseg[qn + __popc(kb & ((1u << sl) - 1u))] = e;
             }
-            const int nq = qn + __popc(kb);
-            ovf = ovf || nq > CAP;
-            qn = min(nq, CAP);
-            k0 += 16;
-            if (k0 >= curN && bands != 0ULL) {  // the segment's next band
+            qn += __popc(kb);
+            k0 += go ? 16 : 0;
+            while (go && k0 >= curN && bands != 0ULL) {  // the segment's next band
                 const int t = __ffsll((long long)bands) - 1;
                 bands &= bands - 1;
                 band_range(t, curA, curN);
@@ -208,19 +208,23 @@ __device__ __forceinline__ void co_seg16_pass(const DevTables &L, double inv_dsi
             for (int k = 0; k < R; ++k) v[k] = ld_co(base, off0, min(row0 + k, L.n_w - 1), rowB);
             const double2 cs = ((const double2 *)L.csphi)[dirc];
             const double U = 2.0 * (ah * cs.x + bh * cs.y);
-            const int flat0 = row0 * L.n_phi + dirc;
+            int flat = row0 * L.n_phi + dirc;
+            double wh = fma((double)row0, whs, wh0);
+            const double snl = okd ? sn : 1e150;  // a lane without a candidate scores ~1e300: never the minimum, never within eps of it
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                const double wh = fma((double)(row0 + k), whs, wh0);
-                const double dd = fma(v[k], inv_dsig, sn);
-                double J = fma(dd, dd, wh * (wh - U));
-                J = (okd && row0 + k < L.n_w) ? J : inf;
+                const double dd = fma(v[k], inv_dsig, (row0 + k < L.n_w) ? snl : 1e150);
+                const double J = fma(dd, dd, wh * (wh - U));
                 second = vmin(second, vmax(J, best));
-                bflat = J < best ? flat0 + k * L.n_phi : bflat;
+                bflat = J < best ? flat : bflat;
                 best = vmin(best, J);
+                wh += whs;
+                flat += L.n_phi;
             }
-            const double g = seg_min_d<16>(best);
-            jub = (g < 1e300) ? fmin(jub, (g + m2) * (1.0 + 1e-9) + 1e-9) : jub;
+            if ((j & 1) != 0 || j + 1 >= jmax) {  // every other block: the bound follows the segment's running minimum
+                const double g = seg_min_d<16>(best);
+                jub = (g < 1e290) ? fmin(jub, (g + m2) * (1.0 + 1e-9) + 1e-9) : jub;
+            }
             cand += (unsigned)__popcll(am) * 4u;
         }
         qn = 0;
@@ -228,32 +232,38 @@ __device__ __forceinline__ void co_seg16_pass(const DevTables &L, double inv_dsi
     };
 
     // round 1: the most promising band (large windows), or the whole window
-    int first = -1, curA = br_lo, curN = (valid && !bandmode) ? nbw : 0;
-    unsigned long long bands = 0ULL;
+    int first = -1;
+    curN = (valid && !bandmode) ? nbw : 0;
     if (nj > 0) {
         level1(false, first, bands);
+        bands = 0ULL;
         if (bandmode && !bad && first >= 0) band_range(first, curA, curN);
     }
-    bound_blocks(curA, curN, 0ULL);
-    sweep_queue();
+    do {
+        bound_blocks();
+        sweep_queue();
+    } while (ballot64(k0 < curN) != 0ULL);
     if (nj > 0) {  // round 2: the bands the tightened bound keeps
         int dummy;
         level1(true, dummy, bands);
         if (first >= 0) bands &= ~(1ULL << first);
         curN = 0;
+        k0 = 0;
         if (bands != 0ULL) {
             const int t = __ffsll((long long)bands) - 1;
             bands &= bands - 1;
             band_range(t, curA, curN);
         }
-        bound_blocks(curA, curN, bands);
-        sweep_queue();
+        do {
+            bound_blocks();
+            sweep_queue();
+        } while (ballot64(k0 < curN) != 0ULL);
     }
 
     // settle, per segment
     const double gmin = seg_min_d<16>(best);
     const double T = gmin + 1e-9 * (1.0 + fabs(gmin) + m2);
-    const unsigned long long amb = ballot64(valid && (second <= T || ovf || bad || !(gmin < 1e300))), surv = ballot64(valid && best <= T);
+    const unsigned long long amb = ballot64(valid && (second <= T || bad || !(gmin < 1e290))), surv = ballot64(valid && best <= T);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (o[k] < 0) continue;
@@ -291,7 +301,21 @@ __device__ __forceinline__ void blocks_wave(const DevTables &L, const KArgs &A, 
             const int rows = W.w_lo | (W.w_hi << 16), dirs = (int)((unsigned)W.ip_lo | ((unsigned)W.ip_hi << 16));
             // (a bound so loose that its float32 square root overflowed: band_d = inf -- the wave-wide search handles it)
             if (!(W.band_d < 1e300)) pend &= ~__ballot(fin && !(W.band_d < 1e300));
-            while (pend) co_seg16_pass(L, A.inv_dsig_co, lane, P.s_co, P.a_re, P.b_eff, W.band_d, P.i_inc, rows, dirs, pend, qlds, my_flat, redo, cand);
+            // the four pixels of a pass wait for the slowest of them: pixels of similar cost share a pass -- they are taken in the
+            // order of their window size (blocks), by classes of powers of two
+            const int nbw_p = ((W.w_hi >> 2) - (W.w_lo >> 2) + 1) * ((W.ip_hi >> 4) - (W.ip_lo >> 4) + 1);
+            const int cls = 31 - __clz(max(nbw_p, 1));
+#pragma unroll 1
+            for (int c = 15; c >= 0 && pend; --c) {
+                unsigned long long m = pend & __ballot(c == 15 ? cls >= 15 : cls == c);
+                if (c > 0 && __popcll(m) < 4 && (pend & ~m)) {  // a part-filled pass: filled up from the next class
+                    const unsigned long long nxt = pend & __ballot(cls == c - 1);
+                    unsigned long long take = nxt;
+                    for (int k = __popcll(m); k < 4 && take; ++k) { m |= take & (0ULL - take); take &= take - 1; }
+                }
+                pend &= ~m;
+                while (m) co_seg16_pass(L, A.inv_dsig_co, lane, P.s_co, P.a_re, P.b_eff, W.band_d, P.i_inc, rows, dirs, m, qlds, my_flat, redo, cand);
+            }
         }
     }
     wave_tail<T, TO, CR, false>(L, A, i, in, lane, flags, my_flat, false, false, -1, cand);
