@@ -421,12 +421,14 @@ def hard_scene_figures(ctx, _lib, stream, device, samples, algo, lines_hs=4000):
         run()
         st = ctx.stats()
         ctx.stats_enable(False)
-        ms = (tm["first_kernel_ms"] + tm["second_kernel_ms"] + tm["band2_kernel_ms"]) / max(tm["launches"], 1)
+        ms = (tm["first_kernel_ms"] + tm["second_kernel_ms"] + tm["band2_kernel_ms"] + tm["blocks_kernel_ms"]) / max(tm["launches"], 1)
         out[key] = {"scene": what, "pixels": lines_hs * samples, "value": round(lines_hs * samples / ms / 1e3, 1), "unit": "Mpixels/s",
                     "k_invert_band_ms": round(tm["first_kernel_ms"] / max(tm["launches"], 1), 2),
                     "k_invert_band2_ms": round(tm["band2_kernel_ms"] / max(tm["launches"], 1), 2),
+                    "k_invert_blocks_ms": round(tm["blocks_kernel_ms"] / max(tm["launches"], 1), 2),
                     "k_invert_list_ms": round(tm["second_kernel_ms"] / max(tm["launches"], 1), 2),
                     "pixels_to_band2_frac": round(tm["last_band2_pixels"] / (lines_hs * samples), 5),
+                    "pixels_to_blocks_frac": round(tm["last_blocks_pixels"] / (lines_hs * samples), 5),
                     "pixels_left_to_the_list_frac": round(tm["last_list_pixels"] / (lines_hs * samples), 5),
                     "evaluated_candidates_per_pixel": round(st["cand_co"] / max(st["pixels_co"], 1), 1),
                     "pixels_exact_fallback": int(st["pixels_exact"])}
@@ -734,7 +736,7 @@ def main():
     ctx.timing_enable(False)
     if tm["launches"]:  # two-kernel path: the dominant kernel is k_invert_band; per STEP = summed over the step's row chunks
         kernel_ms = tm["first_kernel_ms"] / args.steps
-        second_ms = (tm["second_kernel_ms"] + tm.get("band2_kernel_ms", 0.0)) / args.steps  # k_invert_band2 + k_invert_list
+        second_ms = (tm["second_kernel_ms"] + tm.get("band2_kernel_ms", 0.0) + tm.get("blocks_kernel_ms", 0.0)) / args.steps  # k_invert_band2 + k_invert_blocks + k_invert_list
     else:
         kernel_ms, second_ms = step_kernels_ms, None
     if world > 1:
@@ -834,7 +836,7 @@ def main():
         # the dominant kernel reads every pixel's inputs and writes the pixels it decides itself (the ones it hands to
         # k_invert_band2 / k_invert_list are written there); the chain as a whole moves bytes_px per pixel
         read_px = BYTES_READ_PX if mode == "mono" else 24
-        handed = (tm.get("last_band2_pixels", 0) + tm.get("last_list_pixels", 0)) if second_ms is not None else 0
+        handed = (tm.get("last_band2_pixels", 0) + tm.get("last_blocks_pixels", 0) + tm.get("last_list_pixels", 0)) if second_ms is not None else 0
         achieved = (read_px * lines * samples + (bytes_px - read_px) * (lines * samples - handed)) / (kernel_ms * 1e-3) / 1e9  # rank 0's tile / rank 0's kernel time
         chain_ms = kernel_ms + (second_ms or 0.0)
         chain_ms_max = kernel_ms_max + (second_ms or 0.0)
@@ -905,18 +907,20 @@ def main():
                          "kernel_ms": round(kernel_ms, 3), "bytes_per_pixel": bytes_px,
                          "second_kernel": None if second_ms is None else dict(
                              {"kernel": "k_invert_list", "kernel_ms": round(second_ms, 3), "pixels_last_launch": tm.get("last_list_pixels")},
-                             **({"kernel": "k_invert_band2 + k_invert_list", "k_invert_band2_ms": round(tm.get("band2_kernel_ms", 0.0) / args.steps, 3),
+                             **({"kernel": "k_invert_band2 + k_invert_blocks + k_invert_list", "k_invert_band2_ms": round(tm.get("band2_kernel_ms", 0.0) / args.steps, 3),
+                                 "k_invert_blocks_ms": round(tm.get("blocks_kernel_ms", 0.0) / args.steps, 3),
                                  "k_invert_list_ms": round(tm["second_kernel_ms"] / args.steps, 3),
-                                 "pixels_to_band2_last_launch": tm.get("last_band2_pixels")} if tm.get("band2_kernel_ms", 0.0) > 0.0 else {})),
-                         "chain": {"kernels": "k_invert_band + k_invert_band2 + k_invert_list" if second_ms is not None else "k_invert",
+                                 "pixels_to_band2_last_launch": tm.get("last_band2_pixels"),
+                                 "pixels_to_blocks_last_launch": tm.get("last_blocks_pixels")} if tm.get("band2_kernel_ms", 0.0) > 0.0 else {})),
+                         "chain": {"kernels": "k_invert_band + k_invert_band2 + k_invert_blocks + k_invert_list" if second_ms is not None else "k_invert",
                                    "ms": round(chain_ms, 3), "achieved": round(bytes_px * lines * samples / (chain_ms * 1e-3) / 1e9, 3),
                                    "frac": round(bytes_px * lines * samples / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
                                    "traffic": chain_traffic},
                          "step_kernels_ms": round(step_kernels_ms, 3),
                          "note": f"algorithmic raster bytes ({read_px} B read per pixel x rank 0's {lines * samples} px + {bytes_px - read_px} B written per "
-                                 "pixel the kernel decides itself, i.e. not handed to k_invert_band2 / k_invert_list) / mean "
+                                 "pixel the kernel decides itself, i.e. not handed to k_invert_band2 / k_invert_blocks / k_invert_list) / mean "
                                  "duration of the dominant kernel per step (HIP events on the launch stream, recorded by the library around each kernel); "
-                                 "chain: all bytes of the step / the three kernels' time; "
+                                 "chain: all bytes of the step / the four kernels' time; "
                                  "the search itself is bound by VALU issue and the texture-address path, not by HBM: see valu",
                          "valu": valu},
             "lut": timings,

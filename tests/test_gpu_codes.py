@@ -194,27 +194,28 @@ ctx.invert_raw(256, 1024, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, t[0].data
 tm = ctx.timing()
 ex = ctx.invert_host(inc, sigma0_co=s_vv, anc=anc, algo="exact", out_dtype=np.complex64)
 same = np.array_equal(out.cpu().numpy().view(np.int32), ex[0].view(np.int32))
-print("RESULT", tm["launches"], tm["last_list_pixels"], tm["last_band2_pixels"], int(same))
+print("RESULT", tm["launches"], tm["last_list_pixels"], tm["last_band2_pixels"], int(same), tm["last_blocks_pixels"])
 """
 
 
 @pytest.mark.parametrize("route", ["overflow", "alloc_failure"])
 def test_work_list_overflow_and_allocation_failure(route):
-    """A scene that leaves more pixels undecided than the capped work lists hold (capacity shrunk to 100 here; an eighth of
+    """A scene that leaves more pixels undecided than the capped work lists hold (capacity shrunk to 40 here; an eighth of
     the raster in production): the consumers take their list and then the pixels marked in the strip masks.  A work list that cannot be allocated (XSW_FAIL_LIST_ALLOC=1) selects the one-kernel path
     instead of an error.  Either way the winds equal XSW_ALGO_EXACT's, bit for bit.  (Fresh process: the switches are read once.)"""
     env = dict(os.environ)
     if route == "alloc_failure":
         env["XSW_FAIL_LIST_ALLOC"] = "1"
     else:
-        env["XSW_LIST_CAP_TEST"] = "100"  # both work lists (to k_invert_band2 and to k_invert_list) hold 100 pixels
+        env["XSW_LIST_CAP_TEST"] = "40"  # the three work lists (to k_invert_band2, k_invert_blocks and k_invert_list) hold 40 pixels
     r = subprocess.run([sys.executable, "-c", _OVERFLOW_SCRIPT.format(repo=REPO)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split()
-    launches, listed, handed, same = (int(x) for x in line[1:])
+    launches, listed, handed, same, to_blocks = (int(x) for x in line[1:])
     assert same == 1, "winds differ from the exact kernel"
     if route == "overflow":
-        assert launches == 1 and listed > 100 and handed > 100, (listed, handed)  # both counters ran past the capacity
+        # every counter ran past the capacity (what does not fit on list C goes on k_invert_list's list, and on its strip mask from there)
+        assert launches == 1 and listed > 40 and handed > 40 and to_blocks > 40, (listed, handed, to_blocks)
     else:
         assert launches == 0  # no two-kernel launch took place
 

@@ -664,7 +664,7 @@ for scale, inc_lo, inc_hi in ((1.0, 17.0, 25.0), (1.6, 20.0, 36.0), (2.5, 30.0, 
     ex = ctx.invert_host(inc, sigma0_co=s_vv, anc=anc, algo="exhaustive", out_dtype=np.complex64)
     got = out.cpu().numpy()
     diff = int(np.sum(got.view(np.int32) != ex[0].view(np.int32)))
-    print("RESULT", scale, diff, tm["launches"], tm["last_band2_pixels"], tm["last_list_pixels"])
+    print("RESULT", scale, diff, tm["launches"], tm["last_band2_pixels"], tm["last_list_pixels"] + tm["last_blocks_pixels"])  # (left to k_invert_blocks / k_invert_list)
 """
 
 
