@@ -631,10 +631,10 @@ static void ensure_list(xsw_ctx *c, long long n, long long lines)
     c->d_masks = nullptr;
     c->list_cap = c->mask_strips = 0;
     static const bool no_list = getenv("XSW_FAIL_LIST_ALLOC") != nullptr;  // tests: the allocation-failure route
-    // lists G, B and C, then the two strip masks (0.25 B per pixel)
-    if (!no_list && hipMalloc((void **)&c->d_list, (3 * want + 16) * sizeof(unsigned) + 2 * want_strips * sizeof(unsigned long long)) == hipSuccess) {
+    // lists G and B (`want` entries each) and C (XSW_LIST_C_SHARE x want), then the two strip masks (0.25 B per pixel)
+    if (!no_list && hipMalloc((void **)&c->d_list, (XSW_LISTS_TOTAL * want + 16) * sizeof(unsigned) + 2 * want_strips * sizeof(unsigned long long)) == hipSuccess) {
         c->list_cap = want;
-        c->d_masks = (unsigned long long *)(c->d_list + 16 + 3 * want);
+        c->d_masks = (unsigned long long *)(c->d_list + 16 + XSW_LISTS_TOTAL * want);
         c->mask_strips = want_strips;
     } else { c->d_list = nullptr; (void)hipGetLastError(); }
 }
@@ -932,7 +932,7 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
                  o_cc = o_anc + (a->anc ? pad(max_px * es * 2) : 0), o_ccr = o_cc + (want_co ? pad(max_px * 4) : 0),
                  o_end = o_ccr + (want_cr ? pad(max_px * 4) : 0);
     const size_t list_cap = std::max<size_t>(max_px / 4, 1 << 14) & ~(size_t)1, mask_strips = strips_for((long long)max_px, lines_per_chunk);
-    const size_t o_masks = o_end + pad((3 * list_cap + 16) * sizeof(unsigned)), dev_bytes = o_masks + 2 * mask_strips * sizeof(unsigned long long);  // lists G, B and C, strip masks
+    const size_t o_masks = o_end + pad((XSW_LISTS_TOTAL * list_cap + 16) * sizeof(unsigned)), dev_bytes = o_masks + 2 * mask_strips * sizeof(unsigned long long);  // lists G, B and C, strip masks
     const int dtype = a->dtype, out_dtype = a->out_dtype;
     static const bool prof = getenv("XSW_HOST_PROFILE") != nullptr;  // phase times of the pipeline on stderr (experiments)
     std::atomic<long long> t_stage{0}, t_gpu{0}, t_expand{0}, t_reserve{0};

@@ -80,6 +80,14 @@ struct LaunchCtl {
 };
 
 
+// Work lists of one launch, side by side in one allocation: [0..15] counters, then list G (k_invert_list) and list B
+// (k_invert_band2) of LaunchCtl::list_cap entries each, then list C (k_invert_blocks) of XSW_LIST_C_SHARE times as many: on the
+// scenes whose a-priori wind is far from the sigma0 contour HALF the pixels are the block kernel's.
+#ifndef XSW_LIST_C_SHARE
+#define XSW_LIST_C_SHARE 4
+#endif
+#define XSW_LISTS_TOTAL (2 + XSW_LIST_C_SHARE)
+
 // One (input dtype, output dtype) pair of the inversion launches per translation unit (xsw_invert_tu.hip, -DXSW_PAIR=0..3:
 // f32->f32, f32->f64, f64->f32, f64->f64), so that the four sets of kernel instantiations compile side by side.
 int xsw_launch_invert_ff(xsw_ctx *c, const xsw::KArgs &A, int algo, const LaunchCtl &lc, std::string &err);

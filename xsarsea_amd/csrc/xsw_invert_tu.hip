@@ -14,7 +14,7 @@
 using namespace xsw;
 
 #ifndef XSW_B2_AREA
-#define XSW_B2_AREA 8192  // measured (profiles/sweep_b2_area.sh, Mpx/s at 1e6 / 8192 / 4096 / 2048): outliers 5 % 695 / 2063 / 2151 / 2252, a-priori x 0.3 422 / 441 / 495 / 304, x 2.5 406 / 407 / 356 / 223
+#define XSW_B2_AREA 2048  // measured with list C at half the raster (profiles/sweep_b2_area.sh, Mpx/s at 1e6 / 8192 / 4096 / 2048 / 1024 / 512): outliers 5 % 727 / 2486 / 2675 / 2711 / 2624 / 2694, a-priori x 0.3 424 / 440 / 512 / 591 / 643 / 620, x 2.5 460 / 459 / 480 / 520 / 508 / 489, x 0.6 1148 / 1147 / 1161 / 1176 / 1128 / 910
 #endif
 #ifndef XSW_BLOCK_MIN
 #define XSW_BLOCK_MIN 1024
@@ -57,7 +57,7 @@ static int launch_invert(xsw_ctx *c, const KArgs &A_in, int algo, const LaunchCt
         // list G, i.e. with k_invert_list (A/B measurements and the tests of that route)
         static const bool blocks_kernel_off = getenv("XSW_NO_BLOCKS_KERNEL") != nullptr;
         const bool blocks3 = c->T.blk != nullptr && c->T.blk_span_ok && !bitonic2 && !blocks_kernel_off && c->T.n_w < 32768 && c->T.n_phi < 32768;
-        if (blocks3) { B.list_c_count = lc.list + 2; B.list_c = lc.list + 16 + 2 * lc.list_cap; B.list_c_cap = B.list_cap; }
+        if (blocks3) { B.list_c_count = lc.list + 2; B.list_c = lc.list + 16 + 2 * lc.list_cap; B.list_c_cap = (unsigned)std::min<size_t>(XSW_LIST_C_SHARE * lc.list_cap, 0xfffffff0u); }
         B.long_run = long_run_env;
         static const int area_max_env = getenv("XSW_B2_AREA") ? std::max(1, atoi(getenv("XSW_B2_AREA"))) : XSW_B2_AREA;
         B.area_max = c->T.blk ? area_max_env : 0x7fffffff;  // (without the block tables the general kernel has nothing better to offer)
