@@ -195,7 +195,11 @@ int xsw_expand_codes(xsw_ctx *ctx, int64_t n, int32_t mem, int32_t out_dtype, co
 /* Page-locked host memory for rasters a caller fills itself (XSW_MEM_HOST_PINNED); freed by xsw_host_free or with the context. */
 int xsw_host_alloc(xsw_ctx *ctx, size_t bytes, void **out);
 int xsw_host_free(xsw_ctx *ctx, void *p);
-/* Host worker threads of the XSW_MEM_HOST paths (0 = default: XSW_HOST_THREADS or 12; at most 32). */
+/* Host worker threads of the XSW_MEM_HOST paths (0 = default: XSW_HOST_THREADS or 12; at most 32).  Every worker keeps one
+ * page-locked staging buffer and one device buffer of a chunk between calls (~2 Mpx: 40 MB each for float32 mono rasters,
+ * ~110 MB for float64 dual-pol), so a context holds up to threads x chunk of pinned host memory; after every host-memory call
+ * what exceeds XSW_STAGING_KEEP_MB (environment, default 512 MB per context) is released again, and lowering the thread count
+ * frees the workers that are no longer used at once. */
 int xsw_set_host_threads(xsw_ctx *ctx, int n);
 
 /* Enable (1) / disable (0) device-side work counters; read them after synchronising. */

@@ -208,6 +208,34 @@ def _tiled_edge_worker(rank, world, port, ret):
             ok = ok and rank == 1 and "boom" in str(e)
         except RuntimeError as e:
             ok = ok and rank != 1 and "another rank" in str(e)
+        # gather=False: every rank keeps its own lines (what a dask consumer of row blocks does): (l0, l1, its tile's result)
+        l0, l1, mine = multi_gpu.invert_from_model_tiled(inc_row, s_co, ancillary_wind=anc, model="m", invert=fake, gather=False)
+        ok = ok and (l0, l1) == multi_gpu.tile_bounds(n, world, rank) and np.array_equal(mine, fake(inc_row, s_co[l0:l1], ancillary_wind=anc[l0:l1]))
+        # a device-resident (torch) ancillary wind is looked at where it lives; an all-NaN one is "no valid ancillary wind" on every rank
+        seen_flag = {}
+
+        def flagged(i, a, /, ancillary_wind=None, model=None):
+            return a.astype(np.complex128)
+
+        out2 = multi_gpu.invert_from_model_tiled(inc_row, s_co, ancillary_wind=torch.from_numpy(anc), model="m", invert=flagged)
+        ok = ok and ((rank == 0 and out2.shape == (n, n)) or (rank != 0 and out2 is None))
+
+        # a rank that fails BEFORE its inversion (cutting its tile) does not leave the others in a collective either
+        class Bad:
+            shape, ndim = (n, n), 2
+
+            def __getitem__(self, k):
+                if dist.get_rank() == 1:
+                    raise IndexError("cannot cut on rank 1")
+                return s_co[k]
+
+        try:
+            multi_gpu.invert_from_model_tiled(inc_row, s_co, ancillary_wind=Bad(), model="m", invert=fake)
+            ok = False
+        except IndexError as e:
+            ok = ok and rank == 1 and "cannot cut" in str(e)
+        except RuntimeError as e:
+            ok = ok and rank != 1 and "another rank failed while cutting" in str(e)
         ret[f"ok{rank}"] = bool(ok)
     finally:
         dist.destroy_process_group()

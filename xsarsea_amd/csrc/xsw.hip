@@ -141,10 +141,49 @@ extern "C" int xsw_use_own_stream(xsw_ctx *c)
     return xsw_set_stream(c, (void *)c->own_stream);
 }
 
+static int host_thread_count(const xsw_ctx *c);
+static void worker_release(xsw_ctx::Worker &w)
+{
+    if (w.s) (void)hipStreamSynchronize(w.s);
+    if (w.pin) (void)hipHostFree(w.pin);
+    if (w.dev) (void)hipFree(w.dev);
+    w.pin = w.dev = nullptr;
+    w.pin_cap = w.dev_cap = 0;
+}
+
+// Staging kept between calls: each worker of the host-memory paths owns a page-locked buffer and a device buffer of one chunk
+// (float32 mono: ~40 MB each; float64 dual-pol: ~110 MB each), i.e. up to threads x chunk of pinned host memory per context.
+// After every host-memory call the buffers beyond XSW_STAGING_KEEP_MB (default 512 MB of pinned memory per context; the same
+// amount of device memory) are released, largest first -- a later call pins them again (a few ms each).
+static void trim_staging(xsw_ctx *c)
+{
+    static const size_t keep = (size_t)(getenv("XSW_STAGING_KEEP_MB") ? std::max(0LL, atoll(getenv("XSW_STAGING_KEEP_MB"))) : 512) << 20;
+    size_t total = 0;
+    for (auto &w : c->workers) total += w.pin_cap;
+    while (total > keep) {
+        xsw_ctx::Worker *big = nullptr;
+        for (auto &w : c->workers)
+            if (w.pin_cap && (!big || w.pin_cap > big->pin_cap)) big = &w;
+        if (!big) break;
+        total -= big->pin_cap;
+        worker_release(*big);
+    }
+}
+
 extern "C" int xsw_set_host_threads(xsw_ctx *c, int n)
 {
     if (!c || n < 0) return XSW_EINVAL;
     c->host_threads = n > 32 ? 32 : n;
+    // workers the new count no longer uses give their staging back now
+    const size_t keep_workers = (size_t)host_thread_count(c);
+    if (c->workers.size() > keep_workers) {
+        (void)hipSetDevice(c->device);
+        for (size_t k = keep_workers; k < c->workers.size(); ++k) {
+            worker_release(c->workers[k]);
+            if (c->workers[k].s) (void)hipStreamDestroy(c->workers[k].s);
+        }
+        c->workers.resize(keep_workers);
+    }
     return XSW_OK;
 }
 
@@ -998,6 +1037,7 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
         if (prof) { const auto t4 = now(); t_reserve += us(t0, t1); t_stage += us(t1, t2); t_gpu += us(t2, t3); t_expand += us(t3, t4); }
         return XSW_OK;
     });
+    trim_staging(c);
     if (prof)
         fprintf(stderr, "[xsw host] %lld px, %lld chunks, %d threads: wall %.2f ms; summed over workers: reserve %.2f, stage %.2f, upload+kernels+download %.2f, expand %.2f ms\n",
                 n, nchunks, (int)std::min<long long>(host_thread_count(c), nchunks), us(t_begin, now()) / 1e3, t_reserve / 1e3, t_stage / 1e3, t_gpu / 1e3, t_expand / 1e3);
@@ -1294,7 +1334,7 @@ extern "C" int xsw_detrend(xsw_ctx *c, int64_t lines, int64_t samples, int32_t d
     const long long nchunks = (lines + lpc - 1) / lpc;
     const size_t max_px = (size_t)std::min<long long>(lpc, lines) * samples;
     const size_t o_out = ((size_t)max_px * es + 255) & ~(size_t)255, total = o_out + max_px * os;
-    return run_chunks(c, nchunks, [&](long long k, xsw_ctx::Worker &w, std::string &err) -> int {
+    const int rc_det = run_chunks(c, nchunks, [&](long long k, xsw_ctx::Worker &w, std::string &err) -> int {
         int rc = worker_reserve(w, pinned ? 0 : total, total, err);
         if (rc) return rc;
         const long long l0 = k * lpc, l1 = std::min((long long)lines, l0 + lpc);
@@ -1311,6 +1351,8 @@ extern "C" int xsw_detrend(xsw_ctx *c, int64_t lines, int64_t samples, int32_t d
         if (!pinned) memcpy(dst, w.pin + o_out, npx * os);
         return XSW_OK;
     });
+    trim_staging(c);
+    return rc_det;
 }
 
 // ---------------------------------------------------------------------------------------- cross-pol noise flattening
@@ -1419,6 +1461,7 @@ extern "C" int xsw_nesz_flatten(xsw_ctx *c, int64_t lines, int64_t samples, int3
         if (e != hipSuccess) rc = fail(c, XSW_EHIP, "nesz_flatten failed: %s", hipGetErrorString(e));
     }
     if (!rc) rc = move_through_workers(c, out, d_out, (size_t)n * 8, false, pinned);
+    trim_staging(c);
     if (c->arena_cap > XSW_ARENA_KEEP) {  // do not sit on a huge staging area
         (void)hipFree(c->arena);
         c->arena = nullptr;

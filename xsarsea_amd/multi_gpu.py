@@ -112,7 +112,7 @@ def gather_rows(tile, lines, dst=0, group=None, out=None):
     return out if rank == dst else None
 
 
-def invert_from_model_tiled(inc, sigma0, sigma0_dual=None, /, *, dst=0, group=None, invert=None, **kwargs):
+def invert_from_model_tiled(inc, sigma0, sigma0_dual=None, /, *, dst=0, group=None, invert=None, gather=True, **kwargs):
     """`windspeed.invert_from_model` on a raster tiled over the ranks of a `torch.distributed` job (one process per GPU;
     the reference's way to parallelise the same call is dask row blocks, windspeed/windspeed.py:350-364).  (Inside ONE process,
     `xsarsea_amd.options.devices = "all"` spreads the same row tiles over the GPUs without any exchange.)
@@ -126,10 +126,14 @@ def invert_from_model_tiled(inc, sigma0, sigma0_dual=None, /, *, dst=0, group=No
     tuple of two for dual-pol) for the full raster on rank `dst`, None on the other ranks.  Without an initialised process
     group it is the plain call.
 
+    gather=False: no exchange at all -- every rank returns `(l0, l1, result)`, its own lines' result with the return conventions
+    of `invert_from_model` (what a dask consumer of row blocks does with them: write its block, reduce it, hand it on).
+
     Whole-raster preconditions are whole-raster: the reference's "co-pol inversion needs a valid ancillary wind" assertion
     (windspeed.py:107) holds when ANY rank's tile has a valid ancillary value (one flag all-reduced); a tile that is all NaN
-    (land) or empty (fewer lines than ranks) yields NaN / no rows instead of raising.  A rank whose inversion fails does not
-    leave the others waiting in the gather: an error flag is all-reduced first and every rank raises.
+    (land) or empty (fewer lines than ranks) yields NaN / no rows instead of raising.  A rank that fails -- while cutting its
+    tile, or in its inversion -- does not leave the others waiting in a collective: every step that can raise runs inside a
+    `try`, its error flag is all-reduced before the next collective, and every rank raises.
     `invert`: the per-tile callable (default `windspeed.invert_from_model`; tests on machines without a GPU pass a stand-in).
     """
     import numpy as np
@@ -138,40 +142,64 @@ def invert_from_model_tiled(inc, sigma0, sigma0_dual=None, /, *, dst=0, group=No
     if default_invert:
         from .windspeed import invert_from_model as invert
     if not (dist.is_available() and dist.is_initialized()):
-        return invert(inc, sigma0, *(() if sigma0_dual is None else (sigma0_dual,)), **kwargs)
+        res = invert(inc, sigma0, *(() if sigma0_dual is None else (sigma0_dual,)), **kwargs)
+        return res if gather else (0, int(np.shape(sigma0)[0]) if np.ndim(sigma0) else 0, res)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    lines = int(np.shape(sigma0)[0])
-    ndim = np.ndim(sigma0)
-    l0, l1 = tile_bounds(lines, world, rank)
-
-    def cut(a):
-        is_raster = a is not None and not np.isscalar(a) and np.ndim(a) == ndim and np.shape(a)[0] == lines
-        return a[l0:l1] if is_raster else a
-
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    kw = {k: (cut(v) if k in ("ancillary_wind", "dsig_cr") else v) for k, v in kwargs.items()}
-    anc_tile = kw.get("ancillary_wind")
-    # the ancillary-wind precondition, once for the whole raster: does ANY tile hold a valid value?
-    valid_here = bool(anc_tile is not None and np.size(anc_tile) and np.any(~np.isnan(np.asarray(anc_tile))))
-    flag = torch.tensor([1 if valid_here else 0], dtype=torch.int32, device=dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-    any_valid_ancillary = bool(flag.item())
-    res, failure = None, None
+
+    def agree(*flags):
+        """MAX-all-reduce of small integer flags: the one collective between the steps"""
+        t = torch.tensor([int(f) for f in flags], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return [int(x) for x in t.tolist()]
+
+    def has_valid(a):
+        if a is None:
+            return False
+        if torch.is_tensor(a):  # device-resident ancillary wind: decided where it lives
+            return bool(a.numel()) and bool((~torch.isnan(torch.view_as_real(a) if a.is_complex() else a)).any().item())
+        return bool(np.size(a)) and bool(np.any(~np.isnan(np.asarray(a))))
+
+    # step 1: cut the tile, look at its ancillary wind
+    failure, l0, l1, tile, kw, valid_here = None, 0, 0, None, {}, False
+    try:
+        lines = int(np.shape(sigma0)[0])
+        ndim = np.ndim(sigma0)
+        l0, l1 = tile_bounds(lines, world, rank)
+
+        def cut(a):
+            is_raster = a is not None and not np.isscalar(a) and np.ndim(a) == ndim and np.shape(a)[0] == lines
+            return a[l0:l1] if is_raster else a
+
+        kw = {k: (cut(v) if k in ("ancillary_wind", "dsig_cr") else v) for k, v in kwargs.items()}
+        tile = (cut(inc), cut(sigma0)) + (() if sigma0_dual is None else (cut(sigma0_dual),))
+        valid_here = has_valid(kw.get("ancillary_wind"))
+    except Exception as exc:  # reported to every rank, then re-raised here
+        failure = exc
+    any_valid_ancillary, failed = agree(valid_here, failure is not None)
+    if failure is not None:
+        raise failure
+    if failed:
+        raise RuntimeError("invert_from_model_tiled: another rank failed while cutting its tile (see its traceback)")
+    # step 2: the rank's inversion
+    res = None
     try:
         if default_invert:
             # the per-tile call skips the per-call ancillary assertion / warning (`_xsw_tile`): the whole-raster answer is passed in
-            kw["_xsw_tile"] = any_valid_ancillary
-            kw["_xsw_codes"] = True  # numpy rasters: the tile's answer as 4-byte grid codes (a quarter of the complex128 bytes)
-        res = invert(cut(inc), cut(sigma0), *(() if sigma0_dual is None else (cut(sigma0_dual),)), **kw)
-    except BaseException as exc:  # reported to every rank below, then re-raised here
+            kw["_xsw_tile"] = bool(any_valid_ancillary)
+            if gather:
+                kw["_xsw_codes"] = True  # numpy rasters: the tile's answer as 4-byte grid codes (a quarter of the complex128 bytes)
+        res = invert(*tile, **kw)
+    except Exception as exc:
         failure = exc
-    flag = torch.tensor([1 if failure is not None else 0], dtype=torch.int32, device=dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    (failed,) = agree(failure is not None)
     if failure is not None:
         raise failure
-    if flag.item():
+    if failed:
         raise RuntimeError("invert_from_model_tiled: the inversion failed on another rank (see its traceback); nothing was gathered")
+    if not gather:
+        return l0, l1, res
     from .windspeed.windspeed import CodedWinds
     if isinstance(res, CodedWinds):  # gather the codes, expand and apply the return conventions on `dst`
         gathered = []

@@ -15,7 +15,10 @@ devices_min_pixels = 1 << 22
 #: result dtype) or "complex64" (half the HBM bytes written).
 device_out_dtype = "complex128"
 
-#: worker threads of the host-memory paths of libxsw per context (0 = the library default: XSW_HOST_THREADS or 12)
+#: worker threads of the host-memory paths of libxsw per context (0 = the library default: XSW_HOST_THREADS or 12).  Each worker
+#: keeps a page-locked staging buffer and a device buffer of one chunk between calls (~40 MB each for float32 mono rasters, ~110 MB
+#: for float64 dual-pol): up to threads x chunk of pinned host memory per context (and per GPU with `devices`); what exceeds
+#: XSW_STAGING_KEEP_MB (environment, default 512) is released after every call, lowering `host_threads` frees the surplus workers.
 host_threads = 0
 
 #: sigma0 -> dB conversion (windspeed.py:126-130).

@@ -60,10 +60,13 @@ class DeviceLut:
         self.incidence, self.wspd, self.phi = target_axes
         self.shape = tuple(len(a) for a in target_axes if a is not None)
 
-    def build(self, ctx):
+    def check_axes(self):
         for ax in (self.incidence, self.wspd, self.phi) + tuple(self.raw_axes):
             if ax is not None and np.size(ax) > 1 and not np.all(np.diff(np.asarray(ax, dtype=np.float64)) > 0):
                 raise ValueError("device LUT build needs strictly ascending axes (the host route re-orders them: lut_build='host')")
+
+    def build(self, ctx):
+        self.check_axes()
         target = dict(inc=self.incidence, wspd=self.wspd)
         if self.phi is not None:
             target.update(phi=self.phi, **host_tables(self.wspd, self.phi))
@@ -90,19 +93,29 @@ def lut_source(model, kwargs):
 
 
 def ensure_luts(ctx, lut_co, lut_cr):
-    """Upload (or build in place) the dB LUT objects unless this context already holds exactly them."""
+    """Upload (or build in place) the dB LUT objects unless this context already holds exactly them.  `ctx.lut_key` follows the
+    context's tables step by step: a LUT is recorded the moment its install has succeeded, and a failing install leaves NO key
+    for that slot (the context's table is then undefined: the next call installs again instead of searching a stale GMF)."""
     key_co, key_cr = ctx.lut_key
     up_co = lut_co is not None and key_co is not lut_co
     up_cr = lut_cr is not None and key_cr is not lut_cr
-    for lut, up in ((lut_co, up_co), (lut_cr, up_cr)):
+    for lut, up in ((lut_co, up_co), (lut_cr, up_cr)):  # validate both before the context is touched
         if up and isinstance(lut, DeviceLut):
+            lut.check_axes()
+    for slot, (lut, up) in enumerate(((lut_co, up_co), (lut_cr, up_cr))):
+        if not up:
+            continue
+        key = list(ctx.lut_key)
+        key[slot] = None
+        ctx.lut_key = tuple(key)  # whatever happens below, the old table of this slot is gone
+        if isinstance(lut, DeviceLut):
             lut.build(ctx)
-    host_co = up_co and not isinstance(lut_co, DeviceLut)
-    host_cr = up_cr and not isinstance(lut_cr, DeviceLut)
-    if host_co or host_cr:
-        ctx.upload_luts(co=_co_dict(lut_co) if host_co else None, cr=_cr_dict(lut_cr) if host_cr else None)
-    if up_co or up_cr:
-        ctx.lut_key = (lut_co if up_co else key_co, lut_cr if up_cr else key_cr)
+        elif slot == 0:
+            ctx.upload_luts(co=_co_dict(lut))
+        else:
+            ctx.upload_luts(cr=_cr_dict(lut))
+        key[slot] = lut
+        ctx.lut_key = tuple(key)
 
 
 _BLOCK = _host.BLOCK
@@ -185,7 +198,9 @@ def _device_list():
             raise ValueError('options.devices must be None, "all" or a list of device indices')
         devs = list(range(_lib.device_count()))
     devs = [int(d) for d in devs]
-    return devs if len(devs) > 1 else None
+    if not devs:
+        raise ValueError("options.devices is an empty list")
+    return devs  # (a one-entry list runs on THAT device: a single tile)
 
 
 def tile_rows(lines, parts):
@@ -339,6 +354,15 @@ def invert_device(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_
     shape = torch.broadcast_shapes(*(t.shape for t in rasters + ([] if t_anc is None else [t_anc])))
     all_f32 = all(t.dtype == torch.float32 for t in rasters) and (t_anc is None or t_anc.dtype == torch.complex64)
     rt, ct = (torch.float32, torch.complex64) if all_f32 else (torch.float64, torch.complex128)
+    is_db = False
+    if not all_f32 and any(t is not None and t.dtype == torch.float32 for t in (t_co, t_cr)):
+        # mixed dtypes (float32 sigma0 next to a float64 incidence, say): the reference converts sigma0 to dB in sigma0's OWN dtype
+        # (windspeed.py:126-130) before anything is widened -- do that here, then hand dB rasters to the kernel
+        to_db = lambda t: None if t is None else (10 * torch.log10(t + 1e-15))
+        # a scalar dsig_cr is broadcast in sigma0_cr's dtype (windspeed.py:122-123): keep that rounding
+        if t_cr is not None and t_dsig is None and dsig_cr is not None and t_cr.dtype == torch.float32:
+            dsig_cr = float(np.float32(dsig_cr))
+        t_co, t_cr, is_db = to_db(t_co), to_db(t_cr), True
     prep = lambda t, d: None if t is None else t.to(d).expand(shape).contiguous()
     t_inc, t_co, t_cr, t_dsig, t_anc = prep(t_inc, rt), prep(t_co, rt), prep(t_cr, rt), prep(t_dsig, rt), prep(t_anc, ct)
     dsig_scalar = 0.1
@@ -355,7 +379,7 @@ def invert_device(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_
             ensure_luts(ctx, lut_co if t_co is not None else None, lut_cr if t_cr is not None else None)
             ctx.invert_raw(lines, samples, _lib.XSW_F32 if all_f32 else _lib.XSW_F64,
                            _lib.XSW_F32 if odt == torch.complex64 else _lib.XSW_F64, _lib.MEM_DEVICE, p(t_inc), p(t_co), p(t_cr),
-                           p(t_dsig), p(t_anc), p(out_co), p(out_cr), None, dsig_co, dsig_scalar, False,
+                           p(t_dsig), p(t_anc), p(out_co), p(out_cr), None, dsig_co, dsig_scalar, is_db,
                            _lib.ALGOS.get(options.algo, options.algo), dual_select and out_cr is not None and out_co is not None)
             # the inputs must outlive the asynchronous launch: tie them to the stream they are read on
             for t in (t_inc, t_co, t_cr, t_dsig, t_anc):

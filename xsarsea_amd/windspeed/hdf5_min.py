@@ -214,11 +214,56 @@ def _btree2_records(buf, addr, O, L):
     return rtype, out
 
 
+class _NoDataset(KeyError):
+    """the caller asked for a name the file does not hold (not a damaged file)"""
+
+
+def _guarded(method):
+    """The parser walks offsets it reads from the file; on a damaged file (truncated, bit-flipped, zeroed spans) they lead anywhere.
+    Whatever the walk trips over -- an index past a structure, a failed unpack, a zlib stream error, a reference loop -- comes out
+    as ONE exception type naming the file, like the "not a valid NetCDF 3 file" of the classic route."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        try:
+            return method(self, *args, **kwargs)
+        except (_NoDataset, NotImplementedError):
+            raise
+        except ValueError as e:
+            raise ValueError(f"{self.path}: not a readable netCDF-4 / HDF5 LUT file: {e}") from None
+        except (IndexError, KeyError, TypeError, struct.error, zlib.error, UnicodeDecodeError, OverflowError, RecursionError,
+                MemoryError, AttributeError, ZeroDivisionError) as e:
+            raise ValueError(f"{self.path}: not a readable netCDF-4 / HDF5 LUT file (damaged?): {type(e).__name__}: {e}") from None
+    return wrapper
+
+
+def fletcher32(data):
+    """HDF5's Fletcher-32 of a byte string (H5checksum.c: big-endian 16-bit words, end-around carry; an odd last byte is the high
+    byte of one more word).  Checked against the checksums h5py wrote into tests/golden/nc4/*fletcher*."""
+    n = len(data) // 2
+    w = np.frombuffer(data, ">u2", n).astype(np.uint64)
+    s1 = int(w.sum())
+    s2 = int((w * np.arange(n, 0, -1, dtype=np.uint64)).sum())
+    if len(data) % 2:
+        s1 += data[-1] << 8
+        s2 += s1
+
+    def fold(x):
+        while x >> 16:
+            x = (x & 0xFFFF) + (x >> 16)
+        return x
+    return (fold(s2) << 16) | fold(s1)
+
+
 class File:
     """`File(path)`: `.attrs` (global attributes), `.names()` (datasets of the root group), `.read(name)` -> ndarray,
-    `.dataset_attrs(name)`, `.dims(name)` -> names of the dimension scales attached to each axis (or None)."""
+    `.dataset_attrs(name)`, `.dims(name)` -> names of the dimension scales attached to each axis (or None).  A file the parser
+    cannot walk raises `ValueError` naming it (NotImplementedError for a valid file that uses a feature outside the subset)."""
 
+    @_guarded
     def __init__(self, path):
+        self.path = path
         with open(path, "rb") as f:
             self.buf = _Buf(f.read())
         b = self.buf
@@ -246,6 +291,7 @@ class File:
         if self.base not in (0, base):
             raise NotImplementedError("HDF5 file with a relocated base address")
         self._gcol = {}
+        self.undefined_fill_used = False  # a read met storage that was never written and found no fill value (zeros were returned)
         self.root = self._object(root)
         self._links = self._group_links(self.root)
         self.attrs = self._attributes(self.root)
@@ -268,8 +314,12 @@ class File:
             size0 = b.u(p, nsz); p += nsz
             blocks = [(p, size0)]
             track = bool(hflags & 4)
+            seen = set()
             while blocks:
                 start, size = blocks.pop(0)
+                if start in seen or len(seen) > 4096:
+                    raise ValueError("HDF5: object header continuation blocks form a loop")
+                seen.add(start)
                 q, end = start, start + size
                 while q + 4 + (2 if track else 0) <= end:
                     mtype, msize, mflags = b.d[q], b.u(q + 1, 2), b.d[q + 3]
@@ -469,12 +519,14 @@ class File:
 
     def _dataset(self, name):
         if name not in self._links:
-            raise KeyError(f"no dataset {name!r} in the HDF5 file (root group holds {self.names()})")
+            raise _NoDataset(f"no dataset {name!r} in the HDF5 file (root group holds {self.names()})")
         return self._object(self._links[name])
 
+    @_guarded
     def dataset_attrs(self, name):
         return self._attributes(self._dataset(name))
 
+    @_guarded
     def dims(self, name):
         """Names of the dimension scales attached to the axes of dataset `name` (netCDF-4 / h5py DIMENSION_LIST), else None."""
         dl = self.dataset_attrs(name).get("DIMENSION_LIST")
@@ -487,6 +539,7 @@ class File:
             out.append(by_addr.get(int(refs[0])) if len(refs) else None)
         return tuple(out)
 
+    @_guarded
     def read(self, name):
         b, O, L = self.buf, self.O, self.L
         obj = self._dataset(name)
@@ -506,8 +559,8 @@ class File:
                 return np.frombuffer(bytes(b.d[lo + 4:lo + 4 + size]), dt.dtype, n).astype(native).reshape(shape)
             if cls == 1:
                 addr = b.u(lo + 2, O)
-                if addr == UNDEF:
-                    return np.zeros(shape, native)
+                if addr == UNDEF:  # never written: the fill value, as HDF5 / netCDF return it
+                    return np.full(shape, self._fill_value(obj, dt), native)
                 return np.frombuffer(b.bytes(addr, n * dt.size), dt.dtype, n).astype(native).reshape(shape)
             if cls == 2:
                 rank1 = b.d[lo + 2]
@@ -518,6 +571,36 @@ class File:
             raise NotImplementedError("HDF5 data layout version 4 chunk indexes (file written with libver >= 1.10 bounds): "
                                       "netCDF-4 writers keep the 1.8-compatible layout; rewrite the file or use the netCDF-3 form")
         raise NotImplementedError(f"HDF5 data layout message version {ver}")
+
+    def _fill_value(self, obj, dt):
+        """What unallocated storage of a dataset reads as: the fill value message (0x05; the old 0x04), else the netCDF `_FillValue`
+        attribute, else -- no value defined -- HDF5's default, zeros, with `self.undefined_fill_used` set: 0.0 is a plausible dB
+        value, so the LUT reader (nc_io.read_lut) refuses a table that needed it rather than search a silently corrupted one."""
+        b = self.buf
+        raw = None
+        m = self._msg(obj, 0x05)
+        if m:
+            p, ver = m[0], b.d[m[0]]
+            if ver in (1, 2):
+                defined = b.d[p + 3] if ver == 2 else 1
+                if defined and m[1] >= 8:
+                    size = b.u(p + 4, 4)
+                    raw = bytes(b.bytes(p + 8, size)) if size else None
+            elif ver == 3 and (b.d[p + 1] & 0x20):
+                size = b.u(p + 2, 4)
+                raw = bytes(b.bytes(p + 6, size)) if size else None
+        if raw is None:
+            m = self._msg(obj, 0x04)
+            if m:
+                size = b.u(m[0], 4)
+                raw = bytes(b.bytes(m[0] + 4, size)) if size else None
+        if raw is not None and len(raw) == dt.size:
+            return np.frombuffer(raw, dt.dtype, 1)[0]
+        fv = self._attributes(obj).get("_FillValue")
+        if fv is not None and np.size(fv) == 1:
+            return np.asarray(fv).reshape(-1)[0].astype(dt.dtype)
+        self.undefined_fill_used = True  # HDF5's default: zeros (what h5py returns); `read_lut` refuses such a table
+        return 0
 
     def _filters(self, obj):
         m = self._msg(obj, 0x0B)
@@ -544,7 +627,8 @@ class File:
     def _read_chunked(self, obj, dt, shape, chunk, btree):
         b, O = self.buf, self.O
         filters = self._filters(obj)
-        out = np.zeros(shape, dt.dtype)
+        out = np.empty(shape, dt.dtype)
+        written = np.zeros(shape, bool)
         rank = len(shape)
         csize = int(np.prod(chunk, dtype=np.int64)) * dt.size
 
@@ -562,15 +646,15 @@ class File:
                 else:
                     yield (b.u(key, 4), b.u(key + 4, 4), tuple(b.u(key + 8 + 8 * d, 8) for d in range(rank)), child)
 
-        if btree == UNDEF:
-            return out
-        for nbytes, mask, offs, addr in leafs(btree):
+        for nbytes, mask, offs, addr in (leafs(btree) if btree != UNDEF else ()):
             raw = bytes(b.bytes(addr, nbytes))
             for k in range(len(filters) - 1, -1, -1):
                 if mask & (1 << k):
                     continue
                 fid, cd = filters[k]
-                if fid == 3:      # fletcher32: checksum appended
+                if fid == 3:      # fletcher32: checksum appended (little-endian), over everything before it
+                    if len(raw) < 4 or fletcher32(raw[:-4]) != int.from_bytes(raw[-4:], "little"):
+                        raise ValueError("HDF5: Fletcher-32 checksum of a chunk does not match (damaged file)")
                     raw = raw[:-4]
                 elif fid == 1:    # deflate
                     raw = zlib.decompress(raw)
@@ -584,4 +668,7 @@ class File:
             block = np.frombuffer(raw, dt.dtype).reshape(chunk)
             sl = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, chunk, shape))
             out[sl] = block[tuple(slice(0, s.stop - s.start) for s in sl)]
+            written[sl] = True
+        if not written.all():  # chunks that were never written hold the fill value
+            out[~written] = self._fill_value(obj, dt)
         return out

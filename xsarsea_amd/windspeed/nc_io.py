@@ -71,6 +71,9 @@ def _read_lut_hdf5(path):
     if dims not in (DIMS2, DIMS3):
         raise IndexError(f"Bad dims '{dims}'. Should be '{DIMS2}' or '{DIMS3}'")
     axes = {d: np.asarray(f.read(d), dtype=np.float64) for d in dims}
+    if f.undefined_fill_used:
+        raise ValueError(f"{path}: part of the table (or of an axis) was never written and the file defines no fill value for it: "
+                         "HDF5 would read zeros there, a plausible dB value -- refusing to search a table with holes")
     fill = f.dataset_attrs("sigma0_model").get("_FillValue")
     if fill is not None:  # xarray's mask_and_scale: _FillValue -> NaN (a no-op for the NaN fill xarray itself writes)
         fv = np.asarray(fill, dtype=np.float64).reshape(-1)[0]
