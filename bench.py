@@ -383,6 +383,40 @@ def host_path_figure(inc, s_vv, anc, samples, lines_host=5000):
     return fig
 
 
+def host_path_all_devices_figure(inc, s_vv, anc, samples, n_dev, lines_per_dev=2500):
+    """N > 1 line: the drop-in call on HOST rasters with `xsarsea_amd.options.devices` = every GPU of the node, from ONE process
+    (rank 0; the other ranks wait at the barrier): row tiles, one context and one host thread per GPU, no exchange.  Weak
+    scaling by construction -- every GPU has its own PCIe link -- until the host's memory bandwidth runs out."""
+    import warnings
+    import xsarsea_amd
+    from xsarsea_amd import windspeed
+    one_dev = os.environ.get("XSW_BENCH_ONE_DEVICE") == "1"
+    reps = -(-lines_per_dev * n_dev // inc.shape[0])
+    h_inc, h_s, h_anc = (np.concatenate([t.contiguous().cpu().numpy()] * reps)[:lines_per_dev * n_dev] for t in (inc, s_vv, anc))
+    px = h_inc.size
+    prev = xsarsea_amd.options.devices
+    xsarsea_amd.options.devices = [0] * n_dev if one_dev else list(range(n_dev))
+    try:
+        times = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = None
+            for _ in range(4):
+                del res
+                t0 = time.perf_counter()
+                res = windspeed.invert_from_model(h_inc, h_s, ancillary_wind=h_anc, model="gmf_cmod5n")
+                times.append(time.perf_counter() - t0)
+        best = min(times[1:])
+        return {"workload": f"windspeed.invert_from_model(numpy float32 {h_inc.shape[0]}x{samples} -> numpy complex128), options.devices = {n_dev} GPUs, one process",
+                "value": round(px / best / 1e6, 1), "unit": "Mpixels/s", "ms": round(best * 1e3, 2), "first_call_ms": round(times[0] * 1e3, 1),
+                "pcie_GBps_per_device": round(20 * px / n_dev / best / 1e9, 2),
+                "note": "16 B/px up + 4 B/px of grid codes down per GPU link; unmeasured on a multi-GPU node before this run"}
+    except Exception as exc:  # a figure of the line, never a reason to lose the line
+        return {"error": f"{type(exc).__name__}: {exc}"}
+    finally:
+        xsarsea_amd.options.devices = prev
+
+
 def hard_scene_figures(ctx, _lib, stream, device, samples, algo, lines_hs=4000):
     """The benchmark scene is the friendly case for an exact branch-and-bound: its a-priori wind is the truth + 1.5 m/s, so the
     bound is tight and ~50 of 90 319 candidates are scored.  Three scenes where it is not, on a 4000-line band through the
@@ -679,12 +713,38 @@ def main():
     stream_aware = backend == "nccl"  # RCCL orders a transfer after the work queued on the current stream; gloo (the one-GPU
     # rehearsal) reads and writes the tensors' memory from the host with no regard for streams: synchronise around it
 
+    # Rank 0 expands chunk k of every rank's tile as soon as that chunk's codes are there -- on a side stream that waits for the
+    # chunk's receives (peers) and for the chunk's own kernels (rank 0's rows), through xsw_expand_codes_on_stream -- while the
+    # launch stream goes on inverting chunk k + 1: only the last chunk's expansion is exposed at the end of the step.
+    side = torch.cuda.Stream(device=device) if coded and rank == 0 else None
+    chunk_reqs = {}
+
     def start_gather(k):
         if not stream_aware:
             torch.cuda.synchronize()
-        pending.extend(multi_gpu.gather_chunk_async(codes, total_lines, k, n_chunks, dst=0, out=full_codes, self_copy=False))
+        reqs = multi_gpu.gather_chunk_async(codes, total_lines, k, n_chunks, dst=0, out=full_codes, self_copy=False)
         if mode == "dual":
-            pending.extend(multi_gpu.gather_chunk_async(codes_dual, total_lines, k, n_chunks, dst=0, out=full_codes_dual, self_copy=False))
+            reqs += multi_gpu.gather_chunk_async(codes_dual, total_lines, k, n_chunks, dst=0, out=full_codes_dual, self_copy=False)
+        chunk_reqs[k] = reqs
+        pending.extend(reqs)
+
+    def expand_chunk(k, own_done):
+        """rank 0: codes of chunk k (of every rank's tile) -> complex64, on the side stream"""
+        with torch.cuda.stream(side):
+            side.wait_event(own_done)      # rank 0's own rows of the chunk
+            for q in chunk_reqs.pop(k, []):
+                q.wait()                   # RCCL: the CURRENT (side) stream waits for the transfer; gloo: the host does
+            if not stream_aware:
+                torch.cuda.synchronize()
+            for r in range(world):
+                t0, t1 = multi_gpu.tile_bounds(total_lines, world, r)
+                c0, c1 = multi_gpu.chunk_bounds(t1 - t0, n_chunks, k)
+                if c1 <= c0:
+                    continue
+                off = (t0 + c0) * samples
+                ctx.expand_codes_on_stream(side.cuda_stream, (c1 - c0) * samples, _lib.XSW_F32, full_codes.data_ptr() + off * 4,
+                                           full_codes_dual.data_ptr() + off * 4 if mode == "dual" else None, full.data_ptr() + off * 8,
+                                           full_dual.data_ptr() + off * 8 if mode == "dual" else None)
 
     def step(gathering=True):
         for k in range(n_chunks):
@@ -693,16 +753,22 @@ def main():
                 invert_rows(r0, r1, as_codes=coded and gathering)
             if coded and gathering:
                 start_gather(k)
+                if rank == 0:
+                    ev_k = torch.cuda.Event()
+                    ev_k.record(stream)
+                    expand_chunk(k, ev_k)
 
     def gather():
-        while pending:  # the single exchange of the path, started chunk by chunk inside step()
-            pending.pop().wait()
+        while pending:  # the single exchange of the path, started chunk by chunk inside step(); rank 0 has queued the waits already
+            q = pending.pop()
+            if rank != 0 or not coded:
+                q.wait()
         if not stream_aware:
             torch.cuda.synchronize()
-        if coded and rank == 0:  # codes -> complex64, the raster a single-GPU run would have written
-            ctx.expand_codes_raw(total_lines * samples, _lib.MEM_DEVICE, _lib.XSW_F32, full_codes.data_ptr(),
-                                 full_codes_dual.data_ptr() if mode == "dual" else None, full.data_ptr(),
-                                 full_dual.data_ptr() if mode == "dual" else None)
+        if coded and rank == 0:  # the launch stream continues once the last chunk is expanded
+            done = torch.cuda.Event()
+            done.record(side)
+            stream.wait_event(done)
 
     def fence():
         torch.cuda.synchronize()
@@ -758,6 +824,7 @@ def main():
         for _ in range(args.steps):
             for k in range(n_chunks):
                 start_gather(k)
+            chunk_reqs.clear()
             while pending:
                 pending.pop().wait()
         g1.record(stream)
@@ -971,6 +1038,13 @@ def main():
             res["parity"] = parity
         if mg is not None:
             res["multi_gpu"] = mg
+            # the same job with the outputs left where they are computed (what a dask consumer of row blocks does; the API's
+            # invert_from_model_tiled(..., gather=False)): no exchange -- the second top-level figure of an N > 1 line
+            res["value_no_gather"] = dict(mg["no_gather"], n_gpus=n_gpus)
+            if mode == "mono" and not args.no_extras:
+                res["host_path_all_devices"] = host_path_all_devices_figure(inc, s_vv, anc, samples, n_gpus)
+            res["multi_gpu"]["hardware_note"] = ("first hardware numbers of the N > 1 path come from the driver's scaling run: no multi-GPU node was available to the build "
+                                                 "(rehearsed with gloo on one device)")
         if gather_ok is not None:
             res["gather_verified"] = gather_ok
         print(json.dumps(res), flush=True)

@@ -192,6 +192,12 @@ int xsw_invert(xsw_ctx *ctx, const xsw_invert_args *args);
 int xsw_expand_codes(xsw_ctx *ctx, int64_t n, int32_t mem, int32_t out_dtype, const uint32_t *code_co,
                      const uint32_t *code_cr, void *out_co, void *out_cr);
 
+/* XSW_VERSION >= 3.  The device form of xsw_expand_codes on a stream of the caller's choice (a HIP stream handle), without
+ * touching the context's launch stream: a consumer that receives codes piece by piece (the row chunks of a multi-GPU gather)
+ * expands each piece on a side stream as it lands, next to the inversions still queued on the launch stream. */
+int xsw_expand_codes_on_stream(xsw_ctx *ctx, void *stream, int64_t n, int32_t out_dtype, const uint32_t *code_co,
+                               const uint32_t *code_cr, void *out_co, void *out_cr);
+
 /* Page-locked host memory for rasters a caller fills itself (XSW_MEM_HOST_PINNED); freed by xsw_host_free or with the context. */
 int xsw_host_alloc(xsw_ctx *ctx, size_t bytes, void **out);
 int xsw_host_free(xsw_ctx *ctx, void *p);

@@ -23,7 +23,7 @@ GMF_IDS = {"gmf_cmod5": 0, "gmf_cmod5n": 1, "gmf_cmod5n_pr_zhangA": 2, "gmf_cmod
 EXPORTS = (
     "xsw_version", "xsw_device_count", "xsw_ctx_create", "xsw_ctx_destroy", "xsw_last_error", "xsw_set_stream", "xsw_use_own_stream",
     "xsw_synchronize", "xsw_lut_upload", "xsw_invert", "xsw_stats_enable", "xsw_stats_read", "xsw_detrend", "xsw_lut_interp", "xsw_gmf_eval",
-    "xsw_nesz_flatten", "xsw_lut_build", "xsw_lut_read", "xsw_timing_enable", "xsw_timing_read", "xsw_expand_codes",
+    "xsw_nesz_flatten", "xsw_lut_build", "xsw_lut_read", "xsw_timing_enable", "xsw_timing_read", "xsw_expand_codes", "xsw_expand_codes_on_stream",
     "xsw_host_alloc", "xsw_host_free", "xsw_set_host_threads",
 )
 
@@ -132,6 +132,7 @@ def load():
         lib.xsw_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.xsw_timing_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(Timing)]
         lib.xsw_expand_codes.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 4
+        lib.xsw_expand_codes_on_stream.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32] + [ctypes.c_void_p] * 4
         lib.xsw_host_alloc.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
         lib.xsw_host_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.xsw_set_host_threads.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -344,6 +345,12 @@ class Context:
     def expand_codes_raw(self, n, mem, out_dtype, code_co, code_cr, out_co, out_cr):
         """Thin call of xsw_expand_codes (pointers are ints or None): grid codes -> the complex winds xsw_invert stores."""
         self._check(self._lib.xsw_expand_codes(self._h, int(n), mem, out_dtype, code_co, code_cr, out_co, out_cr), "xsw_expand_codes")
+
+    def expand_codes_on_stream(self, stream, n, out_dtype, code_co, code_cr, out_co, out_cr):
+        """xsw_expand_codes_on_stream: device codes -> device winds on `stream` (a HIP stream handle as an int), the context's
+        launch stream untouched."""
+        self._check(self._lib.xsw_expand_codes_on_stream(self._h, ctypes.c_void_p(int(stream)), int(n), out_dtype, code_co, code_cr, out_co, out_cr),
+                    "xsw_expand_codes_on_stream")
 
     def expand_codes_host(self, codes_co, codes_cr, out_dtype=np.complex128):
         """Grid codes (uint32 arrays of one shape; either may be None) -> (ws_co, ws_cr) on the host, block-wise on the host

@@ -777,10 +777,26 @@ static int check_codes_tables(xsw_ctx *c, const uint32_t *code_co, const uint32_
     return XSW_OK;
 }
 
+static int expand_codes_on(xsw_ctx *c, hipStream_t stream, int64_t n, int32_t mem, int32_t out_dtype, const uint32_t *code_co,
+                           const uint32_t *code_cr, void *out_co, void *out_cr);
+
 extern "C" int xsw_expand_codes(xsw_ctx *c, int64_t n, int32_t mem, int32_t out_dtype, const uint32_t *code_co,
                                 const uint32_t *code_cr, void *out_co, void *out_cr)
 {
     if (!c) return XSW_EINVAL;
+    return expand_codes_on(c, c->stream, n, mem, out_dtype, code_co, code_cr, out_co, out_cr);
+}
+
+extern "C" int xsw_expand_codes_on_stream(xsw_ctx *c, void *stream, int64_t n, int32_t out_dtype, const uint32_t *code_co,
+                                          const uint32_t *code_cr, void *out_co, void *out_cr)
+{
+    if (!c) return XSW_EINVAL;
+    return expand_codes_on(c, (hipStream_t)stream, n, XSW_MEM_DEVICE, out_dtype, code_co, code_cr, out_co, out_cr);
+}
+
+static int expand_codes_on(xsw_ctx *c, hipStream_t stream, int64_t n, int32_t mem, int32_t out_dtype, const uint32_t *code_co,
+                           const uint32_t *code_cr, void *out_co, void *out_cr)
+{
     if (n < 0 || (!code_co && !code_cr)) return fail(c, XSW_EINVAL, "expand_codes: no codes");
     if (out_dtype != XSW_F32 && out_dtype != XSW_F64) return fail(c, XSW_EINVAL, "out_dtype must be XSW_F32 or XSW_F64");
     if ((out_co && !code_co) || (out_cr && !code_cr)) return fail(c, XSW_EINVAL, "expand_codes: an output without its codes");
@@ -792,10 +808,10 @@ extern "C" int xsw_expand_codes(xsw_ctx *c, int64_t n, int32_t mem, int32_t out_
         const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, 256 * 16);
         const long long plane = (long long)c->T.n_w * c->T.n_phi;
         if (out_dtype == XSW_F32)
-            hipLaunchKernelGGL((k_expand<float>), dim3(blocks), dim3(256), 0, c->stream, c->T.sol, c->T.dual_dir, c->T.wcr, plane, c->have_cr ? c->T.n_wcr : 0, (long long)n, code_co,
+            hipLaunchKernelGGL((k_expand<float>), dim3(blocks), dim3(256), 0, stream, c->T.sol, c->T.dual_dir, c->T.wcr, plane, c->have_cr ? c->T.n_wcr : 0, (long long)n, code_co,
                                code_cr, (Cx<float>::type *)out_co, (Cx<float>::type *)out_cr);
         else
-            hipLaunchKernelGGL((k_expand<double>), dim3(blocks), dim3(256), 0, c->stream, c->T.sol, c->T.dual_dir, c->T.wcr, plane, c->have_cr ? c->T.n_wcr : 0, (long long)n, code_co,
+            hipLaunchKernelGGL((k_expand<double>), dim3(blocks), dim3(256), 0, stream, c->T.sol, c->T.dual_dir, c->T.wcr, plane, c->have_cr ? c->T.n_wcr : 0, (long long)n, code_co,
                                code_cr, (Cx<double>::type *)out_co, (Cx<double>::type *)out_cr);
         HIPCHK(c, hipGetLastError());
         return XSW_OK;
