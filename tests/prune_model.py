@@ -284,56 +284,6 @@ def band_rows_from_table(inv, b_lo, b_hi, w_lo, w_hi):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Rise-then-fall columns (round 3, k_invert_band2).  A column that is non-decreasing on rows [0, P) and non-increasing on
-# rows [P - 1, n_w) (P = first row lower than its predecessor) cuts the band {r: s - d <= col[r] <= s + d} into at most TWO row
-# intervals, one per branch.  Both are read off inverse tables over ONE threshold grid t_b = b * width + t0 spanning the whole
-# slice, b = 0 .. bins - 1, plus a row `bins` that stands for +inf (xsw_lutbuild.hpp: k_peak_rows / k_inv_rows2):
-#   up[b] = first r < P with col[r] >= t_b (else P);   up[0] = 0;    up[bins] = P
-#   dn[b] = first r >= P with col[r] <  t_b (else n_w); dn[0] = n_w;  dn[bins] = P
-# With b_lo = the largest bin whose threshold is <= s - d (0 also stands for anything below the grid) and b_hi = the smallest
-# bin whose threshold is > s + d (`bins` when there is none):
-#   rising rows  [max(up[b_lo], w_lo), min(up[b_hi] - 1, w_hi)]       falling rows  [max(dn[b_hi], w_lo), min(dn[b_lo] - 1, w_hi)]
-def peak_row(col):
-    """(P, ok): first row lower than its predecessor (len(col) if none); ok = never rises again from there on."""
-    n = len(col)
-    dec = np.nonzero(col[1:] < col[:-1])[0]
-    if dec.size == 0:
-        return n, True
-    P = int(dec[0]) + 1
-    return P, bool(np.all(col[P:] <= col[P - 1:-1]))
-
-
-def bitonic_tables(col, t0, width, bins):
-    """(up, dn) of one column, bins + 1 entries each: numpy restatement of k_inv_rows2."""
-    n = len(col)
-    P, _ = peak_row(col)
-    up, dn = np.zeros(bins + 1, dtype=np.int64), np.zeros(bins + 1, dtype=np.int64)
-    r = 0
-    for b in range(1, bins):
-        thr = b * width + t0
-        while r < P and col[r] < thr:
-            r += 1
-        up[b] = r
-    up[bins] = dn[bins] = P
-    r = P
-    for b in range(bins - 1, 0, -1):
-        thr = b * width + t0
-        while r < n and not (col[r] < thr):
-            r += 1
-        dn[b] = r
-    dn[0] = n
-    return up, dn
-
-
-def bitonic_band_rows(up, dn, b_lo, b_hi, bins, w_lo, w_hi):
-    """((first, last) rising, (first, last) falling) as co_band_pass<BITONIC> clips them (last < first: none)."""
-    bh = b_hi if b_hi >= 0 else bins
-    rise = (max(int(up[b_lo]), w_lo), min(int(up[bh]) - 1, w_hi))
-    fall = (max(int(dn[bh]), w_lo), min(int(dn[b_lo]) - 1, w_hi))
-    return rise, fall
-
-
-# ---------------------------------------------------------------------------------------------------------------------
 # Chord clip (round 3, k_invert_band2): the window is only the bounding box of the disc |c - m| <= 2 sqrt(J_ub).  Along one
 # direction e (unit vector), with U = m . e and wh = w / 2:  |w e - m|^2 / 4 = wh^2 - U wh + |m|^2/4 <= J_ub
 #   <=>  |wh - U/2| <= sqrt(U^2/4 - |m|^2/4 + J_ub):  the rows of that direction that can hold the argmin are one interval.

@@ -249,7 +249,7 @@ def test_two_kernel_path_bookkeeping(gpu_ctx, default_luts):
     assert tm["launches"] == 1 and tm["first_kernel_ms"] > 0 and tm["second_kernel_ms"] >= 0
     valid = int(np.sum(~np.isnan(inc) & ~np.isnan(s_vv)))
     assert st["pixels_co"] == valid, (st, valid)
-    assert 0 <= tm["last_list_pixels"] < 0.05 * n, tm
+    assert 0 <= tm["last_list_pixels"] < 0.005 * n, tm  # (a broken segment reduction once left 2.5 % undecided: results stayed exact, the chain 30 % slower)
     assert 16 < st["cand_co"] / valid < 400  # a few dozen candidates per pixel, not the 90 319 of the grid
     ex = gpu_ctx.invert_host(inc, sigma0_co=s_vv, anc=anc, algo="exact", out_dtype=np.complex64)
     assert np.array_equal(out.cpu().numpy().view(np.int32), ex[0].view(np.int32))
@@ -680,7 +680,7 @@ def test_long_run_kernel(long_run, list_cap):
     import subprocess
     import sys
     from conftest import REPO
-    env = {k: v for k, v in os.environ.items() if k not in ("XSW_LONG_RUN", "XSW_BAND2", "XSW_NO_STRIP_MASKS")}
+    env = {k: v for k, v in os.environ.items() if k not in ("XSW_LONG_RUN", "XSW_NO_STRIP_MASKS")}
     if long_run is not None:
         env["XSW_LONG_RUN"] = long_run
     if list_cap:
@@ -700,30 +700,6 @@ def test_long_run_kernel(long_run, list_cap):
         assert any(int(r_[4]) > 0 for r_ in rows), "no pixel was handed to k_invert_band2"
 
 
-@pytest.mark.parametrize("list_cap", [None, "300", "300-nomask"])
-def test_band2_rise_then_fall_columns(list_cap):
-    """XSW_BAND2=1 (opt-in, fresh process: read at LUT install): windows that leave the monotone rows of the LUT (high winds at
-    near-range incidences, where CMOD5.N saturates and turns over; a-priori winds far above the truth) are handed to
-    k_invert_band2, which applies the band rule to both branches of the rise-then-fall columns.  The three-kernel chain returns
-    the bits of the LDS-tiled exhaustive sweep (an independent kernel) on every pixel, k_invert_band2 really takes pixels, and
-    with list capacities of 300 pixels both overflow routes run (k_invert_band2 walks every strip, k_invert_list every tile)."""
-    import subprocess
-    import sys
-    from conftest import REPO
-    env = dict({k: v for k, v in os.environ.items() if k != "XSW_NO_STRIP_MASKS"}, XSW_BAND2="1")
-    if list_cap:
-        env["XSW_LIST_CAP_TEST"] = list_cap.split("-")[0]
-        if list_cap.endswith("nomask"):
-            env["XSW_NO_STRIP_MASKS"] = "1"
-    r = subprocess.run([sys.executable, "-c", _BAND2_SCRIPT.format(repo=REPO)], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    rows = [l.split() for l in r.stdout.splitlines() if l.startswith("RESULT")]
-    assert len(rows) == 4
-    for _, scale, diff, launches, b2, _listed in rows:
-        assert int(diff) == 0, f"scale {scale}: {diff} values differ from the exhaustive sweep"
-        assert int(launches) == 1 and (float(scale) < 1.0 or int(b2) > 0)
-
-
 def test_tail_cut_keeps_saturating_windows_in_the_band_kernels():
     """Round 3: a window that reaches past the monotone rows of its slice stays with the band rule when no LUT value up there can
     be in the band (L.tail_min, tests/prune_model.py: tail_cut), and otherwise keeps it on its monotone part while
@@ -735,7 +711,7 @@ def test_tail_cut_keeps_saturating_windows_in_the_band_kernels():
     from conftest import REPO
     listed = {}
     for mode in ("both", "cut", "none"):
-        env = {k: v for k, v in os.environ.items() if k not in ("XSW_LONG_RUN", "XSW_BAND2", "XSW_NO_TAIL_CUT", "XSW_LIST_CAP_TEST", "XSW_TAIL_SWEEP")}
+        env = {k: v for k, v in os.environ.items() if k not in ("XSW_LONG_RUN", "XSW_NO_TAIL_CUT", "XSW_LIST_CAP_TEST", "XSW_TAIL_SWEEP")}
         if mode != "both":
             env["XSW_TAIL_SWEEP"] = "0"
         if mode == "none":

@@ -380,10 +380,9 @@ static int install_co(xsw_ctx *c, const xsw_lut *l, const double *d_dense)
         static const bool tail_off = getenv("XSW_NO_TAIL_CUT") != nullptr;  // A/B measurements only
         if (e == hipSuccess && !tail_off) {
             double *d_tail = nullptr;
-            static const int tail_global = getenv("XSW_TAIL_GLOBAL") != nullptr ? 1 : 0;  // A/B: one minimum per slice
             if (hipMalloc((void **)&d_tail, (size_t)nI * (XSW_TAIL_LEVELS + 1) * ppad * sizeof(double) + 64) == hipSuccess) {
                 c->co_allocs.push_back(d_tail);
-                hipLaunchKernelGGL(k_tail_min, dim3((unsigned)nI), dim3(256), 0, c->stream, d_dense, nW, nP, (int)ppad, d_mono, d_tail, tail_global);
+                hipLaunchKernelGGL(k_tail_min, dim3((unsigned)nI), dim3(256), 0, c->stream, d_dense, nW, nP, (int)ppad, d_mono, d_tail);
                 if (hipGetLastError() == hipSuccess) T.tail_min = d_tail;
             } else (void)hipGetLastError();
         }
@@ -424,37 +423,6 @@ static int install_co(xsw_ctx *c, const xsw_lut *l, const double *d_dense)
             }
             if (e2 == hipSuccess) { T.blk = d_blk; T.bandmm = d_band; }
             else (void)hipGetLastError();
-        }
-        // the same for columns that rise and then fall (k_invert_band2; 755 MB at the default size).  OFF unless XSW_BAND2=1:
-        // measured in round 3, the windows that leave the monotone rows sit on the flat top of the saturating GMF, where a
-        // band of +-d dB is tens of rows long -- the rule prunes little there and k_invert_band2 hands most of its pixels on
-        // to the general kernel anyway.  Kept as a tested, exact route for LUTs with steep falling branches.
-        T.inv2 = nullptr; T.inv_grid2 = nullptr; T.bitonic_ok = nullptr;
-        static const bool band2_on = getenv("XSW_BAND2") != nullptr && atoi(getenv("XSW_BAND2")) != 0;
-        const size_t inv2_n = (size_t)nI * 2 * (XSW_INV_BINS + 1) * ppad;
-        if (e == hipSuccess && T.inv_rows && band2_on && inv2_n * sizeof(unsigned short) < ((size_t)1 << 32)) {
-            unsigned short *d_inv2 = nullptr, *d_peak = nullptr;
-            double *d_grid2 = nullptr;
-            int *d_ok = nullptr;
-            hipError_t e2 = hipMalloc((void **)&d_inv2, inv2_n * sizeof(unsigned short) + 64);
-            if (e2 == hipSuccess) { c->co_allocs.push_back(d_inv2); e2 = hipMalloc((void **)&d_grid2, (size_t)3 * nI * sizeof(double) + 64); }
-            if (e2 == hipSuccess) { c->co_allocs.push_back(d_grid2); e2 = hipMalloc((void **)&d_ok, (size_t)nI * sizeof(int) + 64); }
-            if (e2 == hipSuccess) { c->co_allocs.push_back(d_ok); e2 = hipMalloc((void **)&d_peak, (size_t)nI * nP * sizeof(unsigned short) + 64); }
-            if (e2 == hipSuccess) {
-                c->co_allocs.push_back(d_peak);
-                std::vector<int> ones((size_t)nI, 1);
-                e2 = hipMemcpy(d_ok, ones.data(), (size_t)nI * sizeof(int), hipMemcpyHostToDevice);
-            }
-            if (e2 == hipSuccess) e2 = hipMemsetAsync(d_inv2, 0, inv2_n * sizeof(unsigned short), c->stream);
-            if (e2 == hipSuccess) {
-                const unsigned nb = (unsigned)(((long long)nI * nP + 255) / 256);
-                hipLaunchKernelGGL(k_peak_rows, dim3(nb), dim3(256), 0, c->stream, d_dense, nI, nW, nP, d_peak, d_ok);
-                hipLaunchKernelGGL(k_inv_range2, dim3((unsigned)nI), dim3(256), 0, c->stream, d_dense, nW, nP, d_grid2);
-                hipLaunchKernelGGL(k_inv_rows2, dim3(nb), dim3(256), 0, c->stream, d_dense, nI, nW, nP, ppad, d_peak, d_grid2, d_inv2);
-                e2 = hipGetLastError();
-            }
-            if (e2 == hipSuccess) { T.inv2 = d_inv2; T.inv_grid2 = d_grid2; T.bitonic_ok = d_ok; }
-            else (void)hipGetLastError();  // feature off, nothing else depends on it
         }
         if (e == hipSuccess) e = hipMemcpyAsync(h_flags, d_flags, sizeof h_flags, hipMemcpyDeviceToHost, c->stream);
         hipError_t se = hipStreamSynchronize(c->stream);

@@ -50,28 +50,10 @@ namespace xsw {
 #ifndef XSW_BAND_MAX
 #define XSW_BAND_MAX 64
 #endif
-// K directions per lane and the occupancy the kernel is compiled for.  Measured at 20000 x 20000 (band kernel alone).
-// With the per-column bisection (first half of round 2): K = 1 at 8 waves/SIMD 94.7 ms; K = 2 (adjacent directions, the second
-// seeded from the first by a walk) at 6 / 7 / 8 waves 101.0 / 101.5 / 101.9 ms.  With the inverse-row table no direction needs
-// its neighbour: K directions are taken BLOCKED (lane sl: directions sl, sl + S, ...), so every load of a segment reads
-// contiguous table / LUT words (interleaved, each load touched the same cache lines twice: 61.6 ms against 56.2 for K = 1);
-// blocked K = 1 / 2 / 3 / 4: 53.9 / 52.8 / 57.2 / 63.3 ms (K = 3, 4 spill): half the passes, the same loads.
-// Final form: K is a property of the window class (2 or 3: capacities S*K = 4, 6, 8, 12, ..., 96, 128; k_invert_band below);
-// XSW_BAND_K only names the K of the measurements above.
-#ifndef XSW_BAND_K
-#define XSW_BAND_K 2
-#endif
+// A lane owns K = 2 or 3 directions of one pixel (a property of the window class: capacities S*K = 4, 6, 8, 12, ..., 96, 128), taken
+// BLOCKED (lane sl: directions sl, sl + S, ...), so that every load of a segment reads contiguous table / LUT words.
 #ifndef XSW_BAND_RAY_D
 #define XSW_BAND_RAY_D 2
-#endif
-#ifndef XSW_BAND_NO_VCHECK
-#define XSW_BAND_NO_VCHECK 1  // k_invert_band scores the rows its tables name without comparing them with the band's thresholds
-#endif
-#ifndef XSW_BAND_NO_CLAMP
-#define XSW_BAND_NO_CLAMP 0  // (1: no clamp of the row to the window -- slower, the masked lanes then touch new cache lines: 34.1 vs 33.7 ms)
-#endif
-#ifndef XSW_BAND_HI_MASK
-#define XSW_BAND_HI_MASK 1
 #endif
 // Hand-over caps of the long-run role.  Compile-time: as runtime arguments (the A/B sweep below ran that way) they cost
 // k_invert_band 0.3 ms of 33.7 in stage 1; profiles/sweep_run_caps.sh builds its variants with -D flags instead.
@@ -114,11 +96,8 @@ namespace xsw {
 #ifndef XSW_BAND_WAVES_CR
 #define XSW_BAND_WAVES_CR 7  // the dual-pol instantiation: 8 / 7 / 6 waves per SIMD measured 59.8 / 58.3 / 58.8 ms at 20000^2 (8 spills 12-20 B per lane)
 #endif
-#ifndef XSW_BAND2_MAX
-#define XSW_BAND2_MAX 24  // k_invert_band2: rows a direction may hold before the pixel is left to the general kernel
-#endif
 #ifndef XSW_BAND2_WAVES
-#define XSW_BAND2_WAVES 4  // k_invert_band2 (two column branches per direction: more live state; at 8 waves it spills 0.5 KB per lane)
+#define XSW_BAND2_WAVES 4  // k_invert_band2: 3 / 4 / 5 / 6 / 8 waves per SIMD measured on the hard scenes -- 4 (128 VGPRs) is the best or within noise of it
 #endif
 
 struct BandSlot {  // 64 bytes per pixel, read by every lane of its segment (same address: LDS broadcast)
@@ -133,11 +112,7 @@ __device__ __forceinline__ double ld_co(const char *__restrict__ base, unsigned 
     return *(const double *)(base + (off0 + __umul24((unsigned)row, rowB)));
 }
 
-// BITONIC (k_invert_band2): the columns may rise and then fall.  A window of n directions is laid out as 2n virtual columns --
-// column c < n is the RISING part of direction c (rows below the column's first decreasing step), column n + c its FALLING part
-// -- so a lane still owns one run of rows per column: only the table (L.inv2: rising and falling inverse tables side by side,
-// XSW_INV_BINS + 1 thresholds, the last one +inf) and the order of the two threshold bins differ between the two halves.
-// CHORD: the rows of a direction are also clipped to the chord the disc |c - m| <= 2 sqrt(J_ub) cuts out of that direction's ray
+// CHORD (k_invert_band2): the rows of a direction are also clipped to the chord the disc |c - m| <= 2 sqrt(J_ub) cuts out of that direction's ray
 // (the window is only the disc's bounding box in (speed, direction): in a wide window most directions cross the band rows
 // OUTSIDE the disc, where the wind term alone already exceeds J_ub).  Along direction e, with U = m . e and wh = w / 2:
 // wh^2 - U wh + |m|^2/4 <= J_ub  <=>  |wh - U/2| <= sqrt(U^2/4 - |m|^2/4 + J_ub).  J_ub is recovered from the band's half
@@ -148,7 +123,7 @@ __device__ __forceinline__ double ld_co(const char *__restrict__ base, unsigned 
 #endif
 // k_invert_band2 only (its long-run role): in k_invert_band the clip costs more than it saves (measured with every window
 // swept there, band kernel at 20000^2: no clip 46.8 ms; segments of 64 lanes 47.2; >= 32: 48.4; >= 16: 50.6).
-template <int S, int K, bool COUNT, bool BITONIC, bool BATCH = false>
+template <int S, int K, bool COUNT, bool BATCH = false>
 __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig, int lane,
                                              const BandSlot *slots /* this wave's [64], sorted by class */, int *res /* [64], by slot */,
                                              int first, int count /* slots [first, first + count) -> segments 0 .. count-1 */, unsigned &cand)
@@ -162,10 +137,9 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
     if (!valid) { B.inc_bin = 0; B.rows = 0; B.ipn = 0; B.bin_hi = -1; }  // idle segment: harmless addresses, nothing scored
     // ROLE 2 slots carry the TAIL of the window in the upper half of bin_hi: rows w_hi + 1 .. w_hi + tail_n lie past the slice's
     // monotone rows (w_hi = the last monotone row) and are swept in full, after the band rows of the monotone part (band_wave)
-    const int tail_n = (!BITONIC && BATCH) ? (int)((unsigned)B.bin_hi >> 16) : 0;
-    if (!BITONIC && BATCH) B.bin_hi = (int)(short)(B.bin_hi & 0xffff);
+    const int tail_n = BATCH ? (int)((unsigned)B.bin_hi >> 16) : 0;
+    if (BATCH) B.bin_hi = (int)(short)(B.bin_hi & 0xffff);
     const int B_ip_lo = B.ipn & 0xffff, B_ncols = (int)((unsigned)B.ipn >> 16);
-    const int B_vcols = BITONIC ? 2 * B_ncols : B_ncols;  // virtual columns
     const int w_lo = B.rows & 0xffff, w_hi = B.rows >> 16;
     const double thr_lo = B.thr_lo, thr_hi = B.thr_hi, sn = B.sn;
     const double wh0 = 0.5 * L.w0, whs = L.wstep_half;
@@ -175,12 +149,10 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
     const unsigned slice0 = (unsigned)(i_inc * L.n_w) * rowB;
     // rows of the inverse table (2-byte entries, one per direction, < 4 GB: xsw.hip): the largest threshold <= s - d gives a
     // row at or below the band's first, the smallest threshold > s + d one past a row at or above its last
-    constexpr int NB = BITONIC ? XSW_INV_BINS + 1 : XSW_INV_BINS;  // thresholds per column table
-    const unsigned short *__restrict__ inv_tab = BITONIC ? L.inv2 : L.inv_rows;
-    const unsigned inv0 = (unsigned)(i_inc * (BITONIC ? 2 : 1) * NB + ((unsigned)B.inc_bin >> 16)) * (unsigned)L.phi_pad * 2u;
-    const unsigned inv1 = (unsigned)(i_inc * (BITONIC ? 2 : 1) * NB + max(B.bin_hi, 0)) * (unsigned)L.phi_pad * 2u;
-    const unsigned inv_fall = (unsigned)NB * (unsigned)L.phi_pad * 2u;  // BITONIC: the falling table follows the rising one
-    constexpr bool CHORD = !BITONIC && BATCH;
+    const unsigned short *__restrict__ inv_tab = L.inv_rows;
+    const unsigned inv0 = (unsigned)(i_inc * XSW_INV_BINS + ((unsigned)B.inc_bin >> 16)) * (unsigned)L.phi_pad * 2u;
+    const unsigned inv1 = (unsigned)(i_inc * XSW_INV_BINS + max(B.bin_hi, 0)) * (unsigned)L.phi_pad * 2u;
+    constexpr bool CHORD = BATCH;
     double jrel = 0.0, inv_whs = 0.0;  // J_ub - |m|^2/4 (inflated); rows per unit of wh
     if (CHORD) {
         const double rs = 0.5 * (thr_hi - thr_lo) * fabs(inv_dsig);  // >= sqrt(J_ub) (1 + 1e-6)
@@ -191,10 +163,10 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
     int brow = 0, bip = 0;
     unsigned ncand = 0;
     bool overflow = false;
-    const int nchunks = S == 64 ? (__builtin_amdgcn_readfirstlane(B_vcols) + 64 * K - 1) / (64 * K) : 1;  // S == 64: one pixel, wave-uniform
+    const int nchunks = S == 64 ? (__builtin_amdgcn_readfirstlane(B_ncols) + 64 * K - 1) / (64 * K) : 1;  // S == 64: one pixel, wave-uniform
 #pragma unroll 1
     for (int ch = 0; ch < nchunks; ++ch) {
-        bool act[K], fall[K];
+        bool act[K];
         int ip[K], r[K], nrow[K];
         int n1[K], gap[K];  // CHORD (ROLE 2): rows of the first run (band rows of the monotone part), and the jump to the tail's first row
         unsigned off0[K];
@@ -202,10 +174,8 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const int vcol = sl + S * j + S * K * ch;  // blocked: the lanes of a segment read contiguous directions in every load
-            act[j] = valid && vcol < B_vcols;
-            fall[j] = BITONIC && vcol >= B_ncols;
-            const int col = fall[j] ? vcol - B_ncols : vcol;
-            ip[j] = B_ip_lo + (act[j] ? col : 0);
+            act[j] = valid && vcol < B_ncols;
+            ip[j] = B_ip_lo + (act[j] ? vcol : 0);
             const unsigned ipB = (unsigned)ip[j] * 8u;
             const double2 cs = *(const double2 *)((const char *)L.csphi + 2u * ipB);
             U[j] = 2.0 * (B.ah * cs.x + B.bh * cs.y);
@@ -215,13 +185,11 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
         int nmax = 0;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            // rising part: rows [table(bin <= s - d), table(bin > s + d)); falling part: [table'(bin > s + d), table'(bin <= s - d))
-            const unsigned o_first = (fall[j] ? inv1 + inv_fall : inv0) + (unsigned)ip[j] * 2u;
-            const unsigned o_last = (fall[j] ? inv0 + inv_fall : inv1) + (unsigned)ip[j] * 2u;
+            const unsigned o_first = inv0 + (unsigned)ip[j] * 2u, o_last = inv1 + (unsigned)ip[j] * 2u;
             const int ra = (int)*(const unsigned short *)((const char *)inv_tab + o_first);
             const int rb = (int)*(const unsigned short *)((const char *)inv_tab + o_last);
             r[j] = max(ra, w_lo);
-            int last = (BITONIC || B.bin_hi >= 0) ? min(rb - 1, w_hi) : w_hi;  // BITONIC: the "no threshold above" bin is tabulated
+            int last = B.bin_hi >= 0 ? min(rb - 1, w_hi) : w_hi;
             if (CHORD) {
                 const double Uh = 0.5 * U[j];
                 const double disc = fma(Uh, Uh, jrel);  // (half chord)^2 in wh units; < 0: the ray misses the disc
@@ -240,13 +208,6 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
                 nrow[j] = act[j] ? last - r[j] + 1 : 0;
             }
             nmax = max(nmax, nrow[j]);
-        }
-        if (BITONIC && nmax > XSW_BAND2_MAX) {
-            // a long run (the flat top of a saturating column): the band rule prunes little there and a lane walks its run row
-            // by row, whereas the general kernel sweeps such a window 64 candidates per trip -- leave the pixel to it, unswept
-            overflow = true;
-#pragma unroll
-            for (int j = 0; j < K; ++j) nrow[j] = 0;
         }
         if (BATCH && S >= XSW_BAND_BATCH_S) {
             // k_invert_band2's pixels (long runs of band rows: an a-priori wind far from the sigma0 contour, or a flat stretch of
@@ -271,7 +232,7 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
                     }
 #pragma unroll
                     for (int u = 0; u < XSW_BAND_BATCH; ++u) {
-                        const bool inb = t0 + u < nrow[j] && (XSW_BAND_NO_VCHECK || (v[u] >= thr_lo && v[u] <= thr_hi));
+                        const bool inb = t0 + u < nrow[j];
                         const double wh = fma((double)rc[u], whs, wh0);
                         const double dd = fma(v[u], inv_dsig, sn);
                         double J = fma(dd, dd, wh * (wh - U[j]));
@@ -297,16 +258,16 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
                 if (left[j] == 0ULL) continue;  // wave-uniform: the j-th directions of this pass have no rows left (often the upper half)
                 // (a lane past its run -- masked below -- may read past the window, up to XSW_BAND_MAX rows: the table is padded by
                 // 260 rows, xsw.hip; r[j] <= n_w)
-                const int rc = XSW_BAND_NO_CLAMP ? r[j] + t : min(r[j] + t, w_hi);
+                const int rc = min(r[j] + t, w_hi);  // (unclamped -- the table is padded -- measured slower: masked lanes then touch new cache lines)
                 const double v = ld_co(base, off0[j], rc, rowB);
                 // the end rows may lie just outside the band: candidates of the window all the same, so scoring them is harmless
                 // and cheaper than the two comparisons that would mask them (band kernel at 20000^2: 35.65 -> 33.9 ms)
-                const bool inb = t < nrow[j] && (XSW_BAND_NO_VCHECK || (v >= thr_lo && v <= thr_hi));
+                const bool inb = t < nrow[j];
                 const double wh = fma((double)rc, whs, wh0);
                 const double dd = fma(v, inv_dsig, sn);
                 double J = fma(dd, dd, wh * (wh - U[j]));
                 // a masked lane scores ~9e307 (finite, above the 1e300 "nothing scored" mark): one select on the high word
-                J = XSW_BAND_HI_MASK ? __hiloint2double(inb ? __double2hiint(J) : 0x7FE00000, __double2loint(J)) : (inb ? J : inf);
+                J = __hiloint2double(inb ? __double2hiint(J) : 0x7FE00000, __double2loint(J));
                 second = vmin(second, vmax(J, best));
                 const bool lt = J < best;
                 brow = lt ? rc : brow;
@@ -316,7 +277,7 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
             }
         }
         }
-        const bool any = nmax > (BITONIC ? XSW_BAND2_MAX : sweep_max);
+        const bool any = nmax > sweep_max;
         overflow = overflow || any;  // rows left after XSW_BAND_MAX trips
         if (K == 1 && S != 64) bip = ip[0];
     }
@@ -430,14 +391,14 @@ __device__ __forceinline__ void wave_tail(const DevTables &L, const KArgs &A, lo
 }
 
 // One wave's 64 pixels (lane l: pixel i, `in` = the lane has one) through stage 1, the band passes, the cross-pol phase and the
-// store.  Body of k_invert_band (tiles of the raster) and k_invert_band2 (pixels of a work list, BITONIC rule).
+// store.  Body of k_invert_band (tiles of the raster) and k_invert_band2 (pixels of a work list).
 // COUNT = true: the statistics instantiation (xsw_stats_enable): candidates are counted per pass; its own kernel so that the
 // production kernel carries one copy of each pass (half the code).
-// ROLE: 0 = every window class in this kernel (the statistics instantiation; the rise-then-fall rule; XSW_WIDE=0);
+// ROLE: 0 = every window class in this kernel (the statistics instantiation; XSW_LONG_RUN=0);
 //       1 = pixels whose band holds A.long_run or more rows along the a-priori direction are handed to the second band kernel
 //           (list B), the others are swept here (k_invert_band's default);
-//       2 = the rows swept in batches and clipped to the disc's chord (k_invert_band2 in its default, LONG-RUN role).
-template <typename T, typename TO, bool CR, bool COUNT, bool BITONIC, int ROLE = 0>
+//       2 = the rows swept in batches and clipped to the disc's chord (k_invert_band2).
+template <typename T, typename TO, bool CR, bool COUNT, int ROLE = 0>
 __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, long long i, bool in, int lane, BandSlot *__restrict__ slots,
                                           int *__restrict__ res_, bool strip_walk = false /* ROLE 2 walking every strip: the short-run pixels are k_invert_band's */,
                                           long long strip = -1 /* the wave's pixels are strip `strip` of the raster (lane = sample); -1: listed pixels */)
@@ -448,8 +409,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
     constexpr int NC = 11;  // window classes: S lanes x K directions = 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128 (and wider: chunks)
     int pos = -1, first[NC] = {}, ncls[NC] = {};  // slot of this lane's pixel; slot range of each class
     bool skip = false;        // ROLE 2 walking every strip (list B overflowed): not one of the long-run pixels this kernel is for
-    bool to_bitonic = false;  // left to the second band kernel: its window leaves the monotone rows of a rise-then-fall slice
-                              // (XSW_BAND2=1), or -- ROLE 1 -- its band holds a long run of rows
+    bool to_b = false;        // ROLE 1: left to the second band kernel (list B) -- its band holds a long run of rows
     bool to_c = false;        // left to k_invert_blocks (list C): a finite pixel the band rule is not for -- its window leaves the monotone
                               // rows, or its band holds more rows / candidates than k_invert_band2 takes
     {
@@ -475,7 +435,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
             // cannot hold the argmin (their sigma0 term alone exceeds J_ub): the window is cut at the last monotone row.
             int w_hi_e = W.w_hi;
             bool has_tail = false;  // the rows w_hi_e + 1 .. W.w_hi are the window's tail (below)
-            if (!BITONIC && L.tail_min) {
+            if (L.tail_min) {
                 const bool fin1 = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0;
                 const int mono1 = L.mono_rows[fin1 ? P.i_inc : 0];
                 if (fin1 && W.w_hi >= mono1 && W.ip_hi >= W.ip_lo) {
@@ -494,13 +454,8 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
             ncols_p = W.ip_hi - W.ip_lo + 1;
             const bool need = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0 && ncols_p >= 1 && (nrows_p >= 1 || has_tail);
             if (ROLE == 2 && strip_walk) skip = !need || !(w_hi_e < L.mono_rows[need ? P.i_inc : 0]);  // everything k_invert_band did not hand over
-            if (BITONIC) {
-                eligb = need && L.bitonic_ok[need ? P.i_inc : 0] != 0;  // every column of the slice rises, then falls
-            } else {
-                eligb = need && w_hi_e < L.mono_rows[need ? P.i_inc : 0];  // the window stays inside the monotone rows
-                to_bitonic = need && !eligb && L.inv2 != nullptr && L.bitonic_ok[P.i_inc] != 0;
-                if (ROLE != 2) to_c = need && !eligb && !to_bitonic;
-            }
+            eligb = need && w_hi_e < L.mono_rows[need ? P.i_inc : 0];  // the window stays inside the monotone rows
+            if (ROLE != 2) to_c = need && !eligb;
             if (COUNT) cand += (unsigned)__popcll(__ballot(eligb)) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)) + (XSW_BAND_RAYS - 1) * 2 * XSW_RAY_SIDE_STEPS);
             // class of a window by its number of (virtual) columns n: the smallest of 4, 6, 8, 12, ..., 96, 128 that holds it, i.e. S lanes
             // x K directions per lane with K = 2 (capacity 2S) or 3 (capacity 3S, S half as large: twice the pixels per pass of
@@ -513,7 +468,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
             const double thr_lo = P.s_co - W.band_d, thr_hi = P.s_co + W.band_d;
             int bin = 0, bhi = XSW_INV_BINS;
             if (eligb) {
-                const double *g = (BITONIC ? L.inv_grid2 : L.inv_grid) + 3 * P.i_inc;
+                const double *g = L.inv_grid + 3 * P.i_inc;
                 const double t0 = g[0], width = g[1];
                 bin = (int)fmin(fmax((thr_lo - t0) * g[2], 0.0), (double)(XSW_INV_BINS - 1));
                 if (bin > 0 && fma((double)bin, width, t0) > thr_lo) --bin;
@@ -524,7 +479,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
             }
             int myc = NC;
             if (eligb) {
-                const int nv = BITONIC ? 2 * ncols_p : ncols_p;
+                const int nv = ncols_p;
                 const int p2 = 31 - __clz(max(nv, 2) - 1);  // 2^p2 < n <= 2^(p2 + 1)
                 myc = nv <= 4 ? 0 : min(2 * p2 - 3 + (nv > (3 << (p2 - 1)) ? 1 : 0), NC - 1);
             }
@@ -560,7 +515,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                 if (ROLE == 1 && handed) {  // the second band kernel's
                     myc = NC;
                     eligb = false;
-                    to_bitonic = true;
+                    to_b = true;
                 }
                 if (ROLE == 2 && eligb && !handed) {  // k_invert_band has dealt with it (decided, or listed)
                     myc = NC;
@@ -578,7 +533,6 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                 ncls[c] = __popcll(m);
                 base += ncls[c];
             }
-#ifndef XSW_BAND_NO_PROMOTE
             // the pixels a class would leave for a part-filled last pass move up into the next wider class when they fit into
             // ITS part-filled last pass (their slots lie right before that class's: only the boundary moves; a narrow window in
             // a wide segment merely leaves lanes idle): one pass less each time
@@ -589,14 +543,13 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                 const int added = (ncls[c + 1] + rem + npn - 1) / npn - (ncls[c + 1] + npn - 1) / npn;
                 if (rem > 0 && added == 0) { ncls[c] -= rem; ncls[c + 1] += rem; first[c + 1] -= rem; }
             }
-#endif
             if (eligb) {
                 BandSlot b;
                 const double ah = 0.5 * P.a_re, bh = 0.5 * P.b_eff;
                 b.sn = -P.s_co * A.inv_dsig_co; b.thr_lo = thr_lo; b.thr_hi = thr_hi;
                 b.ah = ah; b.bh = bh; b.m2 = ah * ah + bh * bh;
                 b.inc_bin = P.i_inc | (bin << 16); b.rows = W.w_lo | (w_hi_e << 16); b.ipn = W.ip_lo | (ncols_p << 16);
-                b.bin_hi = bhi < XSW_INV_BINS ? bhi : (BITONIC ? XSW_INV_BINS /* the tabulated +inf threshold */ : -1);
+                b.bin_hi = bhi < XSW_INV_BINS ? bhi : -1;
                 if (ROLE == 2) b.bin_hi = (b.bin_hi & 0xffff) | ((has_tail ? W.w_hi - w_hi_e : 0) << 16);  // co_band_pass: rows past the monotone ones
                 slots[pos] = b;
 #ifdef XSW_TIMING_STAGE1_ONLY
@@ -616,7 +569,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
         auto run = [&](auto seg, auto kk, int c) {
             constexpr int S = decltype(seg)::value, K = decltype(kk)::value;
             for (int p = 0; p < ncls[c]; p += 64 / S)
-                co_band_pass<S, K, COUNT, BITONIC, ROLE == 2>(L, A.inv_dsig_co, lane, slots, res_, first[c] + p, min(64 / S, ncls[c] - p), cand);
+                co_band_pass<S, K, COUNT, ROLE == 2>(L, A.inv_dsig_co, lane, slots, res_, first[c] + p, min(64 / S, ncls[c] - p), cand);
         };
         using two = std::integral_constant<int, 2>;
         using three = std::integral_constant<int, 3>;
@@ -641,7 +594,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
         skip = skip || (flags & F_NEED_CO) == 0;
         in = in && !skip;
     }
-    wave_tail<T, TO, CR, COUNT>(L, A, i, in, lane, flags, my_flat, !BITONIC && A.list_b != nullptr && to_bitonic, to_c, strip, cand);
+    wave_tail<T, TO, CR, COUNT>(L, A, i, in, lane, flags, my_flat, A.list_b != nullptr && to_b, to_c, strip, cand);
 }
 
 template <typename T, typename TO, bool CR, bool COUNT, int ROLE = 0>
@@ -662,14 +615,13 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, CR ? XSW_BAND_WAVES_CR : XS
     const long long smp = col * 64 + lane;
     const bool in = smp < A.samples;
     const long long i = line * A.samples + (in ? smp : A.samples - 1);
-    band_wave<T, TO, CR, COUNT, false, ROLE>(L, A, i, in, lane, slots[wv], res_[wv], false, line * strips_per_line + col);
+    band_wave<T, TO, CR, COUNT, ROLE>(L, A, i, in, lane, slots[wv], res_[wv], false, line * strips_per_line + col);
 }
 
-// Second kernel of the three-kernel chain: the pixels k_invert_band left on list B (their window leaves the monotone rows of a
-// slice whose columns rise and then fall: high winds at near-range incidences, where CMOD5.N saturates and turns over) with the
-// band rule applied to BOTH branches of every column.  64 listed pixels per wave (gathered rasters), fixed grid, every wave
-// strides over the list; a list that overflowed is left to k_invert_list (which then inverts every tile).
-template <typename T, typename TO, bool CR, bool BITONIC>
+// Second kernel of the chain: the pixels k_invert_band left on list B (their band holds a long run of rows along the a-priori
+// direction), 64 listed pixels per wave (gathered rasters), rows swept in batches and clipped to the disc's chord; fixed grid,
+// every wave strides over the list; a list that overflowed is continued in the strip mask.
+template <typename T, typename TO, bool CR>
 __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND2_WAVES) void k_invert_band2(DevTables L, KArgs A)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -680,15 +632,14 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND2_WAVES) void k_inv
     const long long strips_per_line = (A.samples + 63) >> 6, nstrips = strips_per_line * A.lines;
     if (count > (long long)A.list_b_cap && !A.mask_b) {
         // list B overflowed (k_invert_band kept counting but could not append) and there are no strip masks: which pixels it meant
-        // is unknown, so this kernel walks EVERY strip of the raster.  Rise-then-fall role: every pixel goes through the rule (it
-        // holds for monotone windows as well: their falling runs are empty; results do not depend on which kernel wrote a pixel).
-        // Long-run role: stage 1 is redone for every pixel and only the long-run pixels -- what k_invert_band did not keep -- are
-        // searched.  (strips in linear order, one per wave: measured 2x faster for this kernel than k_invert_band's XCD-aware tile
-        // walk as a grid-stride loop -- the heavy pixels of a scene cluster, and the linear order spreads them over all the waves)
+        // is unknown, so this kernel walks EVERY strip of the raster: stage 1 is redone for every pixel and only the long-run
+        // pixels -- what k_invert_band did not keep -- are searched.  (strips in linear order, one per wave: measured 2x faster
+        // for this kernel than k_invert_band's XCD-aware tile walk as a grid-stride loop -- the heavy pixels of a scene cluster,
+        // and the linear order spreads them over all the waves)
         for (long long c = (long long)blockIdx.x * XSW_BAND_WG_WAVES + wv; c < nstrips; c += nwaves) {  // wave-uniform
             const long long line = c / strips_per_line, smp = (c - line * strips_per_line) * 64 + lane;
             const bool in = smp < A.samples;
-            band_wave<T, TO, CR, false, BITONIC, BITONIC ? 0 : 2>(L, A, line * A.samples + (in ? smp : A.samples - 1), in, lane, slots[wv], res_[wv], !BITONIC, c);
+            band_wave<T, TO, CR, false, 2>(L, A, line * A.samples + (in ? smp : A.samples - 1), in, lane, slots[wv], res_[wv], true, c);
             __builtin_amdgcn_wave_barrier();
         }
         return;
@@ -698,7 +649,7 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND2_WAVES) void k_inv
         const long long k = c * 64 + lane;
         const bool in = k < nlist;
         const long long i = (long long)A.list_b[in ? k : nlist - 1];
-        band_wave<T, TO, CR, false, BITONIC, BITONIC ? 0 : 2>(L, A, i, in, lane, slots[wv], res_[wv]);
+        band_wave<T, TO, CR, false, 2>(L, A, i, in, lane, slots[wv], res_[wv]);
         __builtin_amdgcn_wave_barrier();
     }
     if (count > (long long)A.list_b_cap) {
@@ -708,7 +659,7 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND2_WAVES) void k_inv
             if (m == 0ULL) continue;
             const long long line = c / strips_per_line, smp = (c - line * strips_per_line) * 64 + lane;
             const bool in = smp < A.samples;
-            band_wave<T, TO, CR, false, BITONIC, BITONIC ? 0 : 2>(L, A, line * A.samples + (in ? smp : A.samples - 1), in && ((m >> lane) & 1ULL) != 0ULL, lane,
+            band_wave<T, TO, CR, false, 2>(L, A, line * A.samples + (in ? smp : A.samples - 1), in && ((m >> lane) & 1ULL) != 0ULL, lane,
                                                                  slots[wv], res_[wv], false, c);
             __builtin_amdgcn_wave_barrier();
         }

@@ -52,14 +52,6 @@ struct DevTables {
     // LUT >= fma(b, inv_grid[3i+1], inv_grid[3i]) (a uniform dB grid per slice, XSW_INV_BINS bins), else mono_rows[i]
     const unsigned short *inv_rows;  // [n_inc][XSW_INV_BINS][phi_pad]
     const double *inv_grid;          // [n_inc][3]: t0, bin width, 1 / bin width
-    // the same for columns that rise and then fall (k_invert_band2): per slice and direction the rising part is rows [0, P), P the
-    // first row lower than its predecessor, the falling part rows [P, n_w).  inv2[i][0][b][p] = first row r < P with LUT >= t_b
-    // (else P), inv2[i][1][b][p] = first row r >= P with LUT < t_b (else n_w); thresholds t_b = fma(b, inv_grid2[3i+1], inv_grid2[3i])
-    // over the dB range of the WHOLE slice, b = 0 .. XSW_INV_BINS - 1, plus row b = XSW_INV_BINS for "+inf" (P in both tables);
-    // falling table: bin 0 = n_w (nothing lies below the slice's minimum).  bitonic_ok[i]: every column of slice i has that shape.
-    const unsigned short *inv2;      // [n_inc][2][XSW_INV_BINS + 1][phi_pad]   (null: not built)
-    const double *inv_grid2;         // [n_inc][3]
-    const int *bitonic_ok;           // [n_inc]
     // block pyramid (co_block_search): blk[i][br][bc] = {min, max} of the LUT over speed rows [XSW_BLK_R br, +XSW_BLK_R) x directions
     // [XSW_BLK_C bc, +XSW_BLK_C) of slice i, float32 rounded outward; bandmm[i][t] the same over block rows [blk_g t, +blk_g), every
     // direction (blk_g = the block rows one wave trip covers, one lane per block).  Null: not built.
@@ -409,9 +401,6 @@ struct CoWindow {
 #ifndef XSW_MAX_FD_TRIPS
 #define XSW_MAX_FD_TRIPS 256
 #endif
-#ifndef XSW_SEG32
-#define XSW_SEG32 0
-#endif
 #ifndef XSW_SEG8
 #define XSW_SEG8 1
 #endif
@@ -420,7 +409,7 @@ struct CoWindow {
 #endif
 __device__ __forceinline__ int seg_lanes(int width)
 {
-    return (XSW_SEG4 && width <= 4) ? 4 : ((XSW_SEG8 && width <= 8) ? 8 : (width <= 16 ? 16 : ((XSW_SEG32 && width <= 32) ? 32 : 64)));
+    return (XSW_SEG4 && width <= 4) ? 4 : ((XSW_SEG8 && width <= 8) ? 8 : (width <= 16 ? 16 : 64));
 }
 __device__ __forceinline__ void chunk_geom(int width, int nrows, int S, int &geom, int &mdiv)
 {
@@ -439,7 +428,6 @@ __device__ __forceinline__ CoWindow box_from_jub(const DevTables &L, double mag,
     CoWindow W;
     W.w_lo = 0; W.w_hi = L.n_w - 1; W.ip_lo = 0; W.ip_hi = L.n_phi - 1;
     W.geom = 0; W.mdiv = 0; W.band_d = 0.0;
-#ifndef XSW_GEOM_F64
     // window geometry from float32 square root / arcsine / arctangent (a few instructions each instead of the ~20 / 70 / 90 of
     // their float64 library forms: stage 1 is VALU-bound, profiles/r03_stage1_counters.json), with the margins widened to cover
     // them -- a window may only ever grow: 2e-3 index units (mag from a float32 square root: 6e-8 relative of <= 80 m/s is
@@ -447,22 +435,13 @@ __device__ __forceinline__ CoWindow box_from_jub(const DevTables &L, double mag,
     // R / |m| = 0.999 (all directions instead: the arcsine's slope there would magnify the ratio's rounding)
     const double MRG = 2e-3;
     const double R = 2.0 * (double)__builtin_sqrtf((float)jub) * (1.0 + 1e-6) + 1e-6;
-#else
-    const double MRG = 1e-5;
-    const double R = 2.0 * sqrt(jub) * (1.0 + 1e-9) + 1e-9;
-#endif
     if (mag < 1e6 && R < 1e6) {
         const double nw = (double)L.n_w, np_ = (double)L.n_phi;
         const double xl = (mag - R - L.w0) * L.inv_wstep, xh = (mag + R - L.w0) * L.inv_wstep;
         W.w_lo = max((int)ceil(fmin(fmax(xl - MRG - 1e-9 * fabs(xl), -4.0), nw + 4.0)), 0);
         W.w_hi = min((int)floor(fmin(fmax(xh + MRG + 1e-9 * fabs(xh), -4.0), nw + 4.0)), L.n_w - 1);
-#ifndef XSW_GEOM_F64
         if (R < mag * 0.999) {
             const double half = (double)asinf((float)(R / mag)) * 57.29577951308232 + 2e-4;
-#else
-        if (R < mag * (1.0 - 1e-9)) {
-            const double half = asin(R / mag) * 57.29577951308232 + 1e-7;
-#endif
             double yl = (theta - half - L.phi0) * L.inv_dphi, yh = (theta + half - L.phi0) * L.inv_dphi;
             yl -= MRG + 1e-9 * fabs(yl);
             yh += MRG + 1e-9 * fabs(yh);
@@ -584,11 +563,7 @@ __device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pi
     CoWindow W = box_from_jub(L, mag, theta, jub);
     // the sigma0 term alone is >= 0 as well: ((LUT - s)/dsig)^2 <= J_ub is necessary, i.e. |LUT - s| <= |dsig| sqrt(J_ub)
     // (inflated: a candidate outside scores > J_ub (1 + 1e-9), above the exact score of the ray's best candidate)
-#ifndef XSW_GEOM_F64
     W.band_d = (double)__builtin_sqrtf((float)jub) * (1.0 + 1e-6) * abs_dsig + 1e-9;
-#else
-    W.band_d = sqrt(jub) * (1.0 + 1e-9) * abs_dsig + 1e-12;  // abs_dsig = |dsig_co| = 1 / |inv_dsig| to an ulp, far inside the inflation
-#endif
     return W;
 }
 
@@ -880,7 +855,7 @@ template <int S> __device__ __forceinline__ double seg_min_d(double v)
     if (S >= 4) v = vmin(v, dpp_d<0x4E, 0xF>(v));   // lane ^ 2
     if (S >= 8) v = vmin(v, dpp_d<0x141, 0xF>(v));  // 8-lane halves mirrored: every lane of an 8-lane group holds its minimum
     if (S >= 16) v = vmin(v, dpp_d<0x140, 0xF>(v));  // 16-lane rows mirrored
-    if (S == 32) v = vmin(v, __shfl_xor(v, 16));
+    if (S == 32) v = vmin(v, __shfl_xor(v, 16));     // (co_band_pass's 32-lane classes)
     return v;
 }
 template <int S>
@@ -1277,13 +1252,8 @@ __device__ __forceinline__ void load_pixel(const DevTables &L, const KArgs &A, l
     }
     P.b_eff = L.phi_180 ? fabs(P.a_im) : P.a_im;  // windspeed.py:218-219
     // search-window geometry of the branch-and-bound kernel, one pixel per lane (64 at a time)
-#ifndef XSW_GEOM_F64
     P.mag = (double)__builtin_sqrtf((float)(P.a_re * P.a_re + P.b_eff * P.b_eff));
     double th = (double)atan2f((float)P.b_eff, (float)P.a_re) * 57.295779513082320877;
-#else
-    P.mag = sqrt(P.a_re * P.a_re + P.b_eff * P.b_eff);
-    double th = atan2(P.b_eff, P.a_re) * 57.295779513082320877;
-#endif
     if (th < L.phi0) th += 360.0;
     P.theta = th;
     P.ipr = (P.flags & F_CO_FINITE)
@@ -1350,10 +1320,8 @@ __device__ __forceinline__ void store_pixel(const DevTables &L, const KArgs &A, 
         ((cx_t *)A.out_co)[i] = z;
     }
     // the answer as grid codes (xsw.h): what xsw_expand_codes turns back into exactly the values formed above
-#ifndef XSW_NO_CODES
     if (A.code_co)
         A.code_co[i] = (P.flags & F_EARLY_NAN) ? K_CODE_NAN_RE : (P.flags & F_NEED_CO) ? ((unsigned)my_flat | ((unsigned)sgn << 30)) : K_CODE_NAN;
-#endif
     if (CR && (A.out_cr || A.code_cr)) {
         bool picked_co = false;
         if (A.dual_select) {  // xr.where((|co| < 5) | (|dual| < 5), co, dual)  (windspeed.py:426-428)
@@ -1371,11 +1339,9 @@ __device__ __forceinline__ void store_pixel(const DevTables &L, const KArgs &A, 
             cx_t z; z.x = (TO)cr_re; z.y = (TO)cr_im;
             ((cx_t *)A.out_cr)[i] = z;
         }
-#ifndef XSW_NO_CODES
         if (A.code_cr)
             A.code_cr[i] = (P.flags & F_EARLY_NAN) ? K_CODE_NAN_RE
                                                      : (((P.flags & F_NEED_CR) ? (unsigned)my_icr : K_CODE_NO_INDEX) | (picked_co ? K_CODE_PICK_CO : 0u));
-#endif
     }
     if (A.out_idx) {
         A.out_idx[3 * i + 0] = o_iw;
@@ -1421,8 +1387,8 @@ __device__ __forceinline__ void invert_strip(const DevTables &L, const KArgs &A,
             const bool elig = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0;
             unsigned long long m4 = __ballot(XSW_SEG4 && elig && ncols_p <= 4);
             unsigned long long m8 = __ballot(XSW_SEG8 && elig && ncols_p <= 8) & ~m4;
-            unsigned long long m16 = __ballot(elig && ncols_p <= 16) & ~(m8 | m4), m32 = __ballot(XSW_SEG32 && elig && ncols_p > 16 && ncols_p <= 32);
-            const unsigned long long segd = m4 | m8 | m16 | m32;
+            unsigned long long m16 = __ballot(elig && ncols_p <= 16) & ~(m8 | m4);
+            const unsigned long long segd = m4 | m8 | m16;
             relay |= segd;
             if (A.stats) {
                 unsigned c = ((segd >> lane) & 1ULL) ? (unsigned)((W.w_hi - W.w_lo + 1) * ncols_p) : 0u;
@@ -1433,7 +1399,6 @@ __device__ __forceinline__ void invert_strip(const DevTables &L, const KArgs &A,
             while (m4) co_seg_pass<4>(L, P, W, A.inv_dsig_co, lane, m4, my_flat, redo);
             while (m8) co_seg_pass<8>(L, P, W, A.inv_dsig_co, lane, m8, my_flat, redo);
             while (m16) co_seg_pass<16>(L, P, W, A.inv_dsig_co, lane, m16, my_flat, redo);
-            while (m32) co_seg_pass<32>(L, P, W, A.inv_dsig_co, lane, m32, my_flat, redo);
             n_co += (unsigned)__popcll(segd & ~redo);
             todo = (todo & ~segd) | redo;
         }
@@ -1578,14 +1543,7 @@ __global__ __launch_bounds__(256, XSW_LIST_WAVES) void k_invert_list(DevTables L
         const long long k = c * ppw + lane;
         const bool in = lane < ppw && k < nlist;
         const long long i = (long long)A.list[in ? k : nlist - 1];
-#ifdef XSW_LIST_CLOCK  // experiments: the slowest wave pass of the list (10 ns ticks << 40 | its first pixel) in stats[3]
-        const unsigned long long t0 = wall_clock64();
-#endif
         invert_strip<T, TO, 1, CR>(L, A, i, in, lane);
-#ifdef XSW_LIST_CLOCK
-        const unsigned long long dt = wall_clock64() - t0;
-        if (lane == 0 && A.stats) atomicMax(&A.stats[3], (dt << 40) | ((unsigned long long)i & 0xFFFFFFFFFFULL));
-#endif
     }
     if (count > (long long)A.list_cap) {
         // the pixels that did not fit into the list are marked in mask_g (one bit per pixel, a word per strip): the marked pixels

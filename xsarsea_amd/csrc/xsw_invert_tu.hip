@@ -44,25 +44,23 @@ static int launch_invert(xsw_ctx *c, const KArgs &A_in, int algo, const LaunchCt
         B.list_count = lc.list;
         B.list = lc.list + 16;
         B.list_cap = (unsigned)std::min<size_t>(lc.list_cap, 0xfffffff0u);
-        // list B (k_invert_band -> k_invert_band2) follows list G.  Long-run role (the default): a pixel whose band holds
-        // XSW_LONG_RUN (4) or more rows along the a-priori direction is handed to k_invert_band2 -- one such pixel holds up every
-        // pixel of its pass in k_invert_band, and where the a-priori wind is far from the sigma0 contour most pixels are such.
-        // XSW_LONG_RUN=0: never (k_invert_band sweeps every window; A/B measurements).  XSW_BAND2=1 (opt-in): the
-        // rise-then-fall rule instead.  The statistics instantiation sweeps every window in k_invert_band as well.
+        // list B (k_invert_band -> k_invert_band2) follows list G: a pixel whose band holds XSW_LONG_RUN (4) or more rows along the
+        // a-priori direction is handed to k_invert_band2 -- one such pixel holds up every pixel of its pass in k_invert_band, and
+        // where the a-priori wind is far from the sigma0 contour most pixels are such.  XSW_LONG_RUN=0: never (k_invert_band
+        // sweeps every window: A/B measurements); the statistics instantiation sweeps every window in k_invert_band as well.
         static const int long_run_env = getenv("XSW_LONG_RUN") ? std::max(0, atoi(getenv("XSW_LONG_RUN"))) : 4;
-        const bool bitonic2 = c->T.inv2 != nullptr && !A.stats, wide2 = !bitonic2 && long_run_env > 0 && !A.stats;
-        const bool band2 = bitonic2 || wide2;
+        const bool band2 = long_run_env > 0 && !A.stats;
         if (band2) { B.list_b_count = lc.list + 1; B.list_b = lc.list + 16 + lc.list_cap; B.list_b_cap = B.list_cap; }
         // list C (k_invert_band -> k_invert_blocks): the finite pixels the band rule is not for.  XSW_NO_BLOCKS_KERNEL=1: they stay on
         // list G, i.e. with k_invert_list (A/B measurements and the tests of that route)
         static const bool blocks_kernel_off = getenv("XSW_NO_BLOCKS_KERNEL") != nullptr;
-        const bool blocks3 = c->T.blk != nullptr && c->T.blk_span_ok && !bitonic2 && !blocks_kernel_off && c->T.n_w < 32768 && c->T.n_phi < 32768;
+        const bool blocks3 = c->T.blk != nullptr && c->T.blk_span_ok && !blocks_kernel_off && c->T.n_w < 32768 && c->T.n_phi < 32768;
         if (blocks3) { B.list_c_count = lc.list + 2; B.list_c = lc.list + 16 + 2 * lc.list_cap; B.list_c_cap = (unsigned)std::min<size_t>(XSW_LIST_C_SHARE * lc.list_cap, 0xfffffff0u); }
         B.long_run = long_run_env;
         static const int area_max_env = getenv("XSW_B2_AREA") ? std::max(1, atoi(getenv("XSW_B2_AREA"))) : XSW_B2_AREA;
         B.area_max = c->T.blk ? area_max_env : 0x7fffffff;  // (without the block tables the general kernel has nothing better to offer)
         static const int tail_max_env = getenv("XSW_TAIL_SWEEP") ? std::min(std::max(0, atoi(getenv("XSW_TAIL_SWEEP"))), 30000) : XSW_TAIL_SWEEP;
-        B.tail_max = (wide2 && c->T.tail_min) ? tail_max_env : 0;  // the long-run role of k_invert_band2 only
+        B.tail_max = (band2 && c->T.tail_min) ? tail_max_env : 0;  // (the tail rows are k_invert_band2's to sweep)
         // strip masks: what the consumers walk when a list overflows (only the marked pixels instead of the whole raster)
         static const bool masks_off = getenv("XSW_NO_STRIP_MASKS") != nullptr;  // A/B measurements and the tests of the old route
         const size_t nstrips = (size_t)(strips_per_line * A.lines);
@@ -81,7 +79,7 @@ static int launch_invert(xsw_ctx *c, const KArgs &A_in, int algo, const LaunchCt
         if (A.stats) {  // statistics instantiation (counts the scored candidates)
             if (mono) hipLaunchKernelGGL((k_invert_band<T, TO, false, true>), band_grid, band_block, 0, lc.stream, c->T, B);
             else hipLaunchKernelGGL((k_invert_band<T, TO, true, true>), band_grid, band_block, 0, lc.stream, c->T, B);
-        } else if (wide2) {
+        } else if (band2) {
             if (mono) hipLaunchKernelGGL((k_invert_band<T, TO, false, false, 1>), band_grid, band_block, 0, lc.stream, c->T, B);
             else hipLaunchKernelGGL((k_invert_band<T, TO, true, false, 1>), band_grid, band_block, 0, lc.stream, c->T, B);
         } else if (mono) {
@@ -92,13 +90,8 @@ static int launch_invert(xsw_ctx *c, const KArgs &A_in, int algo, const LaunchCt
         if (lc.timing) timing_mark(c);
         if (band2) {
             const dim3 b2_grid((unsigned)std::min<long long>(nblocks, 256 * XSW_BAND2_WAVES));  // XSW_BAND2_WAVES waves per SIMD, 4-wave workgroups
-            if (bitonic2) {
-                if (mono) hipLaunchKernelGGL((k_invert_band2<T, TO, false, true>), b2_grid, band_block, 0, lc.stream, c->T, B);
-                else hipLaunchKernelGGL((k_invert_band2<T, TO, true, true>), b2_grid, band_block, 0, lc.stream, c->T, B);
-            } else {
-                if (mono) hipLaunchKernelGGL((k_invert_band2<T, TO, false, false>), b2_grid, band_block, 0, lc.stream, c->T, B);
-                else hipLaunchKernelGGL((k_invert_band2<T, TO, true, false>), b2_grid, band_block, 0, lc.stream, c->T, B);
-            }
+            if (mono) hipLaunchKernelGGL((k_invert_band2<T, TO, false>), b2_grid, band_block, 0, lc.stream, c->T, B);
+            else hipLaunchKernelGGL((k_invert_band2<T, TO, true>), b2_grid, band_block, 0, lc.stream, c->T, B);
         }
         if (lc.timing) timing_mark(c);
         if (blocks3) {
@@ -107,9 +100,6 @@ static int launch_invert(xsw_ctx *c, const KArgs &A_in, int algo, const LaunchCt
             else hipLaunchKernelGGL((k_invert_blocks<T, TO, true>), bl_grid, dim3(256), 0, lc.stream, c->T, B);
         }
         if (lc.timing) timing_mark(c);
-#ifdef XSW_LIST_CLOCK  // experiments: k_invert_list alone counts into the statistics buffer (xsw_stats_read), see the kernel
-        if (!B.stats) { (void)hipMemsetAsync(c->d_stats, 0, 4 * sizeof(unsigned long long), lc.stream); B.stats = c->d_stats; }
-#endif
         if (mono) hipLaunchKernelGGL((k_invert_list<T, TO, false>), dim3(list_blocks), dim3(256), 0, lc.stream, c->T, B);
         else hipLaunchKernelGGL((k_invert_list<T, TO, true>), dim3(list_blocks), dim3(256), 0, lc.stream, c->T, B);
         if (lc.timing) timing_mark(c);

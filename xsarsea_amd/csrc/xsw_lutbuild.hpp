@@ -88,9 +88,9 @@ __global__ __launch_bounds__(256) void k_mono_rows(const double *__restrict__ de
 // directions [a, b] is min(tail[k][a], tail[k][b - 2^k + 1]) with 2^k <= b - a + 1 < 2^(k+1) -- and level XSW_TAIL_LEVELS holds
 // the minimum over ALL directions (windows wider than 2^XSW_TAIL_LEVELS - 1).  +inf where every row is monotone.  A pixel whose
 // band ends below the minimum of its window's directions has no candidate in the rows past the monotone ones.
-// One workgroup per slice.  whole_tail (A/B, XSW_TAIL_GLOBAL=1): every level holds the all-directions minimum.
+// One workgroup per slice.
 __global__ __launch_bounds__(256) void k_tail_min(const double *__restrict__ dense, int n_w, int n_phi, int phi_pad, const int *__restrict__ mono,
-                                                  double *__restrict__ tail, int whole_tail)
+                                                  double *__restrict__ tail)
 {
     const int i = blockIdx.x, m = mono[i];
     const double *sl = dense + (size_t)i * n_w * n_phi;
@@ -121,11 +121,6 @@ __global__ __launch_bounds__(256) void k_tail_min(const double *__restrict__ den
     }
     const double all = slo[0];
     for (int p = threadIdx.x; p < phi_pad; p += blockDim.x) out[(size_t)XSW_TAIL_LEVELS * phi_pad + p] = all;
-    if (whole_tail) {
-        __syncthreads();
-        for (int k = 0; k < XSW_TAIL_LEVELS; ++k)
-            for (int p = threadIdx.x; p < phi_pad; p += blockDim.x) out[(size_t)k * phi_pad + p] = all;
-    }
 }
 
 // dB range of the monotone rows of each slice -> the slice's uniform threshold grid {t0, width, 1 / width}
@@ -213,92 +208,6 @@ __global__ __launch_bounds__(256) void k_band_minmax(const float2 *__restrict__ 
     o.x = lo;
     o.y = hi;
     band[t] = o;
-}
-
-// ---- rise-then-fall columns (k_invert_band2): peak rows, the slice's shape flag, and the two inverse tables
-// peak[i][p] = P, the first row of column p of slice i that is LOWER than its predecessor (n_w: the column never falls);
-// ok[i] (preset 1) is cleared when a column rises again after it has started to fall.
-__global__ __launch_bounds__(256) void k_peak_rows(const double *__restrict__ dense, int n_inc, int n_w, int n_phi,
-                                                   unsigned short *__restrict__ peak, int *__restrict__ ok)
-{
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)n_inc * n_phi) return;
-    const int i = (int)(t / n_phi), p = (int)(t % n_phi);
-    const double *col = dense + (size_t)i * n_w * n_phi + p;
-    int P = n_w;
-    double prev = col[0];
-    int r = 1;
-    for (; r < n_w; ++r) {
-        const double v = col[(size_t)r * n_phi];
-        if (v < prev) { P = r; break; }
-        prev = v;
-    }
-    bool good = true;
-    for (; r < n_w; ++r) {  // from P on: never above its predecessor
-        const double v = col[(size_t)r * n_phi];
-        if (v > prev) { good = false; break; }
-        prev = v;
-    }
-    peak[t] = (unsigned short)P;
-    if (!good) atomicAnd(&ok[i], 0);
-}
-
-// dB range of ALL rows of each slice -> threshold grid {t0, width, 1 / width} of the rise-then-fall tables
-__global__ __launch_bounds__(256) void k_inv_range2(const double *__restrict__ dense, int n_w, int n_phi, double *__restrict__ grid)
-{
-    const int i = blockIdx.x;
-    const double *sl = dense + (size_t)i * n_w * n_phi;
-    const long long n = (long long)n_w * n_phi;
-    double lo = __builtin_inf(), hi = -__builtin_inf();
-    for (long long k = threadIdx.x; k < n; k += blockDim.x) { const double v = sl[k]; lo = fmin(lo, v); hi = fmax(hi, v); }
-    __shared__ double slo[256], shi[256];
-    slo[threadIdx.x] = lo; shi[threadIdx.x] = hi;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) { slo[threadIdx.x] = fmin(slo[threadIdx.x], slo[threadIdx.x + st]); shi[threadIdx.x] = fmax(shi[threadIdx.x], shi[threadIdx.x + st]); }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const double width = (shi[0] - slo[0]) / (double)XSW_INV_BINS;
-        const bool ok = width > 0.0 && width < 1e300 && slo[0] > -1e300;
-        grid[3 * i + 0] = ok ? slo[0] : 0.0;
-        grid[3 * i + 1] = ok ? width : 0.0;
-        grid[3 * i + 2] = ok ? 1.0 / width : 0.0;
-    }
-}
-
-// one thread per (slice, direction).  Rising table (rows [0, P), non-decreasing): up[b] = first row r < P with col[r] >= t_b,
-// else P; up[0] = 0 (also serves any threshold below the grid); up[XSW_INV_BINS] = P ("+inf").  Falling table (rows [P, n_w),
-// non-increasing): dn[b] = first row r >= P with col[r] < t_b, else n_w; dn[0] = n_w (nothing lies below a threshold at or below
-// the slice's minimum, nor below anything smaller); dn[XSW_INV_BINS] = P.
-__global__ __launch_bounds__(256) void k_inv_rows2(const double *__restrict__ dense, int n_inc, int n_w, int n_phi, int phi_pad,
-                                                   const unsigned short *__restrict__ peak, const double *__restrict__ grid,
-                                                   unsigned short *__restrict__ inv2)
-{
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)n_inc * n_phi) return;
-    const int i = (int)(t / n_phi), p = (int)(t % n_phi);
-    const double *col = dense + (size_t)i * n_w * n_phi + p;
-    constexpr int NB = XSW_INV_BINS + 1;
-    unsigned short *up = inv2 + ((size_t)i * 2 + 0) * NB * phi_pad + p, *dn = inv2 + ((size_t)i * 2 + 1) * NB * phi_pad + p;
-    const double t0 = grid[3 * i], width = grid[3 * i + 1];
-    const int P = (int)peak[t];
-    int r = 0;
-    up[0] = 0;
-    for (int b = 1; b < XSW_INV_BINS; ++b) {
-        const double thr = fma((double)b, width, t0);
-        while (r < P && col[(size_t)r * n_phi] < thr) ++r;
-        up[(size_t)b * phi_pad] = (unsigned short)r;
-    }
-    up[(size_t)XSW_INV_BINS * phi_pad] = (unsigned short)P;
-    dn[(size_t)XSW_INV_BINS * phi_pad] = (unsigned short)P;
-    r = P;
-    for (int b = XSW_INV_BINS - 1; b >= 1; --b) {  // descending thresholds: the first row below the threshold moves right
-        const double thr = fma((double)b, width, t0);
-        while (r < n_w && !(col[(size_t)r * n_phi] < thr)) ++r;
-        dn[(size_t)b * phi_pad] = (unsigned short)r;
-    }
-    dn[0] = (unsigned short)n_w;
 }
 
 }  // namespace xsw

@@ -71,19 +71,8 @@ __global__ __launch_bounds__(256) void k_lut_interp(InterpArgs a)
 #ifndef XSW_DETREND_LINES
 #define XSW_DETREND_LINES 4
 #endif
-#ifndef XSW_DETREND_NT
-#define XSW_DETREND_NT 0
-#endif
-#if XSW_DETREND_NT & 1
-#define XSW_DETREND_LD(p) __builtin_nontemporal_load(p)
-#else
 #define XSW_DETREND_LD(p) (*(p))
-#endif
-#if XSW_DETREND_NT & 2
-#define XSW_DETREND_ST(v, p) __builtin_nontemporal_store(v, p)
-#else
 #define XSW_DETREND_ST(v, p) (*(p) = (v))
-#endif
 template <typename T, int N> struct VecOf;
 template <> struct VecOf<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
 template <> struct VecOf<double, 4> { typedef double type __attribute__((ext_vector_type(4))); };
