@@ -41,7 +41,7 @@ LANE_OPS_PEAK = 7.86e13  # 256 CU x 128 lanes x 2.4 GHz, non-packed (SURVEY.md 8
 OPS_PER_CANDIDATE = 6    # sub, scale, square-accumulate, separable wind term, compare, select
 BYTES_READ_PX = 16       # inc f32 + sigma0 f32 + ancillary complex64   
 BYTES_WRITE_PX = 8       # complex64 wind
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 PCIE_PEAK_GBS = 64.0      # PCIe Gen5 x16, one direction (MI355X_MICROARCH.md host link)
 
 CONFIGS = {  # BASELINE.json configs (1 is the CPU plumbing case: tests/test_gpu_api.py::test_sigma0_detrend)

@@ -22,7 +22,7 @@ python3 - <<PY
 import csv, glob, json, collections
 px=20000*20000
 res={}
-for kern in ("k_invert_band<", "k_invert_band2<", "k_invert_list<", "k_invert<"):
+for kern in ("k_invert_band<", "k_invert_band2<", "k_invert_blocks<", "k_invert_list<", "k_invert<"):
     acc=collections.defaultdict(float); n=collections.Counter()
     for f in glob.glob("$OUT/p*/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):

@@ -8,9 +8,9 @@ from xsarsea_amd.windspeed import _engine, get_model
 dev = torch.device("cuda", 0)
 ctx = _lib.Context(0)
 
-def run(tag, co, n_lines, n_samples, seed, dsig_co=0.1, algo_ref="exhaustive", scale_anc=1.0, inc_shift=0.0):
+def run(tag, co, n_lines, n_samples, seed, dsig_co=0.1, algo_ref="exhaustive", scale_anc=1.0, inc_shift=0.0, outliers=0.0):
     ctx.upload_luts(co=co)
-    inc, s, anc = bench.make_scene(n_lines, n_samples, n_lines, 0, seed, dev)
+    inc, s, anc = bench.make_scene(n_lines, n_samples, n_lines, 0, seed, dev, outlier_frac=outliers)
     if inc_shift:
         inc = inc + inc_shift
     if scale_anc != 1.0:
@@ -40,6 +40,9 @@ total += run("default LUT, incidence +12 deg (42..58)", co, 8000, 20000, 17, inc
 # applicable: those pixels take the general kernel through the work list)
 total += run("default LUT, incidence -13 deg (17..33)", co, 8000, 20000, 21, inc_shift=-13.0)
 total += run("default LUT, incidence -13 deg, ancillary x2", co, 8000, 20000, 22, inc_shift=-13.0, scale_anc=2.0)
+# round 4: sigma0 outliers (+10 / +15 dB blobs: windows covering the whole grid -> k_invert_blocks), also at near-range incidences
+total += run("default LUT, 5 % sigma0 outliers", co, 8000, 20000, 23, outliers=0.05)
+total += run("default LUT, incidence -13 deg, 5 % outliers, ancillary x0.6", co, 8000, 20000, 24, inc_shift=-13.0, scale_anc=0.6, outliers=0.05)
 low = get_model("gmf_cmod5n")._lut(units="dB", resolution="low"); col = _engine._co_dict(low)
 total += run("low-res LUT", col, 20000, 20000, 18)
 # 0..360 axis (phi_180 False): mirror the default LUT
