@@ -39,7 +39,13 @@ extern "C" {
 enum { XSW_F32 = 0, XSW_F64 = 1 };           /* raster element type (complex rasters: c64 / c128) */
 enum { XSW_MEM_HOST = 0, XSW_MEM_DEVICE = 1,
        XSW_MEM_HOST_PINNED = 2 /* host rasters in page-locked memory (xsw_host_alloc / hipHostMalloc): DMA reads them directly,
-                                  the staging copy of XSW_MEM_HOST is skipped for the inputs */ };
+                                  the staging copy of XSW_MEM_HOST is skipped for the inputs */,
+       XSW_MEM_DEVICE_SIGMA0_HOST = 3 /* XSW_VERSION >= 3, xsw_invert only: every raster lives in device memory EXCEPT sigma0_co /
+                                  sigma0_cr, which are host rasters (pageable).  They travel through the workers' staging ring in
+                                  row chunks -- the `stage` callback may fill a chunk itself: the bit-parity route converts
+                                  sigma0 to dB there with numpy's own float32 log10 (windspeed.py:126-130) -- and each chunk is
+                                  searched on its worker's stream against the resident incidence / ancillary rasters, results
+                                  written in place.  Synchronous.  The context's stream is synchronised first. */ };
 enum {
     XSW_ALGO_AUTO = 0,       /* pruned when the LUT axes are uniform and finite, else exact        */
     XSW_ALGO_PRUNED = 1,     /* exact branch-and-bound search (production kernel)                   */

@@ -155,3 +155,54 @@ def test_single_process_multi_device(gpu_ctx, lowres_luts, mode):
     for a, b in zip(one, many):
         assert bits_equal(a, b)
     assert np.isnan(many[0][:70]).all() and not np.isnan(many[0][70:, 3:]).all()
+
+
+def test_device_rasters_with_sigma0_from_the_host(gpu_ctx, default_luts):
+    """XSW_MEM_DEVICE_SIGMA0_HOST (round 4): incidence / ancillary wind / outputs resident in HBM, the linear float32 sigma0 rasters
+    on the host; the staging callback converts each chunk to dB with numpy's own log10 inside the library's worker ring.  Winds ==
+    the all-device call on the host-converted dB rasters, bit for bit -- mono and dual-pol (fused select), ragged last chunk."""
+    import ctypes
+    torch = pytest.importorskip("torch")
+    from xsarsea_amd import _lib
+    from test_gpu_kernel import synthetic_scene
+    from util import lut_dicts
+    lco, lcr = default_luts
+    co, cr = lut_dicts(lco, lcr)
+    gpu_ctx.upload_luts(co=co, cr=cr)
+    lines, samples = 2050, 1500  # ~3.1 Mpx: two chunks of the worker ring, the second one ragged
+    inc, s_vv, s_vh, dsig, anc = synthetic_scene(lines, samples, np.float32, 5)
+    dev = torch.device("cuda", 0)
+    t_inc, t_dsig, t_anc = (torch.from_numpy(a).to(dev) for a in (inc, dsig, anc))
+    with np.errstate(all="ignore"):
+        db_vv, db_vh = (10 * np.log10(s_vv + 1e-15)).astype(np.float32), (10 * np.log10(s_vh + 1e-15)).astype(np.float32)
+    t_vv, t_vh = torch.from_numpy(db_vv).to(dev), torch.from_numpy(db_vh).to(dev)
+    src = {_lib.STAGE_SIGMA0_CO: s_vv.reshape(-1), _lib.STAGE_SIGMA0_CR: s_vh.reshape(-1)}
+    calls = []
+
+    def stage(which, px0, npx, dst):
+        if which not in src:
+            return 0
+        calls.append((which, px0, npx))
+        o = np.frombuffer((ctypes.c_char * (npx * 4)).from_address(dst), dtype=np.float32)
+        with np.errstate(all="ignore"):
+            o[...] = 10 * np.log10(src[which][px0:px0 + npx] + 1e-15)
+        return 1
+
+    for dual in (False, True):
+        ref_co = torch.empty((lines, samples), dtype=torch.complex64, device=dev)
+        ref_cr = torch.empty_like(ref_co) if dual else None
+        got_co, got_cr = torch.zeros_like(ref_co), (torch.zeros_like(ref_co) if dual else None)
+        p = lambda t: None if t is None else t.data_ptr()
+        gpu_ctx.invert_raw(lines, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, p(t_inc), p(t_vv), p(t_vh) if dual else None,
+                           p(t_dsig) if dual else None, p(t_anc), p(ref_co), p(ref_cr), sigma0_is_db=True, dual_select=dual)
+        gpu_ctx.synchronize()
+        calls.clear()
+        gpu_ctx.invert_raw(lines, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE_SIGMA0_HOST, p(t_inc), s_vv.ctypes.data,
+                           s_vh.ctypes.data if dual else None, p(t_dsig) if dual else None, p(t_anc), p(got_co), p(got_cr),
+                           sigma0_is_db=True, dual_select=dual, stage=stage)
+        bits = lambda t: torch.view_as_real(t).view(torch.int32)
+        assert torch.equal(bits(got_co), bits(ref_co))
+        if dual:
+            assert torch.equal(bits(got_cr), bits(ref_cr))
+        staged = sorted(c for c in calls if c[0] == _lib.STAGE_SIGMA0_CO)
+        assert len(staged) >= 2 and sum(c[2] for c in staged) == lines * samples and staged[0][1] == 0

@@ -10,7 +10,7 @@ import numpy as np
 from . import _build, _host
 
 XSW_F32, XSW_F64 = 0, 1
-MEM_HOST, MEM_DEVICE, MEM_HOST_PINNED = 0, 1, 2
+MEM_HOST, MEM_DEVICE, MEM_HOST_PINNED, MEM_DEVICE_SIGMA0_HOST = 0, 1, 2, 3
 CODE_NAN_RE, CODE_NAN, CODE_PICK_CO, CODE_NO_INDEX = 0xFFFFFFFF, 0xFFFFFFFE, 0x40000000, 0x3FFFFFFF
 ALGO_AUTO, ALGO_PRUNED, ALGO_EXHAUSTIVE, ALGO_EXACT, ALGO_EXHAUSTIVE_F64 = 0, 1, 2, 3, 4
 ALGOS = {"auto": ALGO_AUTO, "pruned": ALGO_PRUNED, "exhaustive": ALGO_EXHAUSTIVE, "exact": ALGO_EXACT,

@@ -863,7 +863,8 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
     if (a->lines < 0 || a->samples < 0) return fail(c, XSW_EINVAL, "negative raster shape");
     if ((a->dtype != XSW_F32 && a->dtype != XSW_F64) || (a->out_dtype != XSW_F32 && a->out_dtype != XSW_F64))
         return fail(c, XSW_EINVAL, "dtype/out_dtype must be XSW_F32 or XSW_F64");
-    if (a->mem != XSW_MEM_HOST && a->mem != XSW_MEM_DEVICE && a->mem != XSW_MEM_HOST_PINNED) return fail(c, XSW_EINVAL, "bad mem kind");
+    if (a->mem != XSW_MEM_HOST && a->mem != XSW_MEM_DEVICE && a->mem != XSW_MEM_HOST_PINNED && a->mem != XSW_MEM_DEVICE_SIGMA0_HOST)
+        return fail(c, XSW_EINVAL, "bad mem kind");
     if (!a->inc) return fail(c, XSW_EINVAL, "inc is NULL");
     if (!a->sigma0_co && !a->sigma0_cr) return fail(c, XSW_EINVAL, "neither sigma0_co nor sigma0_cr given");
     if (a->sigma0_co && !c->have_co) return fail(c, XSW_ENOLUT, "sigma0_co given but no co-pol LUT uploaded");
@@ -926,6 +927,65 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
             rc = dispatch_invert(c, A, a->dtype, a->out_dtype, algo, lc, err);
         }
         return rc ? fail(c, rc, "%s", err.c_str()) : XSW_OK;
+    }
+
+    if (a->mem == XSW_MEM_DEVICE_SIGMA0_HOST) {
+        // Device rasters, sigma0 from the host: row chunks (~4 Mpx) through the workers -- stage the chunk's sigma0 into the worker's
+        // page-locked buffer (the caller's callback may fill it: numpy's own log10 on the bit-parity route), one upload per sigma0
+        // raster, the kernels on the worker's stream with the caller's device pointers advanced to the chunk, results in place.
+        if (a->out_idx || a->lines < 4) return fail(c, XSW_EINVAL, "XSW_MEM_DEVICE_SIGMA0_HOST: out_idx is not supported, and the raster needs 4 lines or more");
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // the resident rasters' producers, and the statistics reset
+        const size_t es = a->dtype == XSW_F32 ? 4 : 8, os = a->out_dtype == XSW_F32 ? 8 : 16;
+        const long long lines = a->lines, samples = a->samples;
+        const long long target_px = std::min<long long>(4LL << 20, std::max<long long>(1LL << 16, n / 16));
+        long long lpc = (std::max<long long>((target_px + samples - 1) / samples, 4) + 3) & ~3LL;
+        const long long nchunks = (lines + lpc - 1) / lpc;
+        const size_t max_px = (size_t)std::min<long long>(lpc, lines) * samples;
+        auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t o_co = 0, o_cr = o_co + (a->sigma0_co ? pad(max_px * es) : 0), o_end = o_cr + (a->sigma0_cr ? pad(max_px * es) : 0);
+        const size_t list_cap = std::max<size_t>(max_px / 4, 1 << 14) & ~(size_t)1, mask_strips = strips_for((long long)max_px, lpc);
+        const size_t o_masks = o_end + pad((XSW_LISTS_TOTAL * list_cap + 16) * sizeof(unsigned)), dev_bytes = o_masks + 2 * mask_strips * sizeof(unsigned long long);
+        const int dtype = a->dtype, out_dtype = a->out_dtype;
+        auto shift = [](const void *p, size_t bytes) -> const void * { return p ? (const char *)p + bytes : nullptr; };
+        const int rc_all = run_chunks(c, nchunks, [&](long long k, xsw_ctx::Worker &w, std::string &err) -> int {
+            int rc = worker_reserve(w, o_end, dev_bytes, err);
+            if (rc) return rc;
+            const long long l0 = k * lpc, l1 = std::min(lines, l0 + lpc);
+            const size_t px0 = (size_t)l0 * samples, npx = (size_t)(l1 - l0) * samples;
+            hipError_t e = hipSuccess;
+            auto up = [&](int which, const void *h, size_t off) {
+                if (!h || e != hipSuccess || rc) return;
+                int staged = 0;
+                if (a->stage) {
+                    staged = a->stage(a->stage_user, which, (int64_t)px0, (int64_t)npx, w.pin + off);
+                    if (staged < 0) { rc = seterr(err, XSW_EINVAL, "the staging callback failed for raster %d, pixels [%zu, %zu)", which, px0, px0 + npx); return; }
+                }
+                if (staged <= 0) memcpy(w.pin + off, (const char *)h + px0 * es, npx * es);
+                e = hipMemcpyAsync(w.dev + off, w.pin + off, npx * es, hipMemcpyHostToDevice, w.s);
+            };
+            up(1, a->sigma0_co, o_co); up(2, a->sigma0_cr, o_cr);
+            if (rc) return rc;
+            if (e != hipSuccess) return seterr(err, XSW_EHIP, "H2D copy failed: %s", hipGetErrorString(e));
+            KArgs B = A;
+            B.lines = l1 - l0;
+            B.n = (long long)npx;
+            B.inc = shift(a->inc, px0 * es);
+            B.s_co = a->sigma0_co ? w.dev + o_co : nullptr;
+            B.s_cr = a->sigma0_cr ? w.dev + o_cr : nullptr;
+            B.dsig_cr = shift(a->dsig_cr, px0 * es);
+            B.anc = shift(a->anc, px0 * es * 2);
+            B.out_co = (void *)shift(a->out_co, px0 * os);
+            B.out_cr = (void *)shift(a->out_cr, px0 * os);
+            B.code_co = (unsigned *)shift(a->out_code_co, px0 * 4);
+            B.code_cr = (unsigned *)shift(a->out_code_cr, px0 * 4);
+            const LaunchCtl lc{w.s, (unsigned *)(w.dev + o_end), list_cap, false, (unsigned long long *)(w.dev + o_masks), mask_strips};
+            rc = dispatch_invert(c, B, dtype, out_dtype, algo, lc, err);
+            if (rc) return rc;
+            e = hipStreamSynchronize(w.s);
+            return e == hipSuccess ? XSW_OK : seterr(err, XSW_EHIP, "kernel execution failed: %s", hipGetErrorString(e));
+        });
+        trim_staging(c);
+        return rc_all;
     }
 
     // Host rasters.  Chunks of whole 4-line tile rows (~2 Mpx) go through the workers: stage the chunk's inputs into the

@@ -330,9 +330,10 @@ __device__ __forceinline__ void mask_mark(unsigned long long *__restrict__ mask,
 // flags / my_flat: the lane's pixel class and winning flat index (-1: no co-pol answer yet).  strip: the wave's pixels are strip
 // `strip` of the raster (lane = sample); -1: listed pixels.
 template <typename T, typename TO, bool CR, bool COUNT>
-__device__ __forceinline__ void wave_tail(const DevTables &L, const KArgs &A, long long i, bool in, int lane, int flags, int my_flat, bool to_b, bool to_c,
-                                          long long strip, unsigned cand)
+__device__ __forceinline__ void wave_tail(const DevTables &L, const KArgs &A, long long i, bool in, int lane, int flags, int my_flat, long long strip,
+                                          unsigned cand)
 {
+    const bool to_b = A.list_b != nullptr && (flags & F_TO_B) != 0, to_c = (flags & F_TO_C) != 0;  // (they ride in `flags`: no register of their own through the passes)
     const double nan = __builtin_nan("");
     int my_icr = -1;
     const bool need_co = (flags & F_NEED_CO) != 0;
@@ -409,9 +410,9 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
     constexpr int NC = 11;  // window classes: S lanes x K directions = 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128 (and wider: chunks)
     int pos = -1, first[NC] = {}, ncls[NC] = {};  // slot of this lane's pixel; slot range of each class
     bool skip = false;        // ROLE 2 walking every strip (list B overflowed): not one of the long-run pixels this kernel is for
-    bool to_b = false;        // ROLE 1: left to the second band kernel (list B) -- its band holds a long run of rows
-    bool to_c = false;        // left to k_invert_blocks (list C): a finite pixel the band rule is not for -- its window leaves the monotone
-                              // rows, or its band holds more rows / candidates than k_invert_band2 takes
+    // (F_TO_B in `flags`: ROLE 1, left to the second band kernel -- its band holds a long run of rows; F_TO_C: left to
+    // k_invert_blocks -- a finite pixel the band rule is not for: its window leaves the monotone rows, or its band holds more rows /
+    // candidates than k_invert_band2 takes)
     {
         // ---- stage 1, one pixel per lane: classify, incidence bin, upper bound along the a-priori direction, window
         Pixel P;
@@ -455,7 +456,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
             const bool need = (P.flags & F_NEED_CO) != 0 && (P.flags & F_CO_FINITE) != 0 && ncols_p >= 1 && (nrows_p >= 1 || has_tail);
             if (ROLE == 2 && strip_walk) skip = !need || !(w_hi_e < L.mono_rows[need ? P.i_inc : 0]);  // everything k_invert_band did not hand over
             eligb = need && w_hi_e < L.mono_rows[need ? P.i_inc : 0];  // the window stays inside the monotone rows
-            if (ROLE != 2) to_c = need && !eligb;
+            if (ROLE != 2 && need && !eligb) flags |= F_TO_C;
             if (COUNT) cand += (unsigned)__popcll(__ballot(eligb)) * (unsigned)(2 * (32 - __clz((L.n_w + 1) >> 1)) + (XSW_BAND_RAYS - 1) * 2 * XSW_RAY_SIDE_STEPS);
             // class of a window by its number of (virtual) columns n: the smallest of 4, 6, 8, 12, ..., 96, 128 that holds it, i.e. S lanes
             // x K directions per lane with K = 2 (capacity 2S) or 3 (capacity 3S, S half as large: twice the pixels per pass of
@@ -509,13 +510,13 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                     myc = NC;
                     eligb = false;
                     if (ROLE == 2) skip = true;
-                    if (ROLE == 1) to_c = true;
+                    if (ROLE == 1) flags |= F_TO_C;
                 }
                 const bool handed = eligb && (run >= A.long_run || has_tail);  // (a tail is k_invert_band2's whatever the run's length)
                 if (ROLE == 1 && handed) {  // the second band kernel's
                     myc = NC;
                     eligb = false;
-                    to_b = true;
+                    flags |= F_TO_B;
                 }
                 if (ROLE == 2 && eligb && !handed) {  // k_invert_band has dealt with it (decided, or listed)
                     myc = NC;
@@ -594,7 +595,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
         skip = skip || (flags & F_NEED_CO) == 0;
         in = in && !skip;
     }
-    wave_tail<T, TO, CR, COUNT>(L, A, i, in, lane, flags, my_flat, A.list_b != nullptr && to_b, to_c, strip, cand);
+    wave_tail<T, TO, CR, COUNT>(L, A, i, in, lane, flags, my_flat, strip, cand);
 }
 
 template <typename T, typename TO, bool CR, bool COUNT, int ROLE = 0>

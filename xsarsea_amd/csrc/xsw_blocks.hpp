@@ -318,7 +318,7 @@ __device__ __forceinline__ void blocks_wave(const DevTables &L, const KArgs &A, 
             }
         }
     }
-    wave_tail<T, TO, CR, true>(L, A, i, in, lane, flags, my_flat, false, false, -1, cand);  // (COUNT: the statistics are a run-time switch here)
+    wave_tail<T, TO, CR, true>(L, A, i, in, lane, flags, my_flat, -1, cand);  // (COUNT: the statistics are a run-time switch here)
 }
 
 // Third kernel of the chain: the pixels k_invert_band left on list C, 64 per wave (fewer when the list is short: the passes of

@@ -114,7 +114,8 @@ enum : unsigned { K_CODE_NAN_RE = 0xFFFFFFFFu /* (nan, 0) */, K_CODE_NAN = 0xFFF
                   K_CODE_PICK_CO = 0x40000000u, K_CODE_NO_INDEX = 0x3FFFFFFFu };
 
 enum : int { F_NEED_CO = 1, F_NEED_CR = 2, F_EARLY_NAN = 4, F_CO_FINITE = 8, F_CR_RAW_NAN = 16 /* band kernel: a raw cross-pol input is NaN */,
-             F_CO_LOOSE = 32 /* general kernel: finite inputs, but a bound far above the scale of the scores: block pyramid, no forward differences */ };
+             F_CO_LOOSE = 32 /* general kernel: finite inputs, but a bound far above the scale of the scores: block pyramid, no forward differences */,
+             F_TO_B = 64, F_TO_C = 128 /* band kernels: the pixel is list B's (k_invert_band2) / list C's (k_invert_blocks) if it is still undecided at the end of the wave */ };
 
 // ------------------------------------------------------------------------------------------------
 // wave64 helpers
