@@ -668,7 +668,8 @@ for scale, inc_lo, inc_hi in ((1.0, 17.0, 25.0), (1.6, 20.0, 36.0), (2.5, 30.0, 
 """
 
 
-@pytest.mark.parametrize("long_run,list_cap", [(None, None), (None, "300"), ("1", None), ("1", "300"), ("0", None), (None, "300-nomask")])
+@pytest.mark.parametrize("long_run,list_cap", [(None, None), (None, "300"), ("1", None), ("1", "300"), ("0", None), (None, "300-nomask"),
+                                               (None, "norecords"), (None, "300-norecords")])
 def test_long_run_kernel(long_run, list_cap):
     """The three-kernel chain in a fresh process: k_invert_band hands the pixels whose band holds XSW_LONG_RUN (default 4) or more
     rows along the a-priori direction to k_invert_band2 (batched sweeps clipped to the disc's chord).  Four scenes from friendly
@@ -680,13 +681,16 @@ def test_long_run_kernel(long_run, list_cap):
     import subprocess
     import sys
     from conftest import REPO
-    env = {k: v for k, v in os.environ.items() if k not in ("XSW_LONG_RUN", "XSW_NO_STRIP_MASKS")}
+    env = {k: v for k, v in os.environ.items() if k not in ("XSW_LONG_RUN", "XSW_NO_STRIP_MASKS", "XSW_NO_RECORDS")}
     if long_run is not None:
         env["XSW_LONG_RUN"] = long_run
     if list_cap:
-        env["XSW_LIST_CAP_TEST"] = list_cap.split("-")[0]
+        if list_cap.split("-")[0].isdigit():
+            env["XSW_LIST_CAP_TEST"] = list_cap.split("-")[0]
         if list_cap.endswith("nomask"):
             env["XSW_NO_STRIP_MASKS"] = "1"
+        if list_cap.endswith("norecords"):  # list B as pixel indices (k_invert_band2 redoes stage 1) instead of records
+            env["XSW_NO_RECORDS"] = "1"
     r = subprocess.run([sys.executable, "-c", _BAND2_SCRIPT.format(repo=REPO)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     rows = [l.split() for l in r.stdout.splitlines() if l.startswith("RESULT")]

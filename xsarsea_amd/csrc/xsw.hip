@@ -636,12 +636,14 @@ static void ensure_list(xsw_ctx *c, long long n, long long lines)
     if (c->d_list) (void)hipFree(c->d_list);
     c->d_list = nullptr;
     c->d_masks = nullptr;
+    c->d_rec = nullptr;
     c->list_cap = c->mask_strips = 0;
     static const bool no_list = getenv("XSW_FAIL_LIST_ALLOC") != nullptr;  // tests: the allocation-failure route
     // lists G and B (`want` entries each) and C (XSW_LIST_C_SHARE x want), then the two strip masks (0.25 B per pixel)
-    if (!no_list && hipMalloc((void **)&c->d_list, (XSW_LISTS_TOTAL * want + 16) * sizeof(unsigned) + 2 * want_strips * sizeof(unsigned long long)) == hipSuccess) {
+    if (!no_list && hipMalloc((void **)&c->d_list, (XSW_LISTS_TOTAL * want + 16) * sizeof(unsigned) + 2 * want_strips * sizeof(unsigned long long) + want * XSW_REC_BYTES) == hipSuccess) {
         c->list_cap = want;
         c->d_masks = (unsigned long long *)(c->d_list + 16 + XSW_LISTS_TOTAL * want);
+        c->d_rec = (void *)(c->d_masks + 2 * want_strips);
         c->mask_strips = want_strips;
     } else { c->d_list = nullptr; (void)hipGetLastError(); }
 }
@@ -900,7 +902,7 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
         A.code_co = a->out_code_co; A.code_cr = a->out_code_cr;
         if (algo == XSW_ALGO_PRUNED) ensure_list(c, n, a->lines);
         std::string err;
-        const LaunchCtl lc{c->stream, c->d_list, c->list_cap, c->timing_on, c->d_masks, c->mask_strips};
+        const LaunchCtl lc{c->stream, c->d_list, c->list_cap, c->timing_on, c->d_masks, c->mask_strips, c->d_rec};
         int rc;
         if (a->lines < 16 && n >= (1LL << 16)) {
             // a flat raster (a long vector of pixels: 1-D inputs arrive as one line) is re-cut into lines of 4096 samples + a
@@ -944,7 +946,7 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
         auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
         const size_t o_co = 0, o_cr = o_co + (a->sigma0_co ? pad(max_px * es) : 0), o_end = o_cr + (a->sigma0_cr ? pad(max_px * es) : 0);
         const size_t list_cap = std::max<size_t>(max_px / 4, 1 << 14) & ~(size_t)1, mask_strips = strips_for((long long)max_px, lpc);
-        const size_t o_masks = o_end + pad((XSW_LISTS_TOTAL * list_cap + 16) * sizeof(unsigned)), dev_bytes = o_masks + 2 * mask_strips * sizeof(unsigned long long);
+        const size_t o_masks = o_end + pad((XSW_LISTS_TOTAL * list_cap + 16) * sizeof(unsigned)), o_rec = o_masks + 2 * mask_strips * sizeof(unsigned long long), dev_bytes = o_rec + list_cap * XSW_REC_BYTES;
         const int dtype = a->dtype, out_dtype = a->out_dtype;
         auto shift = [](const void *p, size_t bytes) -> const void * { return p ? (const char *)p + bytes : nullptr; };
         const int rc_all = run_chunks(c, nchunks, [&](long long k, xsw_ctx::Worker &w, std::string &err) -> int {
@@ -978,7 +980,7 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
             B.out_cr = (void *)shift(a->out_cr, px0 * os);
             B.code_co = (unsigned *)shift(a->out_code_co, px0 * 4);
             B.code_cr = (unsigned *)shift(a->out_code_cr, px0 * 4);
-            const LaunchCtl lc{w.s, (unsigned *)(w.dev + o_end), list_cap, false, (unsigned long long *)(w.dev + o_masks), mask_strips};
+            const LaunchCtl lc{w.s, (unsigned *)(w.dev + o_end), list_cap, false, (unsigned long long *)(w.dev + o_masks), mask_strips, (void *)(w.dev + o_rec)};
             rc = dispatch_invert(c, B, dtype, out_dtype, algo, lc, err);
             if (rc) return rc;
             e = hipStreamSynchronize(w.s);
@@ -1015,7 +1017,7 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
                  o_cc = o_anc + (a->anc ? pad(max_px * es * 2) : 0), o_ccr = o_cc + (want_co ? pad(max_px * 4) : 0),
                  o_end = o_ccr + (want_cr ? pad(max_px * 4) : 0);
     const size_t list_cap = std::max<size_t>(max_px / 4, 1 << 14) & ~(size_t)1, mask_strips = strips_for((long long)max_px, lines_per_chunk);
-    const size_t o_masks = o_end + pad((XSW_LISTS_TOTAL * list_cap + 16) * sizeof(unsigned)), dev_bytes = o_masks + 2 * mask_strips * sizeof(unsigned long long);  // lists G, B and C, strip masks
+    const size_t o_masks = o_end + pad((XSW_LISTS_TOTAL * list_cap + 16) * sizeof(unsigned)), o_rec = o_masks + 2 * mask_strips * sizeof(unsigned long long), dev_bytes = o_rec + list_cap * XSW_REC_BYTES;  // lists G, B and C, strip masks, list B's records
     const int dtype = a->dtype, out_dtype = a->out_dtype;
     static const bool prof = getenv("XSW_HOST_PROFILE") != nullptr;  // phase times of the pipeline on stderr (experiments)
     std::atomic<long long> t_stage{0}, t_gpu{0}, t_expand{0}, t_reserve{0};
@@ -1061,7 +1063,7 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
         B.anc = a->anc ? w.dev + o_anc : nullptr;
         B.code_co = want_co ? (unsigned *)(w.dev + o_cc) : nullptr;
         B.code_cr = want_cr ? (unsigned *)(w.dev + o_ccr) : nullptr;
-        const LaunchCtl lc{w.s, (unsigned *)(w.dev + o_end), list_cap, false, (unsigned long long *)(w.dev + o_masks), mask_strips};
+        const LaunchCtl lc{w.s, (unsigned *)(w.dev + o_end), list_cap, false, (unsigned long long *)(w.dev + o_masks), mask_strips, (void *)(w.dev + o_rec)};
         rc = dispatch_invert(c, B, dtype, out_dtype, algo, lc, err);
         if (rc) return rc;
         if (o_end > o_cc) e = hipMemcpyAsync(w.pin + o_cc, w.dev + o_cc, o_end - o_cc, hipMemcpyDeviceToHost, w.s);

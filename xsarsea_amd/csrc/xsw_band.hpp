@@ -106,6 +106,12 @@ struct BandSlot {  // 64 bytes per pixel, read by every lane of its segment (sam
     int bin_hi /* threshold bin above s + d, or -1 */;
 };
 
+struct BandRec {  // what k_invert_band hands to k_invert_band2 per pixel (KArgs::rec_b): 72 bytes, written and read coalesced
+    BandSlot slot;  // (bin_hi in k_invert_band2's encoding: the window's tail rows in its upper half)
+    unsigned idx;   // pixel index
+    int flags;      // the pixel's class bits (+ its incidence bin << 8 for the cross-pol phase)
+};
+
 __device__ __forceinline__ unsigned long long ballot64(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 __device__ __forceinline__ double ld_co(const char *__restrict__ base, unsigned off0, int row, unsigned rowB)
 {
@@ -368,7 +374,8 @@ __device__ __forceinline__ void wave_tail(const DevTables &L, const KArgs &A, lo
     // is marked in the list's strip mask -- KArgs::mask_g / mask_b, zeroed before every launch, touched only when a list overflows --
     // and the consumer takes the list, then the marked pixels)
     bool drop_b = false, drop_c = false;
-    if (A.list_b) drop_b = list_append(A.list_b_count, A.list_b, A.list_b_cap, unresolved && to_b, i, lane);
+    // (with records, a pixel that is still list B's here is one whose record did not fit -- counted already: straight to the mask)
+    if (A.list_b) drop_b = A.rec_b ? (unresolved && to_b) : list_append(A.list_b_count, A.list_b, A.list_b_cap, unresolved && to_b, i, lane);
     if (A.list_c) drop_c = list_append(A.list_c_count, A.list_c, A.list_c_cap, unresolved && to_c && !to_b, i, lane);
     const bool for_c = A.list_c != nullptr && to_c && !to_b && !drop_c;
     const bool drop_g = list_append(A.list_count, A.list, A.list_cap, unresolved && !to_b && !for_c, i, lane);
@@ -544,14 +551,38 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                 const int added = (ncls[c + 1] + rem + npn - 1) / npn - (ncls[c + 1] + npn - 1) / npn;
                 if (rem > 0 && added == 0) { ncls[c] -= rem; ncls[c + 1] += rem; first[c + 1] -= rem; }
             }
-            if (eligb) {
-                BandSlot b;
+            const bool to_rec = ROLE == 1 && A.rec_b != nullptr && (flags & F_TO_B) != 0;
+            BandSlot b;
+            if (eligb || to_rec) {
                 const double ah = 0.5 * P.a_re, bh = 0.5 * P.b_eff;
                 b.sn = -P.s_co * A.inv_dsig_co; b.thr_lo = thr_lo; b.thr_hi = thr_hi;
                 b.ah = ah; b.bh = bh; b.m2 = ah * ah + bh * bh;
                 b.inc_bin = P.i_inc | (bin << 16); b.rows = W.w_lo | (w_hi_e << 16); b.ipn = W.ip_lo | (ncols_p << 16);
                 b.bin_hi = bhi < XSW_INV_BINS ? bhi : -1;
-                if (ROLE == 2) b.bin_hi = (b.bin_hi & 0xffff) | ((has_tail ? W.w_hi - w_hi_e : 0) << 16);  // co_band_pass: rows past the monotone ones
+                // k_invert_band2's slots (its own, and the records written for it) carry the window's tail rows in the upper half
+                if (ROLE == 2 || to_rec) b.bin_hi = (b.bin_hi & 0xffff) | ((has_tail ? W.w_hi - w_hi_e : 0) << 16);
+            }
+            if (ROLE == 1 && A.rec_b != nullptr) {
+                // the handed pixels' RECORDS (their search parameters: k_invert_band2 then neither gathers the rasters again nor
+                // redoes stage 1), appended compactly, one atomicAdd per wave; a record that does not fit leaves the pixel to the
+                // overflow route (wave_tail: the list's strip mask; k_invert_band2 redoes stage 1 for the marked pixels)
+                const unsigned long long hm = __ballot(to_rec);
+                if (hm) {
+                    unsigned at0 = 0;
+                    if (lane == 0) at0 = atomicAdd(A.list_b_count, (unsigned)__popcll(hm));
+                    at0 = (unsigned)__builtin_amdgcn_readfirstlane((int)at0);
+                    const unsigned at = at0 + __builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
+                    if (to_rec && at < A.list_b_cap) {
+                        BandRec r;
+                        r.slot = b;
+                        r.idx = (unsigned)i;
+                        r.flags = flags & ~F_TO_B;
+                        ((BandRec *)A.rec_b)[at] = r;
+                        flags |= F_REC_DONE;
+                    }
+                }
+            }
+            if (eligb) {
                 slots[pos] = b;
 #ifdef XSW_TIMING_STAGE1_ONLY
                 res_[pos] = 0;   // (timing build: pretend the pass decided, so that nothing floods the work list)
@@ -591,11 +622,78 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (pos >= 0) my_flat = res_[pos];  // -1: undecided by its pass
+    if (ROLE == 1 && (flags & F_REC_DONE) != 0) in = false;  // its record is k_invert_band2's: no cross-pol search, no list, no store here
     if (ROLE == 2 && strip_walk) {  // strip walk: lanes without a co-pol search, and the pixels k_invert_band kept, are not this kernel's
         skip = skip || (flags & F_NEED_CO) == 0;
         in = in && !skip;
     }
     wave_tail<T, TO, CR, COUNT>(L, A, i, in, lane, flags, my_flat, strip, cand);
+}
+
+// k_invert_band2 on RECORDS: lane l takes record l of the wave's 64 -- the slot stage 1 of k_invert_band built -- sorts the slots by
+// window class as stage 1 does, runs the batched, chord-clipped passes and finishes with wave_tail (cross-pol phase, store; what
+// a pass cannot decide goes to k_invert_list's list).
+template <typename T, typename TO, bool CR>
+__device__ __forceinline__ void band_wave_rec(const DevTables &L, const KArgs &A, const BandRec &r, bool in, int lane, BandSlot *__restrict__ slots,
+                                              int *__restrict__ res_)
+{
+    constexpr int NC = 11;
+    int pos = -1, first[NC] = {}, ncls[NC] = {};
+    unsigned cand = 0;
+    {
+        const int nv = (int)((unsigned)r.slot.ipn >> 16);
+        const int p2 = 31 - __clz(max(nv, 2) - 1);
+        const int myc = !in ? NC : (nv <= 4 ? 0 : min(2 * p2 - 3 + (nv > (3 << (p2 - 1)) ? 1 : 0), NC - 1));
+        int base = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const unsigned long long m = __ballot(myc == c);
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            pos = myc == c ? base + rank : pos;
+            first[c] = base;
+            ncls[c] = __popcll(m);
+            base += ncls[c];
+        }
+#pragma unroll
+        for (int c = 0; c + 1 < NC; ++c) {  // part-filled last passes promoted into the next class (band_wave)
+            const int np = 64 / (2 << (c >> 1)), npn = 64 / (2 << ((c + 1) >> 1));
+            const int rem = ncls[c] % np;
+            const int added = (ncls[c + 1] + rem + npn - 1) / npn - (ncls[c + 1] + npn - 1) / npn;
+            if (rem > 0 && added == 0) { ncls[c] -= rem; ncls[c + 1] += rem; first[c + 1] -= rem; }
+        }
+        if (in) {
+            slots[pos] = r.slot;
+            res_[pos] = -1;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+        auto run = [&](auto seg, auto kk, int c) {
+            constexpr int S = decltype(seg)::value, K = decltype(kk)::value;
+            for (int p = 0; p < ncls[c]; p += 64 / S)
+                co_band_pass<S, K, false, true>(L, A.inv_dsig_co, lane, slots, res_, first[c] + p, min(64 / S, ncls[c] - p), cand);
+        };
+        using two = std::integral_constant<int, 2>;
+        using three = std::integral_constant<int, 3>;
+        run(std::integral_constant<int, 2>{}, two{}, 0);
+        run(std::integral_constant<int, 2>{}, three{}, 1);
+        run(std::integral_constant<int, 4>{}, two{}, 2);
+        run(std::integral_constant<int, 4>{}, three{}, 3);
+        run(std::integral_constant<int, 8>{}, two{}, 4);
+        run(std::integral_constant<int, 8>{}, three{}, 5);
+        run(std::integral_constant<int, 16>{}, two{}, 6);
+        run(std::integral_constant<int, 16>{}, three{}, 7);
+        run(std::integral_constant<int, 32>{}, two{}, 8);
+        run(std::integral_constant<int, 32>{}, three{}, 9);
+        run(std::integral_constant<int, 64>{}, two{}, 10);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int my_flat = pos >= 0 ? res_[pos] : -1;
+    wave_tail<T, TO, CR, false>(L, A, (long long)r.idx, in, lane, r.flags, my_flat, -1, cand);
 }
 
 template <typename T, typename TO, bool CR, bool COUNT, int ROLE = 0>
@@ -649,8 +747,13 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND2_WAVES) void k_inv
     for (long long c = (long long)blockIdx.x * XSW_BAND_WG_WAVES + wv; c * 64 < nlist; c += nwaves) {  // wave-uniform
         const long long k = c * 64 + lane;
         const bool in = k < nlist;
-        const long long i = (long long)A.list_b[in ? k : nlist - 1];
-        band_wave<T, TO, CR, false, 2>(L, A, i, in, lane, slots[wv], res_[wv]);
+        if (A.rec_b) {  // records: the slots as k_invert_band built them
+            const BandRec r = ((const BandRec *)A.rec_b)[in ? k : nlist - 1];
+            band_wave_rec<T, TO, CR>(L, A, r, in, lane, slots[wv], res_[wv]);
+        } else {
+            const long long i = (long long)A.list_b[in ? k : nlist - 1];
+            band_wave<T, TO, CR, false, 2>(L, A, i, in, lane, slots[wv], res_[wv]);
+        }
         __builtin_amdgcn_wave_barrier();
     }
     if (count > (long long)A.list_b_cap) {

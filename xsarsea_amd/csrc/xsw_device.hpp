@@ -91,6 +91,8 @@ struct KArgs {
     unsigned list_cap;          // entries the list holds; the counter runs on past it (overflow: k_invert_list takes every tile)
     unsigned *list_b, *list_b_count;  // list B (nullable): pixels k_invert_band hands to k_invert_band2 (long runs of band rows; rise-then-fall columns)
     unsigned list_b_cap;
+    void *rec_b;                // nullable: list B as RECORDS (BandRec, xsw_band.hpp: the pixel's search parameters as stage 1 of k_invert_band built
+                                // them, 72 bytes) instead of pixel indices -- k_invert_band2 then neither gathers the rasters again nor redoes stage 1
     unsigned *list_c, *list_c_count;  // list C (nullable): finite pixels the band rule is not for, k_invert_band -> k_invert_blocks (block pyramid, four pixels per wave at a time)
     unsigned list_c_cap;
     // one 64-bit word per strip of 64 samples (strip = line * ceil(samples / 64) + strip column; nullable): bit l of mask_g =
@@ -115,6 +117,7 @@ enum : unsigned { K_CODE_NAN_RE = 0xFFFFFFFFu /* (nan, 0) */, K_CODE_NAN = 0xFFF
 
 enum : int { F_NEED_CO = 1, F_NEED_CR = 2, F_EARLY_NAN = 4, F_CO_FINITE = 8, F_CR_RAW_NAN = 16 /* band kernel: a raw cross-pol input is NaN */,
              F_CO_LOOSE = 32 /* general kernel: finite inputs, but a bound far above the scale of the scores: block pyramid, no forward differences */,
+             F_REC_DONE = 256 /* k_invert_band: the pixel's record is on list B: nothing more to do for it in this wave */,
              F_TO_B = 64, F_TO_C = 128 /* band kernels: the pixel is list B's (k_invert_band2) / list C's (k_invert_blocks) if it is still undecided at the end of the wave */ };
 
 // ------------------------------------------------------------------------------------------------

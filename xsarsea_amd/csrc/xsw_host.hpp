@@ -28,6 +28,7 @@ struct xsw_ctx {
     unsigned *d_list = nullptr;  // hand-over k_invert_band -> k_invert_list: [0] = count, [16..] = pixel indices
     size_t list_cap = 0;         // entries (context-owned, grown on demand: an eighth of the largest raster seen)
     unsigned long long *d_masks = nullptr;  // strip masks (2 x mask_strips words, after the lists in the same allocation)
+    void *d_rec = nullptr;                  // list B's records (after the masks)
     size_t mask_strips = 0;
     double *d_ratio = nullptr;  // detrend ratio row (context-owned, grown on demand)
     size_t ratio_cap = 0;
@@ -77,6 +78,7 @@ struct LaunchCtl {
     bool timing;       // xsw_timing_enable events (context stream only)
     unsigned long long *masks = nullptr;  // strip masks (KArgs::mask_g, then mask_b), mask_strips words each; nullptr: none
     size_t mask_strips = 0;
+    void *rec_b = nullptr;  // list_cap records of XSW_REC_BYTES (KArgs::rec_b); nullptr: list B holds pixel indices
 };
 
 
@@ -87,6 +89,7 @@ struct LaunchCtl {
 #define XSW_LIST_C_SHARE 4
 #endif
 #define XSW_LISTS_TOTAL (2 + XSW_LIST_C_SHARE)
+#define XSW_REC_BYTES 72  // sizeof(BandRec) (xsw_band.hpp; static_assert in xsw_invert_tu.hip): list B's records follow the strip masks
 
 // One (input dtype, output dtype) pair of the inversion launches per translation unit (xsw_invert_tu.hip, -DXSW_PAIR=0..3:
 // f32->f32, f32->f64, f64->f32, f64->f64), so that the four sets of kernel instantiations compile side by side.

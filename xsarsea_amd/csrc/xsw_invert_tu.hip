@@ -51,6 +51,9 @@ static int launch_invert(xsw_ctx *c, const KArgs &A_in, int algo, const LaunchCt
         static const int long_run_env = getenv("XSW_LONG_RUN") ? std::max(0, atoi(getenv("XSW_LONG_RUN"))) : 4;
         const bool band2 = long_run_env > 0 && !A.stats;
         if (band2) { B.list_b_count = lc.list + 1; B.list_b = lc.list + 16 + lc.list_cap; B.list_b_cap = B.list_cap; }
+        static const bool records_off = getenv("XSW_NO_RECORDS") != nullptr;  // A/B measurements and the tests of the index-list route
+        static_assert(sizeof(BandRec) == XSW_REC_BYTES, "XSW_REC_BYTES (xsw_host.hpp) is sizeof(BandRec)");
+        B.rec_b = (band2 && !records_off) ? lc.rec_b : nullptr;
         // list C (k_invert_band -> k_invert_blocks): the finite pixels the band rule is not for.  XSW_NO_BLOCKS_KERNEL=1: they stay on
         // list G, i.e. with k_invert_list (A/B measurements and the tests of that route)
         static const bool blocks_kernel_off = getenv("XSW_NO_BLOCKS_KERNEL") != nullptr;
