@@ -339,3 +339,32 @@ def test_staging_callback_contract(gpu_ctx, default_luts):
     from xsarsea_amd import _lib
     with pytest.raises(_lib.XswError, match="not a pointer of xsw_host_alloc"):
         gpu_ctx._check(gpu_ctx._lib.xsw_host_free(gpu_ctx._h, ctypes.c_void_p(got[0].ctypes.data)), "xsw_host_free")
+
+
+def test_staging_is_released(gpu_ctx, default_luts):
+    """the page-locked / device staging of the host workers is not kept for the life of the process -- lowering
+    the worker count frees the surplus workers at once, XSW_STAGING_KEEP_MB=0 (fresh process: read once) releases everything after
+    each call; results stay those of the default configuration."""
+    lco, _ = default_luts
+    co, _ = lut_dicts(lco, None)
+    gpu_ctx.upload_luts(co=co)
+    inc, s_vv, _, _, anc = synthetic_scene(1024, 4096, np.float32, 3)  # 4.2 Mpx: sixteen chunks, every worker gets one
+    ref = gpu_ctx.invert_host(inc, sigma0_co=s_vv, anc=anc, out_dtype=np.complex64)[0]
+    try:
+        gpu_ctx.set_host_threads(2)   # ten workers' buffers go back now
+        a = gpu_ctx.invert_host(inc, sigma0_co=s_vv, anc=anc, out_dtype=np.complex64)[0]
+        gpu_ctx.set_host_threads(12)  # ... and are pinned again on demand
+        b = gpu_ctx.invert_host(inc, sigma0_co=s_vv, anc=anc, out_dtype=np.complex64)[0]
+    finally:
+        gpu_ctx.set_host_threads(0)
+    assert np.array_equal(a.view(np.int32), ref.view(np.int32)) and np.array_equal(b.view(np.int32), ref.view(np.int32))
+    script = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {REPO!r}); sys.path.insert(0, {REPO!r} + '/tests')\n"
+        "from oracle import lut as olut\nfrom util import lut_dicts\nfrom test_gpu_kernel import synthetic_scene\nfrom xsarsea_amd import _lib\n"
+        "ctx = _lib.Context(0); ctx.upload_luts(co=lut_dicts(olut.to_lut('gmf_cmod5n', resolution='low'), None)[0])\n"
+        "inc, s, _, _, anc = synthetic_scene(512, 4096, np.float32, 3)\n"
+        "r = [ctx.invert_host(inc, sigma0_co=s, anc=anc, out_dtype=np.complex64)[0] for _ in range(3)]\n"
+        "print('SAME', int(all(np.array_equal(r[0].view(np.int32), x.view(np.int32)) for x in r[1:])))\n")
+    r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, XSW_STAGING_KEEP_MB="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SAME 1" in r.stdout, r.stderr[-1500:]

@@ -202,7 +202,7 @@ def test_bench_line_contract(tmp_path):
         assert k in p, k
     assert p["pixels_outside_1e-4_host_db"] == 0 and p["frac_outside_1e-4_device_db"] < 1e-3
     e2e = j["parity_config_end_to_end"]
-    assert e2e["value"] > 0 and abs(e2e["host_log10_ms"] + e2e["upload_ms"] + e2e["kernels_ms"] - e2e["ms"]) < 0.5
+    assert e2e["value"] > 0 and e2e["ms"] > 0 and e2e["bytes_over_pcie"] == 4 * 768 * 2048  # sigma0 alone crosses the link (XSW_MEM_DEVICE_SIGMA0_HOST)
     hp = j["host_path"]
     assert hp["value"] > 0 and hp["roofline"]["bound"] == "pcie" and hp["bytes_over_pcie"] == 20 * 768 * 2048
     assert "numpy_restatement" in cb and cb["numpy_restatement"]["equals_c_port"] is True

@@ -551,6 +551,11 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                 const int added = (ncls[c + 1] + rem + npn - 1) / npn - (ncls[c + 1] + npn - 1) / npn;
                 if (rem > 0 && added == 0) { ncls[c] -= rem; ncls[c + 1] += rem; first[c + 1] -= rem; }
             }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {  // wave-uniform by construction: say so (they live in SGPRs through the passes, not in VGPRs)
+                first[c] = __builtin_amdgcn_readfirstlane(first[c]);
+                ncls[c] = __builtin_amdgcn_readfirstlane(ncls[c]);
+            }
             const bool to_rec = ROLE == 1 && A.rec_b != nullptr && (flags & F_TO_B) != 0;
             BandSlot b;
             if (eligb || to_rec) {
@@ -592,6 +597,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
             }
         }
     }
+    res_[64 + lane] = pos;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -621,6 +627,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    pos = res_[64 + lane];
     if (pos >= 0) my_flat = res_[pos];  // -1: undecided by its pass
     if (ROLE == 1 && (flags & F_REC_DONE) != 0) in = false;  // its record is k_invert_band2's: no cross-pol search, no list, no store here
     if (ROLE == 2 && strip_walk) {  // strip walk: lanes without a co-pol search, and the pixels k_invert_band kept, are not this kernel's
@@ -701,7 +708,8 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, CR ? XSW_BAND_WAVES_CR : XS
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ BandSlot slots[XSW_BAND_WG_WAVES][64];  // search parameters of the wave's eligible pixels, sorted by window class
-    __shared__ int res_[XSW_BAND_WG_WAVES][64];        // slot -> winning flat index (or -1)
+    __shared__ int res_[XSW_BAND_WG_WAVES][128];       // [0, 64): slot -> winning flat index (or -1); [64, 128): lane -> its pixel's slot
+                                                       // (parked here through the passes: one VGPR less where the pressure peaks)
     // same tile walk as k_invert (XCD x owns a contiguous range of tile columns, line groups fastest), as a 2-D grid so that
     // no division is needed: blockIdx.x = xcd + 8 * line group, blockIdx.y = tile column inside the XCD's range (workgroups
     // are dealt to the XCDs round-robin in linear order, x fastest: the XCD of a workgroup is still blockIdx.x & 7)
@@ -725,7 +733,7 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND2_WAVES) void k_inv
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ BandSlot slots[XSW_BAND_WG_WAVES][64];
-    __shared__ int res_[XSW_BAND_WG_WAVES][64];
+    __shared__ int res_[XSW_BAND_WG_WAVES][128];
     const long long count = (long long)*A.list_b_count;
     const long long nwaves = (long long)gridDim.x * XSW_BAND_WG_WAVES;
     const long long strips_per_line = (A.samples + 63) >> 6, nstrips = strips_per_line * A.lines;
