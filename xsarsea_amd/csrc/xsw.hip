@@ -517,6 +517,8 @@ static int install_co(xsw_ctx *c, const xsw_lut *l, const double *d_dense)
                   (l->phi[nP - 1] - l->phi[0]) <= 360.0 + 1e-9 && lut_finite)
                      ? 1 : 0;
     T.co_off32 = ((uint64_t)nI * nW + 260) * (uint64_t)ppad * 8u < ((uint64_t)1 << 32) ? 1 : 0;
+    T.band_mul24 = ((uint64_t)nI * nW <= 0xFFFFFFu && (uint64_t)(nI + 1) * XSW_INV_BINS <= 0xFFFFFFu && (uint64_t)ppad * 8u <= 0xFFFFFFu &&
+                    (uint64_t)(nI + 1) * nP <= 0xFFFFFFu && (uint64_t)wpad * 8u <= 0xFFFFFFu && (uint64_t)nI * nP * wpad * 8u < ((uint64_t)1 << 32)) ? 1 : 0;
     T.blk_span_ok = (nP > 1 && (XSW_BLK_C - 1) * (l->phi[nP - 1] - l->phi[0]) / (nP - 1) < 170.0) ? 1 : 0;
     // transposed slices for the ray scan
     double *dT = nullptr;

@@ -152,12 +152,15 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
     const char *__restrict__ base = (const char *)L.co;
     const unsigned rowB = (unsigned)L.phi_pad * 8u;
     const int i_inc = B.inc_bin & 0xffff;
-    const unsigned slice0 = (unsigned)(i_inc * L.n_w) * rowB;
+    // (24-bit multiplies: full rate, where v_mul_lo_u32 takes four issue slots -- four of them per lane and pass; the operands fit:
+    // the band kernels run only when n_inc * n_w and n_inc * XSW_INV_BINS stay below 2^24, xsw.hip: band_mul24)
+    const unsigned slice0 = mul24_sv(rowB, mul24_sv((unsigned)L.n_w, (unsigned)i_inc));
     // rows of the inverse table (2-byte entries, one per direction, < 4 GB: xsw.hip): the largest threshold <= s - d gives a
     // row at or below the band's first, the smallest threshold > s + d one past a row at or above its last
     const unsigned short *__restrict__ inv_tab = L.inv_rows;
-    const unsigned inv0 = (unsigned)(i_inc * XSW_INV_BINS + ((unsigned)B.inc_bin >> 16)) * (unsigned)L.phi_pad * 2u;
-    const unsigned inv1 = (unsigned)(i_inc * XSW_INV_BINS + max(B.bin_hi, 0)) * (unsigned)L.phi_pad * 2u;
+    const unsigned inv_rowB = (unsigned)L.phi_pad * 2u;
+    const unsigned inv0 = mul24_sv(inv_rowB, (unsigned)(i_inc * XSW_INV_BINS) + ((unsigned)B.inc_bin >> 16));
+    const unsigned inv1 = mul24_sv(inv_rowB, (unsigned)(i_inc * XSW_INV_BINS) + (unsigned)max(B.bin_hi, 0));
     constexpr bool CHORD = BATCH;
     double jrel = 0.0, inv_whs = 0.0;  // J_ub - |m|^2/4 (inflated); rows per unit of wh
     if (CHORD) {
@@ -448,7 +451,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                 const int mono1 = L.mono_rows[fin1 ? P.i_inc : 0];
                 if (fin1 && W.w_hi >= mono1 && W.ip_hi >= W.ip_lo) {
                     const int len = W.ip_hi - W.ip_lo + 1, k = min(31 - __clz(len), XSW_TAIL_LEVELS);
-                    const double *tk = L.tail_min + ((size_t)P.i_inc * (XSW_TAIL_LEVELS + 1) + k) * L.phi_pad;
+                    const double *tk = L.tail_min + mul24_sv((unsigned)L.phi_pad, (unsigned)(P.i_inc * (XSW_TAIL_LEVELS + 1) + k));
                     const double lo = fmin(tk[W.ip_lo], tk[k < XSW_TAIL_LEVELS ? W.ip_hi - (1 << k) + 1 : W.ip_lo]);
                     if (P.s_co + W.band_d < lo) w_hi_e = mono1 - 1;
                     // TAIL SWEEP (ROLE 1 / 2): the band does reach up there -- the flat top of a saturating GMF under speckle: the
@@ -498,10 +501,11 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                 // per SIMD); its strip walk repeats this per-pixel decision.
                 int run = 0;
                 if (eligb) {
-                    const unsigned short *tab = L.inv_rows + (size_t)P.i_inc * XSW_INV_BINS * L.phi_pad;
+                    // (32-bit element offsets by 24-bit multiplies: band_mul24, the table is < 4 GB)
+                    const unsigned tab0 = (unsigned)(P.i_inc * XSW_INV_BINS);
                     auto run_at = [&](int ip) {
-                        const int ra = (int)tab[(size_t)bin * L.phi_pad + ip];
-                        const int rb = bhi < XSW_INV_BINS ? (int)tab[(size_t)bhi * L.phi_pad + ip] : w_hi_e + 1;
+                        const int ra = (int)L.inv_rows[mul24_sv((unsigned)L.phi_pad, tab0 + (unsigned)bin) + (unsigned)ip];
+                        const int rb = bhi < XSW_INV_BINS ? (int)L.inv_rows[mul24_sv((unsigned)L.phi_pad, tab0 + (unsigned)bhi) + (unsigned)ip] : w_hi_e + 1;
                         return min(rb - 1, w_hi_e) - max(ra, W.w_lo) + 1;
                     };
                     run = run_at(P.ipr);  // (the window's first and last directions as well: hands over 3.5x the pixels for 2 ms less here, 4 ms more there)

@@ -46,6 +46,7 @@ struct DevTables {
     int phi_180;   // windspeed.py:152-156
     int prunable;  // uniform axes, finite LUT: branch-and-bound allowed
     int co_off32;  // the padded co table is < 4 GB: 32-bit byte offsets from its base address every word
+    int band_mul24;  // n_inc * n_w, n_inc * XSW_INV_BINS + XSW_INV_BINS and the row pitches fit 24 bits: the band kernels' offsets by v_mul_u32_u24
     const double *tail_min;  // [n_inc][XSW_TAIL_LEVELS + 1][phi_pad] sparse table over the directions of the smallest LUT value in rows >= mono_rows[i] (k_tail_min); nullable
     const int *mono_rows;  // [n_inc] every column of slice i is non-decreasing in wind speed over rows [0, mono_rows[i]) (band pruning)
     // inverse of the monotone rows (band pruning): inv_rows[i][b][p] = first row r < mono_rows[i] of column p with
@@ -144,6 +145,14 @@ __device__ __forceinline__ double vmax(double a, double b)
     return r;
 }
 
+// uniform (SGPR) x per-lane, both below 2^24: one full-rate v_mul_u32_u24 (the compiler turns __umul24 back into the quarter-rate
+// v_mul_lo_u32 when it can prove one operand short)
+__device__ __forceinline__ unsigned mul24_sv(unsigned uniform, unsigned v)
+{
+    unsigned r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "s"(uniform), "v"(v));
+    return r;
+}
 // DPP lane permutes (no LDS traffic): ctrl codes of the gfx9 family -- quad_perm 0x00-0xFF,
 // row_half_mirror 0x141, row_mirror 0x140, row_bcast:15 0x142, row_bcast:31 0x143.
 template <int CTRL, int ROW_MASK>
@@ -520,14 +529,18 @@ __device__ __forceinline__ CoWindow co_window_lanes(const DevTables &L, const Pi
         const int dq = ((q + 1) >> 1) * RAY_D + (q > 2 ? 1 : 0);  // 0, -D, +D, -(2D+1), +(2D+1), ...
         const int ipr = fin ? min(max(P.ipr + ((q & 1) ? -dq : dq), 0), L.n_phi - 1) : 0;
         const double ur = 2.0 * (ah * L.cphi[ipr] + bh * L.sphi[ipr]);
-        const double *__restrict__ ray = L.coT + ((size_t)(fin ? P.i_inc : 0) * L.n_phi + ipr) * L.w_pad;
+        // (band_mul24: the transposed table is < 4 GB and its row index < 2^24 -- a 32-bit byte offset by two full-rate multiplies
+        // instead of a 64-bit multiply, three quarter-rate instructions, per ray)
+        const double *__restrict__ ray =
+            L.band_mul24 ? (const double *)((const char *)L.coT + mul24_sv((unsigned)L.w_pad * 8u, mul24_sv((unsigned)L.n_phi, (unsigned)(fin ? P.i_inc : 0)) + (unsigned)ipr))
+                         : L.coT + ((size_t)(fin ? P.i_inc : 0) * L.n_phi + ipr) * L.w_pad;
         if (SEEDED && q == 0) {
             int lo = 0, hi = fin ? npairs : 0;
             int mid = npairs >> 1;
             if (fin) {
                 const double *g = L.inv_grid + 3 * P.i_inc;
                 const int bin = (int)fmin(fmax((s - g[0]) * g[2], 0.0), (double)(XSW_INV_BINS - 1));
-                mid = min((int)L.inv_rows[((size_t)P.i_inc * XSW_INV_BINS + bin) * L.phi_pad + ipr] >> 1, npairs - 1);
+                mid = min((int)L.inv_rows[mul24_sv((unsigned)L.phi_pad, (unsigned)(P.i_inc * XSW_INV_BINS + bin)) + (unsigned)ipr] >> 1, npairs - 1);  // (SEEDED implies band_mul24)
             }
             int stride = 1, state = 0;  // state: 0 first probe, 1 galloping right, 2 galloping left, 3 bisecting
 #pragma unroll 1

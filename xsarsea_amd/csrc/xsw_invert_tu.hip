@@ -38,7 +38,7 @@ static int launch_invert(xsw_ctx *c, const KArgs &A_in, int algo, const LaunchCt
     static const int block_min_env = getenv("XSW_BLOCK_MIN") ? std::max(0, atoi(getenv("XSW_BLOCK_MIN"))) : XSW_BLOCK_MIN;
     A.block_min = block_min_env;  // windows of at least this many candidates: block pyramid (general kernel)
     static const bool band_off = getenv("XSW_NO_BAND") != nullptr;  // experiments / A-B measurements only
-    if (algo == XSW_ALGO_PRUNED && !band_off && lc.list && A.s_co && c->T.prunable && c->T.mono_rows && c->T.inv_rows && c->T.co_off32 &&
+    if (algo == XSW_ALGO_PRUNED && !band_off && lc.list && A.s_co && c->T.prunable && c->T.mono_rows && c->T.inv_rows && c->T.co_off32 && c->T.band_mul24 &&
         (!A.s_cr || c->T.cr_monotone) && A.n < (1LL << 32)) {
         KArgs B = A;
         B.list_count = lc.list;
