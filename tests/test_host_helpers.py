@@ -78,3 +78,57 @@ def test_in_place_piecewise_db_equals_the_one_shot_expression(dtype):
                 np.log10(out, out=out)
                 np.multiply(out, 10, out=out)
         assert np.array_equal(ref.view(u), got.view(u)), (dtype, shift)
+
+
+def test_ensure_luts_never_leaves_a_stale_key():
+    """`ctx.lut_key` follows the context's tables install by install -- a co-pol install that succeeds followed by a
+    cross-pol install that fails must not leave the OLD co-pol key in place (a later call with the old LUT object would skip
+    the upload and search the wrong GMF); both LUTs' axes are validated before the context is touched."""
+    from xsarsea_amd.windspeed import _engine
+
+    class FakeCtx:
+        def __init__(self):
+            self.lut_key = (None, None)
+            self.installed = []
+
+        def upload_luts(self, co=None, cr=None):
+            if cr is not None and cr.get("boom"):
+                raise RuntimeError("cross-pol upload failed")
+            self.installed.append("co" if co is not None else "cr")
+
+    class L:  # stands in for a host Lut: _co_dict / _cr_dict are patched below
+        def __init__(self, boom=False):
+            self.boom = boom
+
+    old_co, new_co, bad_cr = L(), L(), L(boom=True)
+    co_dict, cr_dict = _engine._co_dict, _engine._cr_dict
+    _engine._co_dict = lambda lut: {"lut": lut}
+    _engine._cr_dict = lambda lut: {"lut": lut, "boom": lut.boom}
+    try:
+        ctx = FakeCtx()
+        _engine.ensure_luts(ctx, old_co, None)
+        assert ctx.lut_key == (old_co, None)
+        with pytest.raises(RuntimeError):
+            _engine.ensure_luts(ctx, new_co, bad_cr)
+        assert ctx.lut_key == (new_co, None)  # the co-pol table IS the new one; the cross-pol slot holds nothing
+        _engine.ensure_luts(ctx, old_co, None)  # the old LUT object is installed again, not skipped
+        assert ctx.lut_key == (old_co, None) and ctx.installed == ["co", "co", "co"]
+    finally:
+        _engine._co_dict, _engine._cr_dict = co_dict, cr_dict
+
+
+def test_a_one_entry_devices_list_is_honoured():
+    """options.devices = [3] means GPU 3, not options.device."""
+    import xsarsea_amd
+    from xsarsea_amd.windspeed import _engine
+    prev = xsarsea_amd.options.devices
+    try:
+        xsarsea_amd.options.devices = [3]
+        assert _engine._device_list() == [3]
+        xsarsea_amd.options.devices = None
+        assert _engine._device_list() is None
+        xsarsea_amd.options.devices = []
+        with pytest.raises(ValueError):
+            _engine._device_list()
+    finally:
+        xsarsea_amd.options.devices = prev
