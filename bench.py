@@ -1055,6 +1055,7 @@ def main():
             res["value_no_gather"] = dict(mg["no_gather"], n_gpus=n_gpus)
             if mode == "mono" and not args.no_extras:
                 res["host_path_all_devices"] = host_path_all_devices_figure(inc, s_vv, anc, samples, n_gpus)
+                torch.cuda.set_device(local_rank)  # (creating contexts on the other GPUs moved this thread's current device)
             res["multi_gpu"]["hardware_note"] = ("first hardware numbers of the N > 1 path come from the driver's scaling run: no multi-GPU node was available to the build "
                                                  "(rehearsed with gloo on one device)")
         if gather_ok is not None:
