@@ -682,101 +682,39 @@ def main():
         out_dual = torch.empty((lines, samples), dtype=torch.complex64, device=device)
     algo = _lib.ALGOS[args.algo]
 
-    # N > 1.  What travels to rank 0 is the answer as 4-byte GRID CODES (xsw_invert's out_code_*: the retrieved wind is a grid
-    # point), a quarter of the complex64 raster for mono (half for dual-pol, two codes); rank 0 expands the gathered codes
-    # to complex64 with one HBM-bound kernel (xsw_expand_codes) inside the timed step.  The tile is inverted in row chunks
-    # so that chunk k travels over xGMI while chunk k+1 is being inverted (RCCL runs on its own stream; requests are
-    # waited for at the end of the step).  Rank 0 writes its own codes straight into the gathered raster.
+    # N > 1: the library's own gathered tiling, `multi_gpu.TiledPipeline` through `multi_gpu.invert_tiled_device` -- what
+    # `multi_gpu.invert_from_model_tiled(gather=True)` runs for a user: the tile is inverted in row chunks to 4-byte GRID CODES
+    # (a quarter of the complex64 bytes; half for dual-pol), chunk k travels to rank 0 over xGMI while chunk k + 1 is inverted,
+    # rank 0 expands every chunk on a side stream as it lands.  Nothing of that choreography lives in this file.
     coded = world > 1
     n_chunks = 8 if world > 1 else 1
-    codes = codes_dual = full = full_dual = full_codes = full_codes_dual = None
-    if coded:
-        if rank == 0:
-            full_codes = torch.empty((total_lines, samples), dtype=torch.int32, device=device)
-            full = torch.empty((total_lines, samples), dtype=torch.complex64, device=device)
-            codes = full_codes[l0:l1]
-            if mode == "dual":
-                full_codes_dual = torch.empty((total_lines, samples), dtype=torch.int32, device=device)
-                full_dual = torch.empty((total_lines, samples), dtype=torch.complex64, device=device)
-                codes_dual = full_codes_dual[l0:l1]
-        else:
-            codes = torch.empty((lines, samples), dtype=torch.int32, device=device)
-            codes_dual = torch.empty((lines, samples), dtype=torch.int32, device=device) if mode == "dual" else None
-    pending = []
+    pipe = multi_gpu.TiledPipeline(total_lines, samples, dual=(mode == "dual"), device=device, dst=0, n_chunks=n_chunks,
+                                   out_dtype=torch.complex64) if coded else None
 
-    def invert_rows(r0, r1, s0_ptr=None, is_db=False, as_codes=False):
+    def invert_rows(r0, r1, s0_ptr=None, is_db=False):
         off = r0 * samples
         co_ptr = (s0_ptr if s0_ptr is not None else s_vv.data_ptr()) + off * 4
-        o_co = None if as_codes else out.data_ptr() + off * 8
-        c_co = codes.data_ptr() + off * 4 if as_codes else None
         if mode == "dual":
             ctx.invert_raw(r1 - r0, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, inc.data_ptr() + off * 4, co_ptr,
                            s_vh.data_ptr() + off * 4, dsig.data_ptr() + off * 4, anc.data_ptr() + off * 8,
-                           o_co, None if as_codes else out_dual.data_ptr() + off * 8, algo=algo, dual_select=True,
-                           sigma0_is_db=is_db, out_code_co=c_co, out_code_cr=codes_dual.data_ptr() + off * 4 if as_codes else None)
+                           out.data_ptr() + off * 8, out_dual.data_ptr() + off * 8, algo=algo, dual_select=True, sigma0_is_db=is_db)
         else:
             ctx.invert_raw(r1 - r0, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, inc.data_ptr() + off * 4, co_ptr,
-                           None, None, anc.data_ptr() + off * 8, o_co, None, algo=algo, sigma0_is_db=is_db, out_code_co=c_co)
-
-    stream_aware = backend == "nccl"  # RCCL orders a transfer after the work queued on the current stream; gloo (the one-GPU
-    # rehearsal) reads and writes the tensors' memory from the host with no regard for streams: synchronise around it
-
-    # Rank 0 expands chunk k of every rank's tile as soon as that chunk's codes are there -- on a side stream that waits for the
-    # chunk's receives (peers) and for the chunk's own kernels (rank 0's rows), through xsw_expand_codes_on_stream -- while the
-    # launch stream goes on inverting chunk k + 1: only the last chunk's expansion is exposed at the end of the step.
-    side = torch.cuda.Stream(device=device) if coded and rank == 0 else None
-    chunk_reqs = {}
-
-    def start_gather(k):
-        if not stream_aware:
-            torch.cuda.synchronize()
-        reqs = multi_gpu.gather_chunk_async(codes, total_lines, k, n_chunks, dst=0, out=full_codes, self_copy=False)
-        if mode == "dual":
-            reqs += multi_gpu.gather_chunk_async(codes_dual, total_lines, k, n_chunks, dst=0, out=full_codes_dual, self_copy=False)
-        chunk_reqs[k] = reqs
-        pending.extend(reqs)
-
-    def expand_chunk(k, own_done):
-        """rank 0: codes of chunk k (of every rank's tile) -> complex64, on the side stream"""
-        with torch.cuda.stream(side):
-            side.wait_event(own_done)      # rank 0's own rows of the chunk
-            for q in chunk_reqs.pop(k, []):
-                q.wait()                   # RCCL: the CURRENT (side) stream waits for the transfer; gloo: the host does
-            if not stream_aware:
-                torch.cuda.synchronize()
-            for r in range(world):
-                t0, t1 = multi_gpu.tile_bounds(total_lines, world, r)
-                c0, c1 = multi_gpu.chunk_bounds(t1 - t0, n_chunks, k)
-                if c1 <= c0:
-                    continue
-                off = (t0 + c0) * samples
-                ctx.expand_codes_on_stream(side.cuda_stream, (c1 - c0) * samples, _lib.XSW_F32, full_codes.data_ptr() + off * 4,
-                                           full_codes_dual.data_ptr() + off * 4 if mode == "dual" else None, full.data_ptr() + off * 8,
-                                           full_dual.data_ptr() + off * 8 if mode == "dual" else None)
+                           None, None, anc.data_ptr() + off * 8, out.data_ptr() + off * 8, None, algo=algo, sigma0_is_db=is_db)
 
     def step(gathering=True):
-        for k in range(n_chunks):
+        if coded and gathering:
+            multi_gpu.invert_tiled_device(ctx, inc, s_vv, anc, total_lines, sigma0_cr=s_vh, dsig_cr=dsig, pipeline=pipe, algo=algo,
+                                          dual_select=True, wait=False)
+            return
+        for k in range(n_chunks):  # the tiles left where they are computed (complex64): no exchange
             r0, r1 = multi_gpu.chunk_bounds(lines, n_chunks, k)
             if r1 > r0:
-                invert_rows(r0, r1, as_codes=coded and gathering)
-            if coded and gathering:
-                start_gather(k)
-                if rank == 0:
-                    ev_k = torch.cuda.Event()
-                    ev_k.record(stream)
-                    expand_chunk(k, ev_k)
+                invert_rows(r0, r1)
 
     def gather():
-        while pending:  # the single exchange of the path, started chunk by chunk inside step(); rank 0 has queued the waits already
-            q = pending.pop()
-            if rank != 0 or not coded:
-                q.wait()
-        if not stream_aware:
-            torch.cuda.synchronize()
-        if coded and rank == 0:  # the launch stream continues once the last chunk is expanded
-            done = torch.cuda.Event()
-            done.record(side)
-            stream.wait_event(done)
+        if coded:
+            pipe.finish()  # senders: their sends; rank 0: the launch stream continues behind the last chunk's expansion
 
     def fence():
         torch.cuda.synchronize()
@@ -830,11 +768,7 @@ def main():
         tg = time.perf_counter()
         g0.record(stream)
         for _ in range(args.steps):
-            for k in range(n_chunks):
-                start_gather(k)
-            chunk_reqs.clear()
-            while pending:
-                pending.pop().wait()
+            pipe.gather_only()
         g1.record(stream)
         fence()
         gather_only_ms = (time.perf_counter() - tg) / args.steps * 1e3
@@ -897,9 +831,9 @@ def main():
                        dual_select=(mode == "dual"))
         torch.cuda.synchronize()
         bits = lambda t: torch.view_as_real(t).view(torch.int32)
-        gather_ok = bool(torch.equal(bits(w_out), bits(full)))
+        gather_ok = bool(torch.equal(bits(w_out), bits(pipe.full)))
         if mode == "dual":
-            gather_ok = gather_ok and bool(torch.equal(bits(w_dual), bits(full_dual)))
+            gather_ok = gather_ok and bool(torch.equal(bits(w_dual), bits(pipe.full_dual)))
         del w_inc, w_s, w_anc, w_out, w_vh, w_dsig, w_dual
 
     if rank == 0:

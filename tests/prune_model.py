@@ -450,3 +450,179 @@ def block_pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig,
             if best is None or key < best:
                 best = key
     return best[1] // n_phi, best[1] % n_phi, state["swept"], state["bands"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 5, k_invert_band2 (and the entry of k_invert_blocks): the pixels whose band holds long runs have an a-priori wind far
+# from the sigma0 contour.  Two refinements, both exact (they only ever drop candidates that score above a real one):
+#
+# CONTOUR BOUND (`contour_bound`).  The three rays of stage 1 look where the a-priori wind points; the minimum of J lies where
+# the CONTOUR LUT = s comes closest to m, which may be tens of degrees away.  The inverse-row table gives the contour's row in
+# any direction with one read: a coarse scan over the window's directions (<= CONTOUR_PROBES of them, then two halvings of the
+# stride around the best) scores the two rows around the crossing; the smallest score is a valid upper bound (every probe is a
+# real candidate), and in practice IS the minimum to a few percent.
+#
+# JOINT SHRINK (`joint_rows`).  Window and band bound each cost term by J_ub on its own; per direction both hold TOGETHER:
+#   J(r) <= J_ub  =>  Jsig(r) <= J_ub - min Jwind over the rows still in question      (B: a narrower band, from the table)
+#                 =>  Jwind(r) <= J_ub - min Jsig over the rows still in question      (A: a shorter chord, analytic)
+# min Jwind over a row interval is analytic (a parabola in w/2); min Jsig over the rows between two table thresholds follows from
+# the thresholds themselves (rows >= inv[b] have LUT >= t_b; rows < inv[b'] have LUT < t_b').  B, A, B, A: two table reads per
+# B step, no LUT read at all; the rows that survive are swept and settled as before.
+CONTOUR_PROBES = 16
+
+
+def contour_bound(slice_wp, inv_tab, grid, mono, wh, cphi, sphi, s, ah, bh, inv_dsig, ip_lo, ip_hi, w_lo, w_hi):
+    """Smallest screening score J_s = wh (wh - U) + ((L - s)/dsig)^2 among the rows around the crossing LUT = s of the scanned
+    directions (rows clamped into the window's monotone part [w_lo, min(w_hi, mono - 1)]); (score, probes).  inv_tab[ip][b],
+    grid = (t0, width, inv_width)."""
+    t0, width, inv_width = grid
+    bins = inv_tab.shape[1]
+    b = int(min(max((s - t0) * inv_width, 0.0), float(bins - 1)))
+    r_top = min(w_hi, mono - 1)
+    if r_top < w_lo:
+        return np.inf, 0
+    sn = -s * inv_dsig
+
+    def probe(ip):
+        r0 = int(inv_tab[ip][b])
+        best = np.inf
+        for r in (min(max(r0 - 1, w_lo), r_top), min(max(r0, w_lo), r_top)):
+            u = 2.0 * (ah * cphi[ip] + bh * sphi[ip])
+            best = min(best, wh[r] * (wh[r] - u) + (slice_wp[r, ip] * inv_dsig + sn) ** 2)
+        return best
+
+    ncols = ip_hi - ip_lo + 1
+    stride = max(1, -(-ncols // CONTOUR_PROBES))
+    dirs = list(range(ip_lo, ip_hi + 1, stride))
+    vals = [probe(ip) for ip in dirs]
+    n = len(dirs)
+    k = int(np.argmin(vals))
+    best_ip, jc = dirs[k], vals[k]
+    h = stride
+    while h > 1:
+        h = (h + 1) // 2
+        for ip in (best_ip - h, best_ip + h):
+            if ip_lo <= ip <= ip_hi:
+                v = probe(ip)
+                n += 1
+                if v < jc:
+                    jc, best_ip = v, ip
+    return jc, n
+
+
+def _chord_from_budget(uh, m2, bud, w0, inv_wstep):
+    """Rows with wh^2 - 2 uh wh + m2 <= bud (uh = U/2), as chord_rows computes them (float32 root, inflated); None: no row."""
+    disc = uh * uh + ((bud - m2) + 1e-9 * (abs(bud) + m2))
+    if disc < 0.0:
+        return None
+    h = float(np.sqrt(np.float32(max(disc, 0.0)))) * (1.0 + 1e-6) + 1e-6
+    inv_whs = 2.0 * inv_wstep
+    xc, xh = (uh - 0.5 * w0) * inv_whs, h * inv_whs + CHORD_MRG
+    return int(np.ceil(max(xc - xh, -4.0))), int(np.floor(min(xc + xh, 40000.0)))
+
+
+def joint_rows(inv_col, grid, s, dsig, j_ub, uh, m2, wh0, whs, w0, inv_wstep, w_lo, w_hi, rounds=2):
+    """Rows [lo, hi] of ONE direction (monotone part of the window, [w_lo, w_hi]) that can hold a candidate with J <= j_ub
+    (j_ub already inflated): steps B, A, B, A, ... as described above.  inv_col[b] = the direction's inverse-row table.
+    Returns (lo, hi) (lo > hi: none), table reads."""
+    t0, width, inv_width = grid
+    bins = len(inv_col)
+    lo, hi = w_lo, w_hi
+    vlo, vhi = -np.inf, np.inf
+    reads = 0
+    inv_dsig = 1.0 / abs(dsig)
+    for _ in range(rounds):
+        if lo > hi:
+            break
+        # B: the smallest wind term over [lo, hi] (the parabola's own minimum clamped into the interval: a lower bound of the discrete one)
+        wa, wb = wh0 + lo * whs, wh0 + hi * whs
+        t = min(max(uh, wa), wb)
+        jw_lb = (m2 + t * (t - 2.0 * uh)) * (1.0 - 1e-9) - 1e-9 * m2
+        bud = j_ub - jw_lb
+        if bud < 0.0:
+            return 1, 0, reads
+        d = band_radius(bud, dsig)
+        b_lo, b_hi = table_bins(t0, width, inv_width, bins, s - d, s + d)
+        first, last = band_rows_from_table(inv_col, b_lo, b_hi, lo, hi)
+        reads += 2
+        lo, hi = max(lo, first), min(hi, last)
+        vlo = (b_lo * width + t0) if b_lo > 0 else -np.inf
+        vhi = (b_hi * width + t0) if b_hi >= 0 else np.inf
+        if lo > hi:
+            break
+        # A: the smallest sigma0 term over rows whose LUT value lies in [vlo, vhi)
+        dmin = max(0.0, vlo - s, s - vhi) * inv_dsig * (1.0 - 1e-9)
+        c = _chord_from_budget(uh, m2, j_ub - dmin * dmin, w0, inv_wstep)
+        if c is None:
+            return 1, 0, reads
+        lo, hi = max(lo, c[0]), min(hi, c[1])
+    return lo, hi, reads
+
+
+def refined_band_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig, rounds=2, bins=2048, tail_sweep=256, use_contour=True):
+    """The reference's argmin of one pixel the way k_invert_band2 finds it in round 5: three-ray bound, contour bound, window,
+    then per direction the joint shrink on the monotone rows (+ the rows past them, clipped to the chord) and the sweep.
+    Returns (i_wspd, i_phi, candidates swept, probes + table reads), or None where the kernel hands the pixel on (window past
+    the monotone rows by more than tail_sweep, non-finite input, near-tie)."""
+    n_w, n_phi = slice_wp.shape
+    if phi_180:
+        b = abs(b)
+    if not (np.isfinite(s) and np.isfinite(a) and np.isfinite(b)):
+        return None
+    w0, inv_wstep = wspd[0], (n_w - 1) / (wspd[-1] - wspd[0])
+    phi0, inv_dphi = phi[0], (n_phi - 1) / (phi[-1] - phi[0])
+    inv = 1.0 / dsig
+    sn = -s * inv
+    ah, bh = 0.5 * a, 0.5 * b
+    m2 = ah * ah + bh * bh
+    mag = np.sqrt(a * a + b * b)
+    theta = np.degrees(np.arctan2(b, a))
+    if theta < phi0:
+        theta += 360.0
+    ipr = int(np.clip(np.rint((theta - phi0) * inv_dphi), 0, n_phi - 1))
+    wh = 0.5 * wspd
+    wh0, whs = wh[0], 0.5 / inv_wstep
+    rbest = min(float(np.min(wh * (wh - 2.0 * (ah * cphi[q] + bh * sphi[q])) + (slice_wp[:, q] * inv + sn) ** 2))
+                for q in (ipr, max(ipr - 2, 0), min(ipr + 2, n_phi - 1)))  # (the rays' own minima: what the bisections find on unimodal columns)
+    mono = mono_rows(slice_wp)
+    lo_v, hi_v = float(slice_wp[:mono].min()), float(slice_wp[:mono].max())
+    width = (hi_v - lo_v) / (bins - 2) if hi_v > lo_v else 1.0
+    grid = (lo_v - width, width, 1.0 / width)
+    inv_tab = np.stack([inverse_rows(slice_wp[:, ip], mono, grid[0], grid[1], bins) for ip in range(n_phi)])
+    w_lo, w_hi, ip_lo, ip_hi = search_window(mag, theta, rbest + m2, w0, inv_wstep, n_w, phi0, phi[-1], inv_dphi, n_phi)
+    work = 0
+    if use_contour:
+        jc, work = contour_bound(slice_wp, inv_tab, grid, mono, wh, cphi, sphi, s, ah, bh, inv, ip_lo, ip_hi, w_lo, w_hi)
+        if jc < rbest:
+            rbest = jc
+            w_lo, w_hi, ip_lo, ip_hi = search_window(mag, theta, rbest + m2, w0, inv_wstep, n_w, phi0, phi[-1], inv_dphi, n_phi)
+    j_ub = (rbest + m2) * (1.0 + 1e-9) + 1e-9
+    tail_n = 0
+    if w_hi >= mono:
+        if mono < 1 or w_hi - mono + 1 > tail_sweep:
+            return None
+        tail_n, w_hi = w_hi - mono + 1, mono - 1
+    cand = []
+    for ip in range(ip_lo, ip_hi + 1):
+        uh = ah * cphi[ip] + bh * sphi[ip]
+        u = 2.0 * uh
+        rows = []
+        if w_hi >= w_lo:
+            lo, hi, reads = joint_rows(inv_tab[ip], grid, s, dsig, j_ub, uh, m2, wh0, whs, w0, inv_wstep, w_lo, w_hi, rounds)
+            work += reads
+            rows += list(range(lo, hi + 1))
+        if tail_n:
+            # the rows past the monotone ones: every LUT value up there is >= the direction's tail minimum (L.tail_min, level 0), so
+            # their sigma0 term is at least that far from s -- the chord of the tail follows from what is left of the bound
+            dmin = max(0.0, float(slice_wp[mono:, ip].min()) - s) * abs(inv) * (1.0 - 1e-9)
+            c = _chord_from_budget(uh, m2, j_ub - dmin * dmin, w0, inv_wstep)
+            if c is not None:
+                rows += list(range(max(mono, w_lo, c[0]), min(mono + tail_n - 1, c[1]) + 1))
+        for r in rows:
+            cand.append((wh[r] * (wh[r] - u) + (slice_wp[r, ip] * inv + sn) ** 2, r, ip))
+    assert cand, "the bound's own candidate always survives"
+    gmin = min(c[0] for c in cand)
+    keep = [c for c in cand if c[0] <= gmin + screening_eps(gmin, m2)]
+    if len(keep) != 1:
+        return None
+    return keep[0][1], keep[0][2], len(cand), work

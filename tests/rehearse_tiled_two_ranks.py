@@ -47,6 +47,32 @@ def worker(rank, world, port, ret):
             ref = windspeed.invert_from_model(inc[0, :sq], s_vv[:sq, :sq], ancillary_wind=anc[150:150 + sq, :sq], model="gmf_cmod5n",
                                               resolution="low")
             ret["square_1d_inc"] = eq(sq_mono, ref)
+        # a raster of a few lines: chunks thinner than the staging ring's minimum (numpy's dB of those rows is uploaded instead)
+        thin = multi_gpu.invert_from_model_tiled(inc[:7], s_vv[:7], s_vh[:7], ancillary_wind=anc[150:157], dsig_cr=0.2,
+                                                 model=("gmf_cmod5n", "gmf_s1_v2"), resolution="low")
+        if rank == 0:
+            ref = windspeed.invert_from_model(inc[:7], s_vv[:7], s_vh[:7], ancillary_wind=anc[150:157], dsig_cr=0.2,
+                                              model=("gmf_cmod5n", "gmf_s1_v2"), resolution="low")
+            ret["thin"] = eq(thin[0], ref[0]) and eq(thin[1], ref[1])
+        # DEVICE tensors in -> torch tensors out on rank 0 (round 5: the gathered call takes CUDA tensors; codes stay on the device)
+        import torch
+        dev = torch.device("cuda", 0)
+        t_inc, t_s, t_vh, t_dsig, t_anc = (torch.from_numpy(a).to(dev) for a in (inc, s_vv, s_vh, dsig, anc))
+        d_mono = multi_gpu.invert_from_model_tiled(t_inc, t_s, ancillary_wind=t_anc, model="gmf_cmod5n")
+        d_dual = multi_gpu.invert_from_model_tiled(t_inc, t_s, t_vh, ancillary_wind=t_anc, dsig_cr=t_dsig, model=("gmf_cmod5n", "gmf_s1_v2"), n_chunks=3)
+        d_cross = multi_gpu.invert_from_model_tiled(t_inc, t_vh, dsig_cr=0.3, model="gmf_s1_v2")
+        if rank == 0:
+            r_mono = windspeed.invert_from_model(t_inc, t_s, ancillary_wind=t_anc, model="gmf_cmod5n")
+            r_dual = windspeed.invert_from_model(t_inc, t_s, t_vh, ancillary_wind=t_anc, dsig_cr=t_dsig, model=("gmf_cmod5n", "gmf_s1_v2"))
+            r_cross = windspeed.invert_from_model(t_inc, t_vh, dsig_cr=0.3, model="gmf_s1_v2")
+            torch.cuda.synchronize()
+            teq = lambda a, b: bool(torch.is_tensor(a) and a.is_cuda and a.shape == b.shape and
+                                    torch.equal(torch.view_as_real(a).view(torch.int64), torch.view_as_real(b).view(torch.int64)))
+            ret["device_mono"] = teq(d_mono, r_mono)
+            ret["device_dual"] = teq(d_dual[0], r_dual[0]) and teq(d_dual[1], r_dual[1])
+            ret["device_cross"] = bool(torch.equal(d_cross.view(torch.int64), r_cross.view(torch.int64)))
+        else:
+            assert d_mono is None and d_dual is None and d_cross is None
     finally:
         dist.destroy_process_group()
 
@@ -62,4 +88,5 @@ if __name__ == "__main__":
         print(f"invert_from_model_tiled, {n} ranks on one device (gloo): raster", ret.get("shape"), "mono bit-equal to the single-process call:",
               ret.get("mono"), "dual:", ret.get("dual"), "all-NaN-ancillary tile:", ret.get("nan_tile"), "1-D incidence on a square raster:",
               ret.get("square_1d_inc"))
-        sys.exit(0 if all(ret.get(k) for k in ("mono", "dual", "nan_tile", "square_1d_inc")) else 1)
+        print("thin raster:", ret.get("thin"), "device tensors mono / dual / cross-only:", ret.get("device_mono"), ret.get("device_dual"), ret.get("device_cross"))
+        sys.exit(0 if all(ret.get(k) for k in ("mono", "dual", "nan_tile", "square_1d_inc", "thin", "device_mono", "device_dual", "device_cross")) else 1)

@@ -279,3 +279,68 @@ def test_coded_gather_gloo(world, lines):
         mp.spawn(_coded_gather_worker, args=(world, _free_port(), lines, 7, 8, ret), nprocs=world, join=True)
         assert ret.get("ok") is True
         assert ret["bytes"] == (lines - lines // world) * 7 * 4
+
+
+def _pipeline_worker(rank, world, port, lines, samples, n_chunks, dual, ret):
+    """`multi_gpu.TiledPipeline` -- the object bench.py --gpus N and `invert_from_model_tiled(gather=True)` run -- on CPU tensors
+    with stand-in device operations: chunked "inversion" to int32 codes, chunk-by-chunk gather, expansion on the destination."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        code_of = lambda g0, g1: (torch.arange(g0 * samples, g1 * samples, dtype=torch.int64) % 1000003).to(torch.int32).reshape(g1 - g0, samples)
+        pipe = multi_gpu.TiledPipeline(lines, samples, dual=dual, device="cpu", dst=0, n_chunks=n_chunks, out_dtype=torch.complex64)
+        assert (pipe.g0, pipe.g1) == multi_gpu.tile_bounds(lines, world, rank) and pipe.side is None
+        seen = []
+
+        def invert_chunk(k, r0, r1):
+            seen.append((k, r0, r1))
+            pipe.codes[r0:r1] = code_of(pipe.g0 + r0, pipe.g0 + r1)
+            if dual:
+                pipe.codes_dual[r0:r1] = -code_of(pipe.g0 + r0, pipe.g0 + r1)
+
+        expanded = []
+
+        def expand_rows(g0, g1, stream):
+            assert stream is None and rank == 0
+            expanded.append((g0, g1))
+            pipe.full[g0:g1] = torch.complex(pipe.full_codes[g0:g1].float(), pipe.full_codes[g0:g1].float() * 2)
+            if dual:
+                pipe.full_dual[g0:g1] = torch.complex(pipe.full_codes_dual[g0:g1].float(), torch.zeros(g1 - g0, samples))
+
+        ok = True
+        for _ in range(2):  # reusable: the second run overwrites the same buffers
+            del seen[:], expanded[:]
+            pipe.run(invert_chunk, expand_rows)
+            out = pipe.finish()
+            ok = ok and [c[1:] for c in seen] == [c for c in (multi_gpu.chunk_bounds(pipe.rows, n_chunks, k) for k in range(n_chunks)) if c[1] > c[0]]
+        if rank == 0:
+            full, full_dual = out
+            want = code_of(0, lines).float()
+            ok = ok and torch.equal(full, torch.complex(want, want * 2)) and len(set(expanded)) == len(expanded)
+            ok = ok and sum(g1 - g0 for g0, g1 in expanded) == lines
+            ok = ok and ((full_dual is None) if not dual else torch.equal(full_dual, torch.complex(-want, torch.zeros_like(want))))
+            ret["ok"] = bool(ok)
+        else:
+            ret[f"ok{rank}"] = bool(ok and out is None and pipe.full is None)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,lines,n_chunks,dual", [(2, 25, 8, False), (3, 10, 4, True), (3, 2, 8, False)])
+def test_tiled_pipeline_gloo(world, lines, n_chunks, dual):
+    """Uneven tiles, more chunks than rows, a rank with an empty tile (2 lines over 3 ranks), mono and dual code rasters."""
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_pipeline_worker, args=(world, _free_port(), lines, 7, n_chunks, dual, ret), nprocs=world, join=True)
+        assert ret.get("ok") is True and all(ret.get(f"ok{r}") for r in range(1, world))
+
+
+def test_code_sink_geometry():
+    """`_CodeSink.begin`: the gathered raster's geometry from the leading-axis tiling -- middle axes folded into the rows, 1-D
+    rasters as rows of one pixel, the same chunk count on every rank."""
+    import numpy as np
+    sink = multi_gpu._CodeSink(10, 10, 0, None, 8)
+    with pytest.raises(ValueError):
+        sink.begin((9, 5), True, False, "cpu", torch.complex64)  # the leading axis is not the tiled one
+    assert multi_gpu.chunk_bounds(10, 4, 3) == (7, 10)
+    assert np.prod([3, 4]) == 12

@@ -153,19 +153,23 @@ static void worker_release(xsw_ctx::Worker &w)
 
 // Staging kept between calls: each worker of the host-memory paths owns a page-locked buffer and a device buffer of one chunk
 // (float32 mono: ~40 MB each; float64 dual-pol: ~110 MB each), i.e. up to threads x chunk of pinned host memory per context.
-// After every host-memory call the buffers beyond XSW_STAGING_KEEP_MB (default 512 MB of pinned memory per context; the same
-// amount of device memory) are released, largest first -- a later call pins them again (a few ms each).
+// After every host-memory call the buffers beyond XSW_STAGING_KEEP_MB (default 1536 MB per context -- the default 12 workers at float32 mono chunks hold ~1.1 GB --, counted per worker as the
+// larger of its page-locked and its device buffer) are released, largest first -- a later call allocates them again (a few ms each).
 static void trim_staging(xsw_ctx *c)
 {
-    static const size_t keep = (size_t)(getenv("XSW_STAGING_KEEP_MB") ? std::max(0LL, atoll(getenv("XSW_STAGING_KEEP_MB"))) : 512) << 20;
+    static const size_t keep = (size_t)(getenv("XSW_STAGING_KEEP_MB") ? std::max(0LL, atoll(getenv("XSW_STAGING_KEEP_MB"))) : 1536) << 20;
+    // a worker counts with the larger of its two buffers: the pinned-input paths (XSW_MEM_HOST_PINNED, the pinned detrend) hold
+    // no page-locked staging at all, and the device side of a worker (inputs + codes + its work lists and records) outgrows
+    // the pinned side
+    auto held = [](const xsw_ctx::Worker &w) { return std::max(w.pin_cap, w.dev_cap); };
     size_t total = 0;
-    for (auto &w : c->workers) total += w.pin_cap;
+    for (auto &w : c->workers) total += held(w);
     while (total > keep) {
         xsw_ctx::Worker *big = nullptr;
         for (auto &w : c->workers)
-            if (w.pin_cap && (!big || w.pin_cap > big->pin_cap)) big = &w;
+            if (held(w) && (!big || held(w) > held(*big))) big = &w;
         if (!big) break;
-        total -= big->pin_cap;
+        total -= held(*big);
         worker_release(*big);
     }
 }

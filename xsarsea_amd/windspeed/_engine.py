@@ -309,8 +309,11 @@ def invert_numpy(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_c
 
     devs = _device_list()
     n = int(np.prod(shape, dtype=np.int64)) if len(shape) else 1
-    if codes or devs is None or len(shape) < 2 or n < options.devices_min_pixels or shape[0] < 4 * len(devs):
-        out_co, out_cr, _ = run(_lib.default_context(options.device), None, None, None)
+    if codes or devs is None or len(devs) == 1 or len(shape) < 2 or n < options.devices_min_pixels or shape[0] < 4 * len(devs):
+        # one device: `options.device`, or the one entry of `options.devices` (a one-entry list names THE device, whatever the
+        # raster's size); several entries with a raster too small to tile: the first of them
+        one = options.device if devs is None else devs[0]
+        out_co, out_cr, _ = run(_lib.default_context(one), None, None, None)
         return out_co, out_cr  # None where that search did not run (the caller never reads it)
     # several GPUs: contiguous row tiles of the leading axis, one host thread and one context per GPU, results in place
     lines = shape[0]
@@ -359,9 +362,10 @@ def invert_device(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_
         # mixed dtypes (float32 sigma0 next to a float64 incidence, say): the reference converts sigma0 to dB in sigma0's OWN dtype
         # (windspeed.py:126-130) before anything is widened -- do that here, then hand dB rasters to the kernel
         to_db = lambda t: None if t is None else (10 * torch.log10(t + 1e-15))
-        # a scalar dsig_cr is broadcast in sigma0_cr's dtype (windspeed.py:122-123): keep that rounding
-        if t_cr is not None and t_dsig is None and dsig_cr is not None and t_cr.dtype == torch.float32:
-            dsig_cr = float(np.float32(dsig_cr))
+        # a scalar dsig_cr is broadcast from the LINEAR sigma0_cr, in its dtype (windspeed.py:122-123: sigma0_cr * 0 + dsig_cr --
+        # finite where sigma0 is; formed from the dB value it would be NaN wherever sigma0_cr + 1e-15 == 0, i.e. -inf dB)
+        if t_cr is not None and t_dsig is None and dsig_cr is not None:
+            t_dsig = t_cr * 0 + dsig_cr
         t_co, t_cr, is_db = to_db(t_co), to_db(t_cr), True
     prep = lambda t, d: None if t is None else t.to(d).expand(shape).contiguous()
     t_inc, t_co, t_cr, t_dsig, t_anc = prep(t_inc, rt), prep(t_co, rt), prep(t_cr, rt), prep(t_dsig, rt), prep(t_anc, ct)
@@ -386,3 +390,129 @@ def invert_device(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_
                 if t is not None:
                     t.record_stream(torch.cuda.current_stream(dev))
     return out_co, out_cr
+
+
+def invert_coded(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, anc, dsig_co, sink, dual_select=False):
+    """A rank's row tile -> 4-byte grid codes in DEVICE memory, chunk by chunk, for the gathered multi-GPU call
+    (`multi_gpu.invert_from_model_tiled`; `sink` is its `_CodeSink`: it owns the code buffers, starts the gather of every
+    chunk and queues its expansion on the destination rank).  numpy or device rasters; nothing of the answer visits the host.
+
+    Two phases, so that a rank that fails leaves no peer waiting in a transfer: everything that can raise for a reason of
+    the inputs -- dtypes, shapes, LUT install, uploads -- happens HERE, before any exchange; the returned `launch()` only queues
+    kernels and transfers (the caller agrees with the other ranks in between).
+
+    numpy rasters follow `invert_numpy`'s arithmetic: float32 sigma0 is converted to dB on the host with numpy's own log10
+    (`options.db_on_device = "auto"`; bit parity with the reference) -- through libxsw's staging ring while the other rasters
+    are already resident (XSW_MEM_DEVICE_SIGMA0_HOST) -- and a scalar `dsig_cr` is broadcast from the LINEAR sigma0
+    (windspeed.py:122-123).  Device rasters follow `invert_device` (sigma0 -> dB fused, the dual-pol select fused)."""
+    import torch
+    from .. import _device
+    given = [a for a in (inc, sigma0_co, sigma0_cr, None if np.isscalar(dsig_cr) else dsig_cr, anc) if a is not None]
+    on_device = _device.any_device_array(*given)
+    dev = _device.device_of(*given) if on_device else torch.device("cuda", int(options.device))
+    ctx = _lib.default_context(dev.index if dev.index is not None else torch.cuda.current_device())
+    want_co, want_cr = sigma0_co is not None, sigma0_cr is not None
+    shape = tuple(np.broadcast_shapes(*(tuple(np.shape(a)) for a in given)))
+    n = int(np.prod(shape, dtype=np.int64)) if len(shape) else 1
+    host_lin, is_db = {}, False
+    if on_device:
+        t = {k: (None if v is None or np.isscalar(v) else _device.as_tensor(v, dev)) for k, v in
+             (("inc", inc), ("co", sigma0_co), ("cr", sigma0_cr), ("dsig", dsig_cr), ("anc", anc))}
+        rasters = [t[k] for k in ("inc", "co", "cr", "dsig") if t[k] is not None]
+        all_f32 = all(x.dtype == torch.float32 for x in rasters) and (t["anc"] is None or t["anc"].dtype == torch.complex64)
+        if not all_f32 and any(t[k] is not None and t[k].dtype == torch.float32 for k in ("co", "cr")):
+            if want_cr and t["dsig"] is None and dsig_cr is not None:  # scalar dsig_cr: broadcast from the LINEAR sigma0, in its dtype
+                t["dsig"] = t["cr"] * 0 + dsig_cr
+            to_db = lambda x: None if x is None else (10 * torch.log10(x + 1e-15))
+            t["co"], t["cr"], is_db = to_db(t["co"]), to_db(t["cr"]), True
+    else:
+        arr = lambda a: None if a is None or np.isscalar(a) else np.asarray(a)
+        h = dict(inc=arr(inc), co=arr(sigma0_co), cr=arr(sigma0_cr), dsig=arr(dsig_cr), anc=arr(anc))
+        rasters = [h[k] for k in ("inc", "co", "cr", "dsig") if h[k] is not None]
+        all_f32 = all(x.dtype == np.float32 for x in rasters) and (h["anc"] is None or h["anc"].dtype == np.complex64)
+        on_dev = options.db_on_device
+        if on_dev == "auto":
+            on_dev = not any(h[k] is not None and h[k].dtype == np.float32 for k in ("co", "cr"))
+        is_db = not on_dev
+        if is_db and want_cr and h["dsig"] is None and dsig_cr is not None:
+            with np.errstate(all="ignore"):
+                h["dsig"] = h["cr"] * 0 + dsig_cr  # windspeed.py:122-123, from the linear sigma0 in its own dtype
+        if is_db:  # sigma0 stays on the host: converted piece by piece on its way up
+            host_lin = {k: np.ascontiguousarray(np.broadcast_to(h[k], shape)) for k in ("co", "cr") if h[k] is not None}
+        t = {k: (None if v is None or (is_db and k in ("co", "cr")) else torch.from_numpy(np.ascontiguousarray(v)).to(dev)) for k, v in h.items()}
+    rt, ct = (torch.float32, torch.complex64) if all_f32 else (torch.float64, torch.complex128)
+    npdt = np.float32 if all_f32 else np.float64
+    prep = lambda x, d: None if x is None else x.to(d).expand(shape).contiguous()
+    t_inc, t_co, t_cr, t_dsig, t_anc = prep(t["inc"], rt), prep(t["co"], rt), prep(t["cr"], rt), prep(t["dsig"], rt), prep(t["anc"], ct)
+    dsig_scalar = 0.1
+    if want_cr and t_dsig is None and dsig_cr is not None:
+        dsig_scalar = float(np.float32(dsig_cr)) if all_f32 else float(dsig_cr)
+    numpy_out = not on_device
+    odt = torch.complex128 if (numpy_out or options.device_out_dtype != "complex64") else torch.complex64
+    sink.begin(shape, want_co, want_cr, dev, odt)
+    pipe = sink.pipe
+    S = pipe.samples
+    item, oitem = (4 if all_f32 else 8), (8 if odt == torch.complex64 else 16)
+    xdt, xodt = (_lib.XSW_F32 if all_f32 else _lib.XSW_F64), (_lib.XSW_F32 if odt == torch.complex64 else _lib.XSW_F64)
+    algo = _lib.ALGOS.get(options.algo, options.algo)
+    fused_select = bool(dual_select and want_co and want_cr and on_device)
+    with ctx.lock:
+        ensure_luts(ctx, lut_co if want_co else None, lut_cr if want_cr else None)  # (also on a rank whose tile is empty: it may expand)
+    at = lambda x, off, size: None if x is None else x.data_ptr() + off * size
+    src = {k: v.reshape(-1) for k, v in host_lin.items()}
+
+    def stage_for(px_base):
+        def stage(which, px0, npx, dst):
+            key = "co" if which == _lib.STAGE_SIGMA0_CO else ("cr" if which == _lib.STAGE_SIGMA0_CR else None)
+            if key not in src:
+                return 0
+            x = src[key][px_base + px0:px_base + px0 + npx]
+            out = np.frombuffer((ctypes.c_char * (npx * item)).from_address(dst), dtype=npdt)
+            with np.errstate(all="ignore"):
+                if x.dtype == npdt:
+                    np.add(x, 1e-15, out=out)
+                    np.log10(out, out=out)
+                    np.multiply(out, 10, out=out)
+                else:
+                    out[...] = 10 * np.log10(x + 1e-15)
+            return 1
+        return stage
+
+    def invert_chunk(k, r0, r1):
+        off, npx = r0 * S, (r1 - r0) * S
+        lines, samples = ((r1 - r0), S) if len(shape) >= 2 else (1, npx)
+        p_co = at(t_co, off, item) if t_co is not None else (at(t_inc, off, item) if "co" in src else None)
+        p_cr = at(t_cr, off, item) if t_cr is not None else (at(t_inc, off, item) if "cr" in src else None)
+        host_route = bool(src) and lines >= 4
+        if src and not host_route:  # a chunk too thin for the staging ring: numpy's dB of these rows, uploaded
+            with np.errstate(all="ignore"):
+                up = {key: torch.from_numpy(np.ascontiguousarray(10 * np.log10(v[off:off + npx] + 1e-15)).astype(npdt, copy=False)).to(dev) for key, v in src.items()}
+            p_co = up["co"].data_ptr() if "co" in up else p_co
+            p_cr = up["cr"].data_ptr() if "cr" in up else p_cr
+            for x in up.values():
+                x.record_stream(torch.cuda.current_stream(dev))
+        if host_route:
+            # (pointers of the host rasters are never read: the staging callback fills every piece)
+            ctx.invert_raw(lines, samples, xdt, xodt, _lib.MEM_DEVICE_SIGMA0_HOST, at(t_inc, off, item),
+                           src["co"].ctypes.data + off * src["co"].itemsize if "co" in src else None,
+                           src["cr"].ctypes.data + off * src["cr"].itemsize if "cr" in src else None,
+                           at(t_dsig, off, item), at(t_anc, off, 2 * item), None, None, None, dsig_co, dsig_scalar, True, algo, False,
+                           out_code_co=at(pipe.codes, off, 4), out_code_cr=at(pipe.codes_dual, off, 4), stage=stage_for(off))
+        else:
+            ctx.invert_raw(lines, samples, xdt, xodt, _lib.MEM_DEVICE, at(t_inc, off, item), p_co, p_cr, at(t_dsig, off, item),
+                           at(t_anc, off, 2 * item), None, None, None, dsig_co, dsig_scalar, is_db, algo, fused_select,
+                           out_code_co=at(pipe.codes, off, 4), out_code_cr=at(pipe.codes_dual, off, 4))
+
+    def expand_rows(g0, g1, stream):
+        off = g0 * S
+        ctx.expand_codes_on_stream(stream.cuda_stream, (g1 - g0) * S, xodt, at(pipe.full_codes, off, 4), at(pipe.full_codes_dual, off, 4),
+                                   at(pipe.full, off, oitem), at(pipe.full_dual, off, oitem))
+
+    def launch():
+        with _device.on_current_stream(ctx, dev):
+            pipe.run(invert_chunk, expand_rows)
+            for x in (t_inc, t_co, t_cr, t_dsig, t_anc):
+                if x is not None:
+                    x.record_stream(torch.cuda.current_stream(dev))
+
+    return launch

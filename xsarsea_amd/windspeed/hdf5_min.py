@@ -242,9 +242,15 @@ def fletcher32(data):
     """HDF5's Fletcher-32 of a byte string (H5checksum.c: big-endian 16-bit words, end-around carry; an odd last byte is the high
     byte of one more word).  Checked against the checksums h5py wrote into tests/golden/nc4/*fletcher*."""
     n = len(data) // 2
-    w = np.frombuffer(data, ">u2", n).astype(np.uint64)
-    s1 = int(w.sum())
-    s2 = int((w * np.arange(n, 0, -1, dtype=np.uint64)).sum())
+    # exact sums as Python integers, block by block: word j weighs (n - j) in the second sum, and a one-shot uint64 product sum
+    # wraps beyond ~2.4e7 words (a 362 MB default-size table written as ONE chunk has 1.8e8)
+    s1 = s2 = 0
+    blk = 1 << 20
+    for j0 in range(0, n, blk):
+        w = np.frombuffer(data, ">u2", min(blk, n - j0), 2 * j0).astype(np.uint64)
+        m, t = len(w), int(w.sum())
+        s1 += t
+        s2 += int((w * np.arange(m, 0, -1, dtype=np.uint64)).sum()) + (n - j0 - m) * t
     if len(data) % 2:
         s1 += data[-1] << 8
         s2 += s1

@@ -55,8 +55,11 @@ class CodedWinds:
     return value of `invert_from_model`: `finish()` expands them on the host (bit-identical to the direct call) and applies the
     return conventions of windspeed.py:415-439.  What `multi_gpu.invert_from_model_tiled` sends between ranks."""
 
-    def __init__(self, mode, lut_co, lut_cr, codes_co, codes_cr):
+    def __init__(self, mode, lut_co, lut_cr, codes_co, codes_cr, launch=None, on_device=False):
         self.mode, self.lut_co, self.lut_cr, self.codes_co, self.codes_cr = mode, lut_co, lut_cr, codes_co, codes_cr
+        # the gathered multi-GPU call (`_engine.invert_coded`): the codes stay in device memory, `launch()` queues the chunked
+        # inversion + gather + expansion, and the expanded winds come back through `finish_winds`
+        self.launch, self.on_device = launch, on_device
 
     def finish(self, codes_co=None, codes_cr=None):
         cc = self.codes_co if codes_co is None else codes_co
@@ -64,6 +67,17 @@ class CodedWinds:
         ws_co, ws_cr = _engine.expand_codes(self.lut_co, self.lut_cr, cc, cr)
         if self.mode == "mono_co":
             return ws_co
+        if self.mode == "mono_cr":
+            return _engine.abs_blocks(ws_cr)
+        return ws_co, _engine.dual_select(ws_co, ws_cr)
+
+    def finish_winds(self, ws_co, ws_cr):
+        """The return conventions of windspeed.py:415-439 on expanded winds: numpy arrays (complex128; the dual-pol select with
+        numpy's own `abs`, as the direct call does) or torch tensors (device rasters: the select was fused into the kernel)."""
+        if self.mode == "mono_co":
+            return ws_co
+        if self.on_device:
+            return ws_cr.abs() if self.mode == "mono_cr" else (ws_co, ws_cr)
         if self.mode == "mono_cr":
             return _engine.abs_blocks(ws_cr)
         return ws_co, _engine.dual_select(ws_co, ws_cr)
@@ -132,7 +146,15 @@ def invert_from_model(inc, sigma0, sigma0_dual=None, /, ancillary_wind=None, dsi
     if sigma0_cr is not None and lut_cr is None:
         raise ValueError("a cross-pol sigma0 was given but `model` names no cross-pol model")
 
-    if _device.any_device_array(inc, sigma0_co, sigma0_cr, None if np.isscalar(dsig_cr) else dsig_cr, ancillary_wind):
+    on_device = _device.any_device_array(inc, sigma0_co, sigma0_cr, None if np.isscalar(dsig_cr) else dsig_cr, ancillary_wind)
+    if hasattr(want_codes, "begin") and not any(_is_xr(v) or _is_dask(v) for v in (inc, sigma0, sigma0_dual, ancillary_wind) if v is not None):
+        # the gathered multi-GPU call: this rank's tile -> grid codes in device memory, chunk by chunk behind `want_codes` (the
+        # pipeline's sink); numpy or device rasters.  Everything that can raise has happened when this returns.
+        mode = "dual" if sigma0_dual is not None else ("mono_co" if models[0] is not None else "mono_cr")
+        launch = _engine.invert_coded(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr, None if no_ancillary else ancillary_wind,
+                                      dsig_co, want_codes, dual_select=sigma0_dual is not None)
+        return CodedWinds(mode, lut_co, lut_cr, None, None, launch=launch, on_device=on_device)
+    if on_device:
         # rasters resident in HBM (torch CUDA tensors / __cuda_array_interface__): torch tensors on the same device come back,
         # nothing crosses PCIe; same routing and return conventions as below (:415-439), the dual-pol select fused in the kernel
         ws_co, ws_cr = _engine.invert_device(lut_co, lut_cr, inc, sigma0_co, sigma0_cr, dsig_cr,
@@ -174,7 +196,7 @@ def invert_from_model(inc, sigma0, sigma0_dual=None, /, ancillary_wind=None, dsi
             ws_cr = None
     else:
         np_args = [None if v is None else (v if np.isscalar(v) else np.asarray(v)) for v in args]
-        if want_codes and template is None:
+        if want_codes is True and template is None:
             mode = "dual" if sigma0_dual is not None else ("mono_co" if models[0] is not None else "mono_cr")
             return CodedWinds(mode, lut_co, lut_cr, *_numpy(*np_args, codes=True))
         ws_co, ws_cr = _numpy(*np_args)
