@@ -42,7 +42,7 @@ LANE_OPS_PEAK_ISSUE = 3.93e13  # 256 CU x 4 SIMDs x 16 lanes per clock x 2.4 GHz
 OPS_PER_CANDIDATE = 6    # sub, scale, square-accumulate, separable wind term, compare, select
 BYTES_READ_PX = 16       # inc f32 + sigma0 f32 + ancillary complex64   
 BYTES_WRITE_PX = 8       # complex64 wind
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 PCIE_PEAK_GBS = 64.0      # PCIe Gen5 x16, one direction (MI355X_MICROARCH.md host link)
 
 CONFIGS = {  # BASELINE.json configs (1 is the CPU plumbing case: tests/test_gpu_api.py::test_sigma0_detrend)
@@ -60,7 +60,8 @@ _C5N = [0.0, -0.6878, -0.7957, 0.338, -0.1728, 0.0, 0.004, 0.1103, 0.0159, 6.732
 
 
 def cmod5n_torch(inc, v, phi_deg):
-    """CMOD5.N forward model with torch ops (scene synthesis only; float64)."""
+    """CMOD5.N forward model with torch ops (float64): the check of `cmod5n_device` in the gmf_eval figure, and scene synthesis
+    on a CPU device."""
     c = _C5N
     cosphi = torch.cos(torch.deg2rad(phi_deg))
     x = (inc - 40.0) / 25.0
@@ -86,6 +87,25 @@ def cmod5n_torch(inc, v, phi_deg):
     v2 = torch.where(v2 < y0, a + b * (v2 - 1.0).clamp_min(0) ** pn, v2)
     b2 = (-d1 + d2 * v2) * torch.exp(-v2)
     return b0 * (1.0 + b1 * cosphi + b2 * (2.0 * cosphi * cosphi - 1.0)) ** 1.6
+
+
+def cmod5n_device(inc, v, phi_deg):
+    """CMOD5.N through the PRODUCT's forward-GMF kernel (xsw_gmf_eval, the device form of GmfModel.__call__(broadcast=True)):
+    float64 tensors of one shape on a GPU -> sigma0 (linear).  The bench scene is generated with it (dogfood; untimed)."""
+    from xsarsea_amd import _lib
+    shape = torch.broadcast_shapes(inc.shape, v.shape, phi_deg.shape)
+    a, b, c = (t.to(torch.float64).expand(shape).contiguous() for t in (inc, v, phi_deg))
+    out = torch.empty(shape, dtype=torch.float64, device=a.device)
+    ctx = _lib.default_context(a.device.index if a.device.index is not None else torch.cuda.current_device())
+    with ctx.lock:
+        ctx.set_stream(torch.cuda.current_stream(a.device).cuda_stream)
+        try:
+            ctx.gmf_eval_raw(_lib.GMF_IDS["gmf_cmod5n"], out.numel(), _lib.MEM_DEVICE, a.data_ptr(), b.data_ptr(), c.data_ptr(), out.data_ptr())
+        finally:
+            ctx.use_own_stream()
+    for t in (a, b, c):
+        t.record_stream(torch.cuda.current_stream(a.device))
+    return out
 
 
 def make_scene(lines, samples, total_lines, line0, seed, device, chunk=500, inc_range=(30.0, 46.0), anc_scale=1.0, outlier_frac=0.0):
@@ -120,7 +140,7 @@ def make_scene(lines, samples, total_lines, line0, seed, device, chunk=500, inc_
         w_t = (9 + 6 * torch.sin(3 * math.pi * ll / L) * torch.cos(2 * math.pi * ss / S)
                + 12 * torch.exp(-r2 / (0.15 * min(L, S)) ** 2)).clamp(1, 40)
         dir_t = torch.atan2(ll - L / 2, ss - S / 2) + 0.6
-        sig = cmod5n_torch(inc_c, w_t, torch.rad2deg(dir_t))
+        sig = cmod5n_device(inc_c, w_t, torch.rad2deg(dir_t)) if device.type == "cuda" else cmod5n_torch(inc_c, w_t, torch.rad2deg(dir_t))
         speckle = torch._standard_gamma(torch.full(sig.shape, 100.0, device=device, dtype=torch.float32), generator=g) / 100.0
         sig32 = (sig.float() * speckle)
         if gain is not None:
@@ -462,7 +482,12 @@ def hard_scene_figures(ctx, _lib, stream, device, samples, algo, lines_hs=4000):
         ctx.stats_enable(True)
         run()
         st = ctx.stats()
+        ctx.stats_enable(2)  # the production chain, its kernels counting what they score
+        run()
+        ch = ctx.stats_chain()
         ctx.stats_enable(False)
+        nl = max(tm["launches"], 1)
+        per_s = lambda cnt, ms_k: None if not ms_k else float(f"{cnt / (ms_k * 1e-3):.3g}")
         ms = (tm["first_kernel_ms"] + tm["second_kernel_ms"] + tm["band2_kernel_ms"] + tm["blocks_kernel_ms"]) / max(tm["launches"], 1)
         out[key] = {"scene": what, "pixels": lines_hs * samples, "value": round(lines_hs * samples / ms / 1e3, 1), "unit": "Mpixels/s",
                     "k_invert_band_ms": round(tm["first_kernel_ms"] / max(tm["launches"], 1), 2),
@@ -473,7 +498,14 @@ def hard_scene_figures(ctx, _lib, stream, device, samples, algo, lines_hs=4000):
                     "pixels_to_blocks_frac": round(tm["last_blocks_pixels"] / (lines_hs * samples), 5),
                     "pixels_left_to_the_list_frac": round(tm["last_list_pixels"] / (lines_hs * samples), 5),
                     "evaluated_candidates_per_pixel": round(st["cand_co"] / max(st["pixels_co"], 1), 1),
-                    "pixels_exact_fallback": int(st["pixels_exact"])}
+                    "pixels_exact_fallback": int(st["pixels_exact"]),
+                    # measured on the production chain (xsw_stats_enable(ctx, 2)): what the kernels behind k_invert_band score, and how fast
+                    "scored_candidates": {"k_invert_band2": ch["cand_band2"], "k_invert_blocks": ch["cand_blocks"], "k_invert_list": ch["cand_list"],
+                                          "band2_records_refined_frac": round(ch["pixels_refined"] / max(tm["last_band2_pixels"], 1), 4)},
+                    "scored_candidates_per_s": {"k_invert_band2": per_s(ch["cand_band2"], tm["band2_kernel_ms"] / nl),
+                                                "k_invert_blocks": per_s(ch["cand_blocks"], tm["blocks_kernel_ms"] / nl),
+                                                "k_invert_list": per_s(ch["cand_list"], tm["second_kernel_ms"] / nl),
+                                                "chain_statistics_instantiation": per_s(st["cand_co"], ms)}}
         del inc, s_vv, anc
     return out
 
@@ -506,6 +538,103 @@ def detrend_figures(args, ctx, stream, s_vv, lines, samples):
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_copy_rate_6290": round(achieved / 6290.0, 4),
                          "traffic": traffic, "traffic_provenance": prov}}
+
+
+def gmf_eval_figures(args, ctx, stream, device, n=400_000_000):
+    """`xsw_gmf_eval(CMOD5.N)` -- the forward GMF of GmfModel.__call__(broadcast=True) (gmfs.py:293-316) -- on n already-broadcast
+    float64 elements resident in HBM: 24 B read + 8 B written per element; ~1.5e3 float64 lane-instructions per element (seven
+    pow, four exp, tanh, cos), so the kernel is VALU-bound: both rooflines are given."""
+    from xsarsea_amd import _lib
+    g = torch.Generator(device=device)
+    g.manual_seed(3)
+    inc = torch.rand(n, generator=g, device=device, dtype=torch.float64) * 30 + 17
+    v = torch.rand(n, generator=g, device=device, dtype=torch.float64) * 40 + 0.5
+    phi = torch.rand(n, generator=g, device=device, dtype=torch.float64) * 360 - 180
+    out = torch.empty(n, dtype=torch.float64, device=device)
+    gid = _lib.GMF_IDS["gmf_cmod5n"]
+
+    def step():
+        ctx.gmf_eval_raw(gid, n, _lib.MEM_DEVICE, inc.data_ptr(), v.data_ptr(), phi.data_ptr(), out.data_ptr())
+
+    _, ms = time_steps(step, max(2, args.steps // 4), 1, stream)
+    k = 1 << 20
+    ref = cmod5n_torch(inc[:k], v[:k], phi[:k])
+    rel = float(((out[:k] - ref).abs() / ref.abs()).max().item())
+    del inc, v, phi, out
+    achieved = 32.0 * n / (ms * 1e-3) / 1e9
+    return {"workload": f"xsw_gmf_eval(gmf_cmod5n) on {n} broadcast float64 elements (incidence 17..47, wind 0.5..40.5, all directions)",
+            "value": round(n / (ms * 1e-3) / 1e6, 1), "unit": "Melements/s", "kernel": "k_gmf_eval<CMOD5N>", "kernel_ms": round(ms, 3),
+            "bytes_per_element": 32, "max_rel_diff_vs_torch_float64": float(f"{rel:.2e}"),
+            "roofline": {"bound": "valu", "hbm": {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4)},
+                         "note": "float64 transcendental arithmetic (ocml pow / exp / tanh / cos, ~1.5e3 lane-instructions per element), 119 VGPRs, no scratch "
+                                 "(one kernel per model since round 5; round 4's one-for-all kernel: 181 VGPRs + 24 B of scratch)"}}
+
+
+def latency_figures(local_rank):
+    """What xsarsea is run at operationally: ~1 km grids, 1e5..1e6 pixels per call.  `invert_from_model` end to end on float32 numpy
+    rasters (complex128 out), CMOD5.N default LUT, for both LUT routes (`options.lut_build`): the FIRST call with nothing
+    prepared (fresh libxsw context, no memoised LUT: LUT preparation + install + staging start-up + search) and the WARM call
+    (median of 7), with the warm call's phases.  Reference: the LUT is rebuilt on every call (windspeed.py:144)."""
+    import xsarsea_amd
+    from xsarsea_amd import _lib, options, windspeed
+    from xsarsea_amd.windspeed import _engine, get_model, gmfs_impl
+    out = {}
+    saved = (options.lut_build, options.device)
+    options.device = local_rank
+    try:
+        for lines, samples in ((250, 400), (1000, 1000)):
+            rng = np.random.default_rng(lines)
+            inc = np.broadcast_to(np.linspace(30, 46, samples, dtype=np.float32), (lines, samples)).copy()
+            wt, pt = rng.uniform(2, 25, (lines, samples)), rng.uniform(-180, 180, (lines, samples))
+            s_vv = (gmfs_impl._cmod5_sigma0(gmfs_impl._CMOD5N, inc.astype(np.float64), wt, pt) * rng.gamma(100, 0.01, (lines, samples))).astype(np.float32)
+            anc = (wt * np.exp(1j * np.deg2rad(pt)) + rng.normal(0, 1.5, (lines, samples)) + 1j * rng.normal(0, 1.5, (lines, samples))).astype(np.complex64)
+            key = f"{lines}x{samples}"
+            out[key] = {"pixels": lines * samples}
+            for route in ("host", "device"):
+                options.lut_build = route
+                model = get_model("gmf_cmod5n")
+                model._lut_cache.clear()
+                model.__dict__.pop("_device_luts", None)
+                with _lib._default_ctx_lock:  # a fresh context: what the first call of a process pays (HIP itself is up already)
+                    old = _lib._default_ctx.pop((int(local_rank), 0), None)
+                if old is not None:
+                    old.close()
+                call = lambda: windspeed.invert_from_model(inc, s_vv, ancillary_wind=anc, model="gmf_cmod5n")
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    t0 = time.perf_counter()
+                    call()
+                    first_ms = (time.perf_counter() - t0) * 1e3
+                    warm = []
+                    for _ in range(7):
+                        t0 = time.perf_counter()
+                        call()
+                        warm.append((time.perf_counter() - t0) * 1e3)
+                    # phases of a warm call
+                    t0 = time.perf_counter()
+                    lut = _engine.lut_source(model, {})
+                    t_lut = (time.perf_counter() - t0) * 1e3
+                    ctx = _lib.default_context(local_rank)
+                    t0 = time.perf_counter()
+                    with ctx.lock:
+                        _engine.ensure_luts(ctx, lut, None)
+                    t_install = (time.perf_counter() - t0) * 1e3
+                    t0 = time.perf_counter()
+                    _engine.invert_numpy(lut, None, inc, s_vv, None, None, anc)
+                    t_search = (time.perf_counter() - t0) * 1e3
+                out[key][f"lut_build_{route}"] = {"first_call_ms": round(first_ms, 2), "warm_call_ms": round(float(np.median(warm)), 3),
+                                                  "warm_call_ms_min": round(float(np.min(warm)), 3),
+                                                  "warm_phases_ms": {"lut_lookup": round(t_lut, 3), "lut_install_check": round(t_install, 3),
+                                                                     "staging_upload_kernels_download_expand": round(t_search, 3)},
+                                                  "warm_Mpixels_per_s": round(lines * samples / float(np.median(warm)) / 1e3, 1)}
+        out["note"] = ("end to end through the drop-in call: float32 numpy in, complex128 numpy out, sigma0 -> dB by numpy on the host (bit parity); "
+                       "first call = fresh libxsw context and no memoised LUT (host route: numpy GMF fill + device interpolation + numpy log10 + "
+                       "upload of the 362 MB table; device route: xsw_lut_build), then staging start-up; the reference rebuilds its LUT and "
+                       "JIT-compiles its kernel on EVERY call (windspeed.py:144, :306-323)")
+    finally:
+        options.lut_build, options.device = saved
+    return out
 
 
 def nesz_figures(args, ctx, stream, noise, inc, lines, samples):
@@ -973,6 +1102,8 @@ def main():
         if extras and mode == "mono" and args.algo == "pruned" and cfg["lut"] == "cmod5n" and args.resolution == "high":
             res["hard_scene"] = hard_scene_figures(ctx, _lib, stream, device, samples, algo, min(4000, lines))
         if extras:
+            res["gmf_eval"] = gmf_eval_figures(args, ctx, stream, device)
+            res["latency"] = latency_figures(local_rank)
             res["detrend"] = detrend_figures(args, ctx, stream, s_vv, lines, samples)
             res["nesz_flatten"] = nesz_figures(args, ctx, stream, s_vv, inc, lines, samples)
         if n_gpus == 1 and not args.no_cpu_baseline and mode == "mono":

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define XSW_VERSION 3
+#define XSW_VERSION 4
 
 enum { XSW_F32 = 0, XSW_F64 = 1 };           /* raster element type (complex rasters: c64 / c128) */
 enum { XSW_MEM_HOST = 0, XSW_MEM_DEVICE = 1,
@@ -214,9 +214,19 @@ int xsw_host_free(xsw_ctx *ctx, void *p);
  * frees the workers that are no longer used at once. */
 int xsw_set_host_threads(xsw_ctx *ctx, int n);
 
-/* Enable (1) / disable (0) device-side work counters; read them after synchronising. */
+/* Enable (1) / disable (0) device-side work counters; read them after synchronising.  on = 1: XSW_ALGO_PRUNED runs its statistics
+ * instantiation (k_invert_band sweeps every window itself and counts every candidate it scores: cand_co is what the band rule
+ * leaves of the grid).  XSW_VERSION >= 4, on = 2: the PRODUCTION chain runs unchanged and the kernels behind k_invert_band count
+ * what THEY score (xsw_stats_read_chain): measured candidates per second of k_invert_band2 / k_invert_blocks / k_invert_list. */
 int xsw_stats_enable(xsw_ctx *ctx, int on);
 int xsw_stats_read(xsw_ctx *ctx, xsw_stats *out);
+typedef struct {
+    uint64_t cand_band2;      /* candidates scored by k_invert_band2 (after contour bound and joint shrink)          */
+    uint64_t cand_blocks;     /* candidates scored by k_invert_blocks (64 per swept block)                            */
+    uint64_t cand_list;       /* candidates scored by k_invert_list                                                   */
+    uint64_t pixels_refined;  /* list-B records k_invert_band2 put through its refinement (contour bound, live arc)  */
+} xsw_chain_stats;
+int xsw_stats_read_chain(xsw_ctx *ctx, xsw_chain_stats *out);
 
 /* Measurement aid (no reference counterpart): while enabled, every XSW_ALGO_PRUNED inversion of DEVICE rasters that takes the
  * two-kernel path (k_invert_band, then k_invert_list on the pixels it left undecided) is bracketed by HIP events on the launch

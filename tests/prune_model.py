@@ -510,6 +510,14 @@ def contour_bound(slice_wp, inv_tab, grid, mono, wh, cphi, sphi, s, ah, bh, inv_
     return jc, n
 
 
+def table_bins_margin(t0, inv_width, bins, thr_lo, thr_hi):
+    """(lower bin, upper bin or `bins`) WITH A BIN OF MARGIN, as k_invert_band2 picks them per direction (xsw_band2.hpp:
+    bins_margin): t_(b_lo) <= thr_lo - width + rounding, t_(b_hi) >= thr_hi + width - rounding -- no exact search of the bin needed."""
+    b_lo = max(int(min(max((thr_lo - t0) * inv_width, 0.0), float(bins - 1))) - 1, 0)
+    b_hi = min(max(int(np.floor(min(max((thr_hi - t0) * inv_width, -3.0), float(bins)))) + 2, 0), bins)
+    return b_lo, b_hi
+
+
 def _chord_from_budget(uh, m2, bud, w0, inv_wstep):
     """Rows with wh^2 - 2 uh wh + m2 <= bud (uh = U/2), as chord_rows computes them (float32 root, inflated); None: no row."""
     disc = uh * uh + ((bud - m2) + 1e-9 * (abs(bud) + m2))
@@ -541,13 +549,14 @@ def joint_rows(inv_col, grid, s, dsig, j_ub, uh, m2, wh0, whs, w0, inv_wstep, w_
         bud = j_ub - jw_lb
         if bud < 0.0:
             return 1, 0, reads
-        d = band_radius(bud, dsig)
-        b_lo, b_hi = table_bins(t0, width, inv_width, bins, s - d, s + d)
-        first, last = band_rows_from_table(inv_col, b_lo, b_hi, lo, hi)
+        d = float(np.sqrt(np.float32(max(bud, 0.0)))) * (1.0 + 1e-6) * abs(dsig) + 1e-9
+        b_lo, b_hi = table_bins_margin(t0, inv_width, bins, s - d, s + d)
         reads += 2
-        lo, hi = max(lo, first), min(hi, last)
+        lo = max(lo, int(inv_col[b_lo]))
+        if b_hi < bins:
+            hi = min(hi, int(inv_col[b_hi]) - 1)
         vlo = (b_lo * width + t0) if b_lo > 0 else -np.inf
-        vhi = (b_hi * width + t0) if b_hi >= 0 else np.inf
+        vhi = (b_hi * width + t0) if b_hi < bins else np.inf
         if lo > hi:
             break
         # A: the smallest sigma0 term over rows whose LUT value lies in [vlo, vhi)

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/xsw.h but not exported"
     assert sorted(_lib.EXPORTS) == names
-    assert lib.xsw_version() == 3
+    assert lib.xsw_version() == 4
 
 
 def test_struct_layouts_match_header():

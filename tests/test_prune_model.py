@@ -346,3 +346,84 @@ def test_block_pyramid_finds_the_oracle_argmin(kind):
     assert np.mean(swept_bound) < 0.08 * nblocks, (np.mean(swept_bound), nblocks)
     # outliers alone (their windows are the whole grid): still a small part of the table
     assert np.mean(swept_bound[:150]) < 0.15 * nblocks, np.mean(swept_bound[:150])
+
+
+def _lut_for(kind, rng):
+    inc_ax, w_ax, phi_ax = np.linspace(20, 44, 5), np.linspace(0.5, 39.5, 196), np.linspace(0, 180, 91)
+    co = 10 * np.log10(gmf.gmf_cmod5n(inc_ax[:, None, None], w_ax[None, :, None], phi_ax[None, None, :]) + 1e-15)
+    if kind == "plateaus":
+        co = np.round(co / 0.05) * 0.05
+    elif kind == "rolloff":
+        co = co - 0.004 * np.maximum(w_ax[None, :, None] - 22.0, 0.0) ** 2
+    return inc_ax, w_ax, phi_ax, co
+
+
+@pytest.mark.parametrize("kind", ["smooth", "plateaus", "rolloff"])
+def test_contour_bound_and_joint_shrink_never_exclude_the_argmin(kind):
+    """Round 5 (k_invert_band2): the contour bound + per-direction joint shrink of window and band find the oracle's argmin on
+    pixels whose a-priori wind is far from the sigma0 contour (x 0.3 ... x 2.5 of the truth) -- with a small fraction of the
+    candidates the separate bounds leave."""
+    rng = np.random.default_rng({"smooth": 11, "plateaus": 12, "rolloff": 13}[kind])
+    inc_ax, w_ax, phi_ax, co = _lut_for(kind, rng)
+    lco = olut.Lut(co, inc_ax, w_ax, phi_ax, "dB", "x", "co", "VV")
+    p = oinv.Prepared(lco, None)
+    n = 240
+    inc, wt, pt = rng.uniform(21, 43, n), rng.uniform(3, 25, n), rng.uniform(-180, 180, n)
+    s = oinv.to_db(gmf.gmf_cmod5n(inc, wt, pt) * rng.gamma(100, 1 / 100, n))
+    scale = rng.choice([0.3, 0.6, 1.0, 1.6, 2.5], n)
+    anc = scale * wt * np.exp(1j * np.deg2rad(pt)) + rng.normal(0, 1.5, n) + 1j * rng.normal(0, 1.5, n)
+    nan = np.full(n, np.nan)
+    idx = cport.invert_numpy(p, inc, s, nan, nan, anc, return_idx=True, reference_layout=False)[2]
+    cphi, sphi = np.cos(np.radians(phi_ax)), np.sin(np.radians(phi_ax))
+    swept, plain, done = [], [], 0
+    for i in range(n):
+        ii = np.argmin(np.abs(inc_ax - inc[i]))
+        r = pm.refined_band_argmin(co[ii], w_ax, phi_ax, cphi, sphi, p.phi_180, s[i], anc[i].real, anc[i].imag, 0.1, bins=512)
+        if r is None:
+            continue  # (handed on: near-tie, or a tail longer than the sweep takes)
+        done += 1
+        assert (r[0], r[1]) == (idx[i, 0], idx[i, 1]), (kind, i, r, idx[i])
+        swept.append(r[2])
+        r0 = pm.refined_band_argmin(co[ii], w_ax, phi_ax, cphi, sphi, p.phi_180, s[i], anc[i].real, anc[i].imag, 0.1, bins=512, rounds=1, use_contour=False)
+        if r0 is not None:
+            assert (r0[0], r0[1]) == (idx[i, 0], idx[i, 1])
+            plain.append(r0[2])
+    assert done > 0.8 * n
+    assert np.mean(swept) < 0.5 * np.mean(plain), (np.mean(swept), np.mean(plain))
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_joint_rows_keep_every_candidate_under_the_bound(seed):
+    """`joint_rows` (steps B, A, B, A from the inverse-row table alone) never drops a row whose score is within the bound, for
+    random directions, bounds and sigma0 on a monotone column; and `table_bins_margin` brackets the thresholds."""
+    rng = np.random.default_rng(100 + seed)
+    n_w = 160
+    w_ax = np.linspace(0.4, 32.2, n_w)
+    wh = 0.5 * w_ax
+    w0, inv_wstep = w_ax[0], (n_w - 1) / (w_ax[-1] - w_ax[0])
+    for case in range(400):
+        col = np.cumsum(rng.uniform(0.0, 0.3, n_w)) - 30.0
+        if case % 5 == 0:
+            col = np.round(col / 0.1) * 0.1  # plateaus
+        bins = int(rng.choice([64, 512, 2048]))
+        width = (col.max() - col.min()) / (bins - 2)
+        grid = (col.min() - width, width, 1.0 / width)
+        inv_col = pm.inverse_rows(col, n_w, grid[0], grid[1], bins)
+        s = rng.uniform(col.min() - 1.0, col.max() + 1.0)
+        dsig = float(rng.choice([0.1, 0.3, 1.0]))
+        ah, bh = rng.uniform(-12, 12, 2)
+        m2 = ah * ah + bh * bh
+        ang = rng.uniform(0, np.pi)
+        uh = ah * np.cos(ang) + bh * np.sin(ang)
+        J = wh * (wh - 2 * uh) + m2 + ((col - s) / dsig) ** 2
+        j_ub = float(rng.choice([J.min() * (1 + 1e-9) + 1e-9, np.quantile(J, rng.uniform(0, 0.3)), rng.uniform(0.1, 80.0)]))
+        w_lo, w_hi = sorted(rng.integers(0, n_w, 2))
+        for rounds in (1, 2, 3):
+            lo, hi, _ = pm.joint_rows(inv_col, grid, s, dsig, j_ub, uh, m2, wh[0], wh[1] - wh[0], w0, inv_wstep, int(w_lo), int(w_hi), rounds)
+            under = np.nonzero(J[w_lo:w_hi + 1] <= j_ub)[0] + w_lo
+            if under.size:
+                assert lo <= under.min() and under.max() <= hi, (case, rounds, lo, hi, under.min(), under.max())
+        thr_lo, thr_hi = s - rng.uniform(0, 2), s + rng.uniform(0, 2)
+        b_lo, b_hi = pm.table_bins_margin(grid[0], grid[2], bins, thr_lo, thr_hi)
+        assert b_lo == 0 or b_lo * width + grid[0] <= thr_lo
+        assert b_hi == bins or b_hi * width + grid[0] > thr_hi

@@ -22,7 +22,7 @@ GMF_IDS = {"gmf_cmod5": 0, "gmf_cmod5n": 1, "gmf_cmod5n_pr_zhangA": 2, "gmf_cmod
 
 EXPORTS = (
     "xsw_version", "xsw_device_count", "xsw_ctx_create", "xsw_ctx_destroy", "xsw_last_error", "xsw_set_stream", "xsw_use_own_stream",
-    "xsw_synchronize", "xsw_lut_upload", "xsw_invert", "xsw_stats_enable", "xsw_stats_read", "xsw_detrend", "xsw_lut_interp", "xsw_gmf_eval",
+    "xsw_synchronize", "xsw_lut_upload", "xsw_invert", "xsw_stats_enable", "xsw_stats_read", "xsw_stats_read_chain", "xsw_detrend", "xsw_lut_interp", "xsw_gmf_eval",
     "xsw_nesz_flatten", "xsw_lut_build", "xsw_lut_read", "xsw_timing_enable", "xsw_timing_read", "xsw_expand_codes", "xsw_expand_codes_on_stream",
     "xsw_host_alloc", "xsw_host_free", "xsw_set_host_threads",
 )
@@ -56,12 +56,16 @@ STAGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int32, ctype
 STAGE_INC, STAGE_SIGMA0_CO, STAGE_SIGMA0_CR, STAGE_DSIG_CR, STAGE_ANC = range(5)
 
 
-ABI_VERSION = 3  # include/xsw.h: XSW_VERSION
+ABI_VERSION = 4  # include/xsw.h: XSW_VERSION
 
 
 class Stats(ctypes.Structure):
     _fields_ = [("pixels_co", ctypes.c_uint64), ("cand_co", ctypes.c_uint64), ("pixels_exact", ctypes.c_uint64),
                 ("pixels_cr", ctypes.c_uint64)]
+
+
+class ChainStats(ctypes.Structure):
+    _fields_ = [("cand_band2", ctypes.c_uint64), ("cand_blocks", ctypes.c_uint64), ("cand_list", ctypes.c_uint64), ("pixels_refined", ctypes.c_uint64)]
 
 
 class Timing(ctypes.Structure):
@@ -120,6 +124,7 @@ def load():
         lib.xsw_invert.argtypes = [ctypes.c_void_p, ctypes.POINTER(InvertArgs)]
         lib.xsw_stats_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.xsw_stats_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(Stats)]
+        lib.xsw_stats_read_chain.argtypes = [ctypes.c_void_p, ctypes.POINTER(ChainStats)]
         lib.xsw_detrend.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                     ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.xsw_lut_interp.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4 + [ctypes.c_int32] * 3 + \
@@ -296,6 +301,13 @@ class Context:
         return out
 
     @_locked
+    def gmf_eval_raw(self, gmf_id, n, mem, inc_ptr, wspd_ptr, phi_ptr, out_ptr):
+        """Thin call of xsw_gmf_eval (pointers are ints or None: float64 arrays of n already-broadcast elements; device
+        pointers with MEM_DEVICE: asynchronous on the context's stream)."""
+        self._check(self._lib.xsw_gmf_eval(self._h, int(gmf_id), int(n), mem, _ptr(inc_ptr), _ptr(wspd_ptr), _ptr(phi_ptr), _ptr(out_ptr)),
+                    "xsw_gmf_eval")
+
+    @_locked
     def timing_enable(self, on=True):
         self._check(self._lib.xsw_timing_enable(self._h, int(bool(on))), "xsw_timing_enable")
 
@@ -308,7 +320,15 @@ class Context:
 
     @_locked
     def stats_enable(self, on=True):
-        self._check(self._lib.xsw_stats_enable(self._h, int(bool(on))), "xsw_stats_enable")
+        """on = True: the statistics instantiation (every window swept in k_invert_band, every candidate counted); on = 2: the
+        production chain with per-kernel counters (`stats_chain`)."""
+        self._check(self._lib.xsw_stats_enable(self._h, 2 if on == 2 else int(bool(on))), "xsw_stats_enable")
+
+    @_locked
+    def stats_chain(self):
+        s = ChainStats()
+        self._check(self._lib.xsw_stats_read_chain(self._h, ctypes.byref(s)), "xsw_stats_read_chain")
+        return {k: int(getattr(s, k)) for k, _ in ChainStats._fields_}
 
     @_locked
     def stats(self):

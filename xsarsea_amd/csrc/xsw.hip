@@ -72,8 +72,8 @@ extern "C" int xsw_ctx_create(int device, xsw_ctx **out)
         HIPCHK(nullptr, hipSetDevice(device));
         HIPCHK(nullptr, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
         c->stream = c->own_stream;
-        HIPCHK(nullptr, hipMalloc((void **)&c->d_stats, 4 * sizeof(unsigned long long)));
-        HIPCHK(nullptr, hipMemset(c->d_stats, 0, 4 * sizeof(unsigned long long)));
+        HIPCHK(nullptr, hipMalloc((void **)&c->d_stats, 8 * sizeof(unsigned long long)));
+        HIPCHK(nullptr, hipMemset(c->d_stats, 0, 8 * sizeof(unsigned long long)));
         return XSW_OK;
     }();
     if (rc != XSW_OK) {  // nothing half-built is handed out or leaked
@@ -225,6 +225,7 @@ extern "C" int xsw_stats_enable(xsw_ctx *c, int on)
 {
     if (!c) return XSW_EINVAL;
     c->stats_on = on != 0;
+    c->stats_chain = on == 2;  // counters of the PRODUCTION chain (xsw_stats_read_chain), not of the statistics instantiation
     return XSW_OK;
 }
 
@@ -282,6 +283,20 @@ extern "C" int xsw_stats_read(xsw_ctx *c, xsw_stats *out)
     out->cand_co = h[1];
     out->pixels_exact = h[2];
     out->pixels_cr = h[3];
+    return XSW_OK;
+}
+
+extern "C" int xsw_stats_read_chain(xsw_ctx *c, xsw_chain_stats *out)
+{
+    if (!c || !out) return XSW_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    unsigned long long h[8];
+    HIPCHK(c, hipMemcpy(h, c->d_stats, sizeof h, hipMemcpyDeviceToHost));
+    out->cand_band2 = h[4];
+    out->cand_blocks = h[5];
+    out->cand_list = h[6];
+    out->pixels_refined = h[7];
     return XSW_OK;
 }
 
@@ -645,8 +660,8 @@ static void ensure_list(xsw_ctx *c, long long n, long long lines)
     c->d_rec = nullptr;
     c->list_cap = c->mask_strips = 0;
     static const bool no_list = getenv("XSW_FAIL_LIST_ALLOC") != nullptr;  // tests: the allocation-failure route
-    // lists G and B (`want` entries each) and C (XSW_LIST_C_SHARE x want), then the two strip masks (0.25 B per pixel)
-    if (!no_list && hipMalloc((void **)&c->d_list, (XSW_LISTS_TOTAL * want + 16) * sizeof(unsigned) + 2 * want_strips * sizeof(unsigned long long) + want * XSW_REC_BYTES) == hipSuccess) {
+    // list G (`want` entries), B (XSW_LIST_B_SHARE x want) and C (XSW_LIST_C_SHARE x want), the two strip masks (0.25 B per pixel), list B's records
+    if (!no_list && hipMalloc((void **)&c->d_list, (XSW_LISTS_TOTAL * want + 16) * sizeof(unsigned) + 2 * want_strips * sizeof(unsigned long long) + (size_t)XSW_LIST_B_SHARE * want * XSW_REC_BYTES) == hipSuccess) {
         c->list_cap = want;
         c->d_masks = (unsigned long long *)(c->d_list + 16 + XSW_LISTS_TOTAL * want);
         c->d_rec = (void *)(c->d_masks + 2 * want_strips);
@@ -898,8 +913,9 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
     A.dual_select = a->dual_select;
     if (!(std::isfinite(A.inv_dsig_co) && A.inv_dsig_co != 0.0) && algo != XSW_ALGO_EXACT) algo = XSW_ALGO_EXACT;
     if (c->stats_on) {
-        HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 4 * sizeof(unsigned long long), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(unsigned long long), c->stream));
         A.stats = c->d_stats;
+        A.stats_chain = c->stats_chain ? 1 : 0;
     }
 
     if (a->mem == XSW_MEM_DEVICE) {
@@ -951,8 +967,8 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
         const size_t max_px = (size_t)std::min<long long>(lpc, lines) * samples;
         auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
         const size_t o_co = 0, o_cr = o_co + (a->sigma0_co ? pad(max_px * es) : 0), o_end = o_cr + (a->sigma0_cr ? pad(max_px * es) : 0);
-        const size_t list_cap = std::max<size_t>(max_px / 4, 1 << 14) & ~(size_t)1, mask_strips = strips_for((long long)max_px, lpc);
-        const size_t o_masks = o_end + pad((XSW_LISTS_TOTAL * list_cap + 16) * sizeof(unsigned)), o_rec = o_masks + 2 * mask_strips * sizeof(unsigned long long), dev_bytes = o_rec + list_cap * XSW_REC_BYTES;
+        const size_t list_cap = std::max<size_t>(max_px / 8, 1 << 14) & ~(size_t)1, mask_strips = strips_for((long long)max_px, lpc);
+        const size_t o_masks = o_end + pad((XSW_LISTS_TOTAL * list_cap + 16) * sizeof(unsigned)), o_rec = o_masks + 2 * mask_strips * sizeof(unsigned long long), dev_bytes = o_rec + XSW_LIST_B_SHARE * list_cap * XSW_REC_BYTES;
         const int dtype = a->dtype, out_dtype = a->out_dtype;
         auto shift = [](const void *p, size_t bytes) -> const void * { return p ? (const char *)p + bytes : nullptr; };
         const int rc_all = run_chunks(c, nchunks, [&](long long k, xsw_ctx::Worker &w, std::string &err) -> int {
@@ -1022,8 +1038,8 @@ extern "C" int xsw_invert(xsw_ctx *c, const xsw_invert_args *a)
                  o_dsig = o_cr + (a->sigma0_cr ? pad(max_px * es) : 0), o_anc = o_dsig + (a->dsig_cr ? pad(max_px * es) : 0),
                  o_cc = o_anc + (a->anc ? pad(max_px * es * 2) : 0), o_ccr = o_cc + (want_co ? pad(max_px * 4) : 0),
                  o_end = o_ccr + (want_cr ? pad(max_px * 4) : 0);
-    const size_t list_cap = std::max<size_t>(max_px / 4, 1 << 14) & ~(size_t)1, mask_strips = strips_for((long long)max_px, lines_per_chunk);
-    const size_t o_masks = o_end + pad((XSW_LISTS_TOTAL * list_cap + 16) * sizeof(unsigned)), o_rec = o_masks + 2 * mask_strips * sizeof(unsigned long long), dev_bytes = o_rec + list_cap * XSW_REC_BYTES;  // lists G, B and C, strip masks, list B's records
+    const size_t list_cap = std::max<size_t>(max_px / 8, 1 << 14) & ~(size_t)1, mask_strips = strips_for((long long)max_px, lines_per_chunk);
+    const size_t o_masks = o_end + pad((XSW_LISTS_TOTAL * list_cap + 16) * sizeof(unsigned)), o_rec = o_masks + 2 * mask_strips * sizeof(unsigned long long), dev_bytes = o_rec + XSW_LIST_B_SHARE * list_cap * XSW_REC_BYTES;  // lists G, B and C, strip masks, list B's records
     const int dtype = a->dtype, out_dtype = a->out_dtype;
     static const bool prof = getenv("XSW_HOST_PROFILE") != nullptr;  // phase times of the pipeline on stderr (experiments)
     std::atomic<long long> t_stage{0}, t_gpu{0}, t_expand{0}, t_reserve{0};
@@ -1230,8 +1246,8 @@ extern "C" int xsw_lut_build(xsw_ctx *c, int32_t gmf_id, const double *inc_raw, 
     const double *d_p = copol ? (const double *)dev(phi_raw, (size_t)n_phi_raw * 8) : nullptr;
     double *d_raw = (double *)dev(nullptr, n_raw * 8);
     if (!rc) {
-        hipLaunchKernelGGL(k_gmf_grid, dim3((unsigned)std::min<size_t>((n_raw + 255) / 256, 256 * 16)), dim3(256), 0, c->stream, (int)gmf_id,
-                           d_i, d_w, d_p, n_inc_raw, n_wspd_raw, copol ? n_phi_raw : 0, d_raw);
+        XSW_GMF_DISPATCH(gmf_id, hipLaunchKernelGGL((k_gmf_grid<M>), dim3((unsigned)std::min<size_t>((n_raw + 255) / 256, 256 * 16)), dim3(256), 0, c->stream,
+                                                    (int)gmf_id, d_i, d_w, d_p, n_inc_raw, n_wspd_raw, copol ? n_phi_raw : 0, d_raw));
         if (hipGetLastError() != hipSuccess) rc = fail(c, XSW_EHIP, "lut_build: launch failed");
     }
     // resolution change only when the grids differ (Model._normalize_lut returns the raw LUT as is otherwise)
@@ -1295,7 +1311,7 @@ extern "C" int xsw_gmf_eval(xsw_ctx *c, int32_t gmf_id, int64_t n, int32_t mem, 
     if (e == hipSuccess) {
         long long blocks = (n + 255) / 256;
         if (blocks > 256 * 16) blocks = 256 * 16;
-        hipLaunchKernelGGL(k_gmf_eval, dim3((unsigned)blocks), dim3(256), 0, c->stream, (int)gmf_id, (long long)n, d_inc, d_w, d_phi, d_out);
+        XSW_GMF_DISPATCH(gmf_id, hipLaunchKernelGGL((k_gmf_eval<M>), dim3((unsigned)blocks), dim3(256), 0, c->stream, (int)gmf_id, (long long)n, d_inc, d_w, d_phi, d_out));
         e = hipGetLastError();
     }
     if (mem == XSW_MEM_HOST) {

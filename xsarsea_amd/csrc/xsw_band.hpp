@@ -75,6 +75,9 @@ namespace xsw {
                             // environment XSW_TAIL_SWEEP).  Measured (Mpx/s, 0 / 96 / 192 / 400 rows): a-priori x 1.6 1107 / 1186 / 1193 / 1191,
                             // x 2.5 252 / 331 / 394 / 396, incidence 17..33 deg x 1.6 421 / 473 / 570 / 560, 17..25 deg 2460 / 2654 / 2612 / 2651
 #endif
+#ifndef XSW_B2_HARD_AREA
+#define XSW_B2_HARD_AREA 256  // band candidates (run x directions) from which a handed pixel is marked for k_invert_band2's refinement
+#endif
 #ifndef XSW_BAND_SEEDED
 #define XSW_BAND_SEEDED 1  // first ray seeded from the inverse-row table (co_window_lanes)
 #endif
@@ -106,11 +109,19 @@ struct BandSlot {  // 64 bytes per pixel, read by every lane of its segment (sam
     int bin_hi /* threshold bin above s + d, or -1 */;
 };
 
-struct BandRec {  // what k_invert_band hands to k_invert_band2 per pixel (KArgs::rec_b): 72 bytes, written and read coalesced
-    BandSlot slot;  // (bin_hi in k_invert_band2's encoding: the window's tail rows in its upper half)
-    unsigned idx;   // pixel index
-    int flags;      // the pixel's class bits (+ its incidence bin << 8 for the cross-pol phase)
+struct BandRec {  // what k_invert_band hands to k_invert_band2 per pixel (KArgs::rec_b): 48 bytes, written and read coalesced
+    double s, ah, bh;  // sigma0 in dB; the ancillary wind / 2 (b: |b| for a 0..180 deg LUT)
+    float d;           // band radius |dsig| sqrt(J_ub) as stage 1 inflated it, rounded up: J_ub is recovered from it
+    int inc_tail;      // incidence bin | rows of the window past the monotone ones (the tail) << 16
+    int rows;          // w_lo | last row of the monotone part << 16 (the window cut at the slice's last monotone row)
+    int ipn;           // ip_lo | directions << 16
+    unsigned idx;      // pixel index
+    int flags;         // the pixel's class bits
 };
+struct Band2Slot;
+template <typename T, typename TO, bool CR>
+__device__ __forceinline__ void band2_core(const DevTables &L, const KArgs &A, const BandRec &r, bool in, bool searchable, int lane, Band2Slot *__restrict__ slots,
+                                           int *__restrict__ res_, long long strip);
 
 __device__ __forceinline__ unsigned long long ballot64(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 __device__ __forceinline__ double ld_co(const char *__restrict__ base, unsigned off0, int row, unsigned rowB)
@@ -118,33 +129,21 @@ __device__ __forceinline__ double ld_co(const char *__restrict__ base, unsigned 
     return *(const double *)(base + (off0 + __umul24((unsigned)row, rowB)));
 }
 
-// CHORD (k_invert_band2): the rows of a direction are also clipped to the chord the disc |c - m| <= 2 sqrt(J_ub) cuts out of that direction's ray
-// (the window is only the disc's bounding box in (speed, direction): in a wide window most directions cross the band rows
-// OUTSIDE the disc, where the wind term alone already exceeds J_ub).  Along direction e, with U = m . e and wh = w / 2:
-// wh^2 - U wh + |m|^2/4 <= J_ub  <=>  |wh - U/2| <= sqrt(U^2/4 - |m|^2/4 + J_ub).  J_ub is recovered from the band's half
-// width (thr_hi - thr_lo) / 2 = |dsig| sqrt(J_ub) (1 + 1e-6) + 1e-9 (co_window_lanes), i.e. already inflated; float32 square
-// root, inflated again, and XSW_CHORD_MRG index units of slack on the row bounds (as box_from_jub).
 #ifndef XSW_CHORD_MRG
-#define XSW_CHORD_MRG 2e-3
+#define XSW_CHORD_MRG 2e-3  // index units of slack on a chord's row bounds (k_invert_band2: chord_budget; as box_from_jub)
 #endif
-// k_invert_band2 only (its long-run role): in k_invert_band the clip costs more than it saves (measured with every window
-// swept there, band kernel at 20000^2: no clip 46.8 ms; segments of 64 lanes 47.2; >= 32: 48.4; >= 16: 50.6).
-template <int S, int K, bool COUNT, bool BATCH = false>
+template <int S, int K, bool COUNT>
 __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig, int lane,
                                              const BandSlot *slots /* this wave's [64], sorted by class */, int *res /* [64], by slot */,
                                              int first, int count /* slots [first, first + count) -> segments 0 .. count-1 */, unsigned &cand)
 {
-    constexpr int sweep_max = (BATCH && S >= XSW_BAND_BATCH_S) ? XSW_SWEEP_MAX : XSW_BAND_MAX;  // rows a direction may hold
+    constexpr int sweep_max = XSW_BAND_MAX;  // rows a direction may hold
     const double inf = __builtin_inf();
     const int q = lane / S, sl = lane & (S - 1);
     const bool valid = q < count;
     const int owner = valid ? first + q : lane;  // slot index (idle segment: any slot, its contents are overridden below)
     BandSlot B = slots[owner];
     if (!valid) { B.inc_bin = 0; B.rows = 0; B.ipn = 0; B.bin_hi = -1; }  // idle segment: harmless addresses, nothing scored
-    // ROLE 2 slots carry the TAIL of the window in the upper half of bin_hi: rows w_hi + 1 .. w_hi + tail_n lie past the slice's
-    // monotone rows (w_hi = the last monotone row) and are swept in full, after the band rows of the monotone part (band_wave)
-    const int tail_n = BATCH ? (int)((unsigned)B.bin_hi >> 16) : 0;
-    if (BATCH) B.bin_hi = (int)(short)(B.bin_hi & 0xffff);
     const int B_ip_lo = B.ipn & 0xffff, B_ncols = (int)((unsigned)B.ipn >> 16);
     const int w_lo = B.rows & 0xffff, w_hi = B.rows >> 16;
     const double thr_lo = B.thr_lo, thr_hi = B.thr_hi, sn = B.sn;
@@ -161,13 +160,6 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
     const unsigned inv_rowB = (unsigned)L.phi_pad * 2u;
     const unsigned inv0 = mul24_sv(inv_rowB, (unsigned)(i_inc * XSW_INV_BINS) + ((unsigned)B.inc_bin >> 16));
     const unsigned inv1 = mul24_sv(inv_rowB, (unsigned)(i_inc * XSW_INV_BINS) + (unsigned)max(B.bin_hi, 0));
-    constexpr bool CHORD = BATCH;
-    double jrel = 0.0, inv_whs = 0.0;  // J_ub - |m|^2/4 (inflated); rows per unit of wh
-    if (CHORD) {
-        const double rs = 0.5 * (thr_hi - thr_lo) * fabs(inv_dsig);  // >= sqrt(J_ub) (1 + 1e-6)
-        jrel = fma(rs, rs, -B.m2) + 1e-9 * (rs * rs + B.m2);
-        inv_whs = 2.0 * L.inv_wstep;
-    }
     double best = inf, second = inf;
     int brow = 0, bip = 0;
     unsigned ncand = 0;
@@ -177,7 +169,6 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
     for (int ch = 0; ch < nchunks; ++ch) {
         bool act[K];
         int ip[K], r[K], nrow[K];
-        int n1[K], gap[K];  // CHORD (ROLE 2): rows of the first run (band rows of the monotone part), and the jump to the tail's first row
         unsigned off0[K];
         double U[K];
 #pragma unroll
@@ -198,64 +189,10 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
             const int ra = (int)*(const unsigned short *)((const char *)inv_tab + o_first);
             const int rb = (int)*(const unsigned short *)((const char *)inv_tab + o_last);
             r[j] = max(ra, w_lo);
-            int last = B.bin_hi >= 0 ? min(rb - 1, w_hi) : w_hi;
-            if (CHORD) {
-                const double Uh = 0.5 * U[j];
-                const double disc = fma(Uh, Uh, jrel);  // (half chord)^2 in wh units; < 0: the ray misses the disc
-                const double h = (double)__builtin_sqrtf((float)fmax(disc, 0.0)) * (1.0 + 1e-6) + 1e-6;
-                const double xc = (Uh - wh0) * inv_whs, xh = fma(h, inv_whs, XSW_CHORD_MRG);
-                const int c_lo = (int)ceil(fmax(xc - xh, -4.0)), c_hi = (int)floor(fmin(xc + xh, 40000.0));
-                r[j] = max(r[j], min(c_lo, L.n_w));
-                last = disc < 0.0 ? r[j] - 1 : min(last, c_hi);
-                // the tail (rows past the monotone ones, every one a candidate), clipped to the same chord
-                const int r2 = max(max(w_hi + 1, w_lo), min(c_lo, L.n_w)), last2 = disc < 0.0 ? r2 - 1 : min(w_hi + tail_n, c_hi);
-                n1[j] = max(last - r[j] + 1, 0);
-                gap[j] = r2 - (r[j] + n1[j]);
-                nrow[j] = act[j] ? n1[j] + max(last2 - r2 + 1, 0) : 0;
-            } else {
-                n1[j] = 0x7fffffff; gap[j] = 0;
-                nrow[j] = act[j] ? last - r[j] + 1 : 0;
-            }
+            const int last = B.bin_hi >= 0 ? min(rb - 1, w_hi) : w_hi;
+            nrow[j] = act[j] ? last - r[j] + 1 : 0;
             nmax = max(nmax, nrow[j]);
         }
-        if (BATCH && S >= XSW_BAND_BATCH_S) {
-            // k_invert_band2's pixels (long runs of band rows: an a-priori wind far from the sigma0 contour, or a flat stretch of
-            // the GMF): the sweep is a chain of dependent load round trips -- take the rows XSW_BAND_BATCH at a time, all loads
-            // of a batch in flight before the first is scored.  (k_invert_band's runs are 1-3 rows: batching costs there.)
-#pragma unroll 1
-            for (int t0 = 0; t0 < sweep_max; t0 += XSW_BAND_BATCH) {
-                unsigned long long left[K], any_left = 0ULL;
-#pragma unroll
-                for (int j = 0; j < K; ++j) { left[j] = ballot64(t0 < nrow[j]); any_left |= left[j]; }
-                if (any_left == 0ULL) break;
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    if (left[j] == 0ULL) continue;
-                    double v[XSW_BAND_BATCH];
-                    int rc[XSW_BAND_BATCH];
-#pragma unroll
-                    for (int u = 0; u < XSW_BAND_BATCH; ++u) {
-                        const int tt = t0 + u;
-                        rc[u] = CHORD ? min(r[j] + tt + (tt >= n1[j] ? gap[j] : 0), w_hi + tail_n) : min(r[j] + tt, w_hi);
-                        v[u] = ld_co(base, off0[j], rc[u], rowB);
-                    }
-#pragma unroll
-                    for (int u = 0; u < XSW_BAND_BATCH; ++u) {
-                        const bool inb = t0 + u < nrow[j];
-                        const double wh = fma((double)rc[u], whs, wh0);
-                        const double dd = fma(v[u], inv_dsig, sn);
-                        double J = fma(dd, dd, wh * (wh - U[j]));
-                        J = inb ? J : inf;
-                        second = vmin(second, vmax(J, best));
-                        const bool lt = J < best;
-                        brow = lt ? rc[u] : brow;
-                        bip = lt ? ip[j] : bip;
-                        best = vmin(best, J);
-                        if (COUNT) ncand += inb ? 1u : 0u;
-                    }
-                }
-            }
-        } else {
 #pragma unroll 1
         for (int t = 0; t < XSW_BAND_MAX; ++t) {  // scalar trip counter; the loop leaves as soon as no lane has rows left
             unsigned long long left[K], any_left = 0ULL;
@@ -284,7 +221,6 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
                 best = vmin(best, J);
                 if (COUNT) ncand += inb ? 1u : 0u;
             }
-        }
         }
         const bool any = nmax > sweep_max;
         overflow = overflow || any;  // rows left after XSW_BAND_MAX trips
@@ -340,7 +276,7 @@ __device__ __forceinline__ void mask_mark(unsigned long long *__restrict__ mask,
 // `strip` of the raster (lane = sample); -1: listed pixels.
 template <typename T, typename TO, bool CR, bool COUNT>
 __device__ __forceinline__ void wave_tail(const DevTables &L, const KArgs &A, long long i, bool in, int lane, int flags, int my_flat, long long strip,
-                                          unsigned cand)
+                                          unsigned cand, int chain_slot = 0 /* chain statistics: the kernel's own counter (A.stats[chain_slot]) */)
 {
     const bool to_b = A.list_b != nullptr && (flags & F_TO_B) != 0, to_c = (flags & F_TO_C) != 0;  // (they ride in `flags`: no register of their own through the passes)
     const double nan = __builtin_nan("");
@@ -370,6 +306,7 @@ __device__ __forceinline__ void wave_tail(const DevTables &L, const KArgs &A, lo
         if (lane == 0) {
             atomicAdd(&A.stats[0], (unsigned long long)__popcll(done_co));
             atomicAdd(&A.stats[1], (unsigned long long)cand);
+            if (chain_slot && A.stats_chain) atomicAdd(&A.stats[chain_slot], (unsigned long long)cand);
             atomicAdd(&A.stats[3], (unsigned long long)__popcll(done_cr));
         }
     }
@@ -488,6 +425,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                 if (bhi < XSW_INV_BINS && !(fma((double)bhi, width, t0) > thr_hi)) ++bhi;
                 if (bhi < XSW_INV_BINS && !(fma((double)bhi, width, t0) > thr_hi)) bhi = XSW_INV_BINS;
             }
+            bool hard = false;  // ROLE 1: the handed pixel is worth k_invert_band2's refinement (long run x wide window, or a tail)
             int myc = NC;
             if (eligb) {
                 const int nv = ncols_p;
@@ -523,7 +461,8 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                     if (ROLE == 2) skip = true;
                     if (ROLE == 1) flags |= F_TO_C;
                 }
-                const bool handed = eligb && (run >= A.long_run || has_tail);  // (a tail is k_invert_band2's whatever the run's length)
+                hard = has_tail || run * ncols_p >= XSW_B2_HARD_AREA || ncols_p >= 64;
+                const bool handed = eligb && (run >= A.long_run || has_tail || ncols_p >= A.wide_min);  // (a tail is k_invert_band2's whatever the run's length; a WIDE window costs a pass of its own here, while k_invert_band2 first narrows it to its live arc)
                 if (ROLE == 1 && handed) {  // the second band kernel's
                     myc = NC;
                     eligb = false;
@@ -561,15 +500,28 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                 ncls[c] = __builtin_amdgcn_readfirstlane(ncls[c]);
             }
             const bool to_rec = ROLE == 1 && A.rec_b != nullptr && (flags & F_TO_B) != 0;
+            if constexpr (ROLE == 2) {
+                // k_invert_band2 on a pixel WITHOUT a record (list B as indices, or a pixel marked in the strip mask because its
+                // record did not fit): the record stage 1 of k_invert_band would have written, built here in registers, then
+                // k_invert_band2's own search (xsw_band2.hpp).  A lane this kernel is not for (strip walk: k_invert_band kept the
+                // pixel) is out; a marked pixel that is not searchable (cannot happen: both kernels run the same stage 1) is
+                // passed on like any undecided one.
+                const bool mine = in && !(strip_walk && (skip || (flags & F_NEED_CO) == 0));
+                BandRec r;
+                r.s = P.s_co; r.ah = 0.5 * P.a_re; r.bh = 0.5 * P.b_eff; r.d = __double2float_ru(W.band_d);
+                r.inc_tail = P.i_inc | ((has_tail ? W.w_hi - w_hi_e : 0) << 16);
+                r.rows = W.w_lo | (w_hi_e << 16); r.ipn = W.ip_lo | (ncols_p << 16);
+                r.idx = (unsigned)i; r.flags = flags | F_B2_HARD;  // (no run length at hand here: refine)
+                band2_core<T, TO, CR>(L, A, r, mine, mine && eligb, lane, (Band2Slot *)slots, res_, strip);
+                return;
+            }
             BandSlot b;
-            if (eligb || to_rec) {
+            if (eligb) {
                 const double ah = 0.5 * P.a_re, bh = 0.5 * P.b_eff;
                 b.sn = -P.s_co * A.inv_dsig_co; b.thr_lo = thr_lo; b.thr_hi = thr_hi;
                 b.ah = ah; b.bh = bh; b.m2 = ah * ah + bh * bh;
                 b.inc_bin = P.i_inc | (bin << 16); b.rows = W.w_lo | (w_hi_e << 16); b.ipn = W.ip_lo | (ncols_p << 16);
                 b.bin_hi = bhi < XSW_INV_BINS ? bhi : -1;
-                // k_invert_band2's slots (its own, and the records written for it) carry the window's tail rows in the upper half
-                if (ROLE == 2 || to_rec) b.bin_hi = (b.bin_hi & 0xffff) | ((has_tail ? W.w_hi - w_hi_e : 0) << 16);
             }
             if (ROLE == 1 && A.rec_b != nullptr) {
                 // the handed pixels' RECORDS (their search parameters: k_invert_band2 then neither gathers the rasters again nor
@@ -583,9 +535,11 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                     const unsigned at = at0 + __builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
                     if (to_rec && at < A.list_b_cap) {
                         BandRec r;
-                        r.slot = b;
+                        r.s = P.s_co; r.ah = 0.5 * P.a_re; r.bh = 0.5 * P.b_eff; r.d = __double2float_ru(W.band_d);
+                        r.inc_tail = P.i_inc | ((has_tail ? W.w_hi - w_hi_e : 0) << 16);
+                        r.rows = W.w_lo | (w_hi_e << 16); r.ipn = W.ip_lo | (ncols_p << 16);
                         r.idx = (unsigned)i;
-                        r.flags = flags & ~F_TO_B;
+                        r.flags = (flags & ~F_TO_B) | (hard ? F_B2_HARD : 0);
                         ((BandRec *)A.rec_b)[at] = r;
                         flags |= F_REC_DONE;
                     }
@@ -611,7 +565,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
         auto run = [&](auto seg, auto kk, int c) {
             constexpr int S = decltype(seg)::value, K = decltype(kk)::value;
             for (int p = 0; p < ncls[c]; p += 64 / S)
-                co_band_pass<S, K, COUNT, ROLE == 2>(L, A.inv_dsig_co, lane, slots, res_, first[c] + p, min(64 / S, ncls[c] - p), cand);
+                co_band_pass<S, K, COUNT>(L, A.inv_dsig_co, lane, slots, res_, first[c] + p, min(64 / S, ncls[c] - p), cand);
         };
         using two = std::integral_constant<int, 2>;
         using three = std::integral_constant<int, 3>;
@@ -641,72 +595,6 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
     wave_tail<T, TO, CR, COUNT>(L, A, i, in, lane, flags, my_flat, strip, cand);
 }
 
-// k_invert_band2 on RECORDS: lane l takes record l of the wave's 64 -- the slot stage 1 of k_invert_band built -- sorts the slots by
-// window class as stage 1 does, runs the batched, chord-clipped passes and finishes with wave_tail (cross-pol phase, store; what
-// a pass cannot decide goes to k_invert_list's list).
-template <typename T, typename TO, bool CR>
-__device__ __forceinline__ void band_wave_rec(const DevTables &L, const KArgs &A, const BandRec &r, bool in, int lane, BandSlot *__restrict__ slots,
-                                              int *__restrict__ res_)
-{
-    constexpr int NC = 11;
-    int pos = -1, first[NC] = {}, ncls[NC] = {};
-    unsigned cand = 0;
-    {
-        const int nv = (int)((unsigned)r.slot.ipn >> 16);
-        const int p2 = 31 - __clz(max(nv, 2) - 1);
-        const int myc = !in ? NC : (nv <= 4 ? 0 : min(2 * p2 - 3 + (nv > (3 << (p2 - 1)) ? 1 : 0), NC - 1));
-        int base = 0;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const unsigned long long m = __ballot(myc == c);
-            const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            pos = myc == c ? base + rank : pos;
-            first[c] = base;
-            ncls[c] = __popcll(m);
-            base += ncls[c];
-        }
-#pragma unroll
-        for (int c = 0; c + 1 < NC; ++c) {  // part-filled last passes promoted into the next class (band_wave)
-            const int np = 64 / (2 << (c >> 1)), npn = 64 / (2 << ((c + 1) >> 1));
-            const int rem = ncls[c] % np;
-            const int added = (ncls[c + 1] + rem + npn - 1) / npn - (ncls[c + 1] + npn - 1) / npn;
-            if (rem > 0 && added == 0) { ncls[c] -= rem; ncls[c + 1] += rem; first[c + 1] -= rem; }
-        }
-        if (in) {
-            slots[pos] = r.slot;
-            res_[pos] = -1;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    {
-        auto run = [&](auto seg, auto kk, int c) {
-            constexpr int S = decltype(seg)::value, K = decltype(kk)::value;
-            for (int p = 0; p < ncls[c]; p += 64 / S)
-                co_band_pass<S, K, false, true>(L, A.inv_dsig_co, lane, slots, res_, first[c] + p, min(64 / S, ncls[c] - p), cand);
-        };
-        using two = std::integral_constant<int, 2>;
-        using three = std::integral_constant<int, 3>;
-        run(std::integral_constant<int, 2>{}, two{}, 0);
-        run(std::integral_constant<int, 2>{}, three{}, 1);
-        run(std::integral_constant<int, 4>{}, two{}, 2);
-        run(std::integral_constant<int, 4>{}, three{}, 3);
-        run(std::integral_constant<int, 8>{}, two{}, 4);
-        run(std::integral_constant<int, 8>{}, three{}, 5);
-        run(std::integral_constant<int, 16>{}, two{}, 6);
-        run(std::integral_constant<int, 16>{}, three{}, 7);
-        run(std::integral_constant<int, 32>{}, two{}, 8);
-        run(std::integral_constant<int, 32>{}, three{}, 9);
-        run(std::integral_constant<int, 64>{}, two{}, 10);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int my_flat = pos >= 0 ? res_[pos] : -1;
-    wave_tail<T, TO, CR, false>(L, A, (long long)r.idx, in, lane, r.flags, my_flat, -1, cand);
-}
-
 template <typename T, typename TO, bool CR, bool COUNT, int ROLE = 0>
 __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, CR ? XSW_BAND_WAVES_CR : XSW_BAND_WAVES) void k_invert_band(DevTables L, KArgs A)
 {
@@ -727,59 +615,6 @@ __global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, CR ? XSW_BAND_WAVES_CR : XS
     const bool in = smp < A.samples;
     const long long i = line * A.samples + (in ? smp : A.samples - 1);
     band_wave<T, TO, CR, COUNT, ROLE>(L, A, i, in, lane, slots[wv], res_[wv], false, line * strips_per_line + col);
-}
-
-// Second kernel of the chain: the pixels k_invert_band left on list B (their band holds a long run of rows along the a-priori
-// direction), 64 listed pixels per wave (gathered rasters), rows swept in batches and clipped to the disc's chord; fixed grid,
-// every wave strides over the list; a list that overflowed is continued in the strip mask.
-template <typename T, typename TO, bool CR>
-__global__ __launch_bounds__(64 * XSW_BAND_WG_WAVES, XSW_BAND2_WAVES) void k_invert_band2(DevTables L, KArgs A)
-{
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __shared__ BandSlot slots[XSW_BAND_WG_WAVES][64];
-    __shared__ int res_[XSW_BAND_WG_WAVES][128];
-    const long long count = (long long)*A.list_b_count;
-    const long long nwaves = (long long)gridDim.x * XSW_BAND_WG_WAVES;
-    const long long strips_per_line = (A.samples + 63) >> 6, nstrips = strips_per_line * A.lines;
-    if (count > (long long)A.list_b_cap && !A.mask_b) {
-        // list B overflowed (k_invert_band kept counting but could not append) and there are no strip masks: which pixels it meant
-        // is unknown, so this kernel walks EVERY strip of the raster: stage 1 is redone for every pixel and only the long-run
-        // pixels -- what k_invert_band did not keep -- are searched.  (strips in linear order, one per wave: measured 2x faster
-        // for this kernel than k_invert_band's XCD-aware tile walk as a grid-stride loop -- the heavy pixels of a scene cluster,
-        // and the linear order spreads them over all the waves)
-        for (long long c = (long long)blockIdx.x * XSW_BAND_WG_WAVES + wv; c < nstrips; c += nwaves) {  // wave-uniform
-            const long long line = c / strips_per_line, smp = (c - line * strips_per_line) * 64 + lane;
-            const bool in = smp < A.samples;
-            band_wave<T, TO, CR, false, 2>(L, A, line * A.samples + (in ? smp : A.samples - 1), in, lane, slots[wv], res_[wv], true, c);
-            __builtin_amdgcn_wave_barrier();
-        }
-        return;
-    }
-    const long long nlist = count < (long long)A.list_b_cap ? count : (long long)A.list_b_cap;
-    for (long long c = (long long)blockIdx.x * XSW_BAND_WG_WAVES + wv; c * 64 < nlist; c += nwaves) {  // wave-uniform
-        const long long k = c * 64 + lane;
-        const bool in = k < nlist;
-        if (A.rec_b) {  // records: the slots as k_invert_band built them
-            const BandRec r = ((const BandRec *)A.rec_b)[in ? k : nlist - 1];
-            band_wave_rec<T, TO, CR>(L, A, r, in, lane, slots[wv], res_[wv]);
-        } else {
-            const long long i = (long long)A.list_b[in ? k : nlist - 1];
-            band_wave<T, TO, CR, false, 2>(L, A, i, in, lane, slots[wv], res_[wv]);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (count > (long long)A.list_b_cap) {
-        // the pixels that did not fit into list B are marked in mask_b: the marked pixels of the marked strips, in linear order
-        for (long long c = (long long)blockIdx.x * XSW_BAND_WG_WAVES + wv; c < nstrips; c += nwaves) {  // wave-uniform
-            const unsigned long long m = A.mask_b[c];  // wave-uniform address
-            if (m == 0ULL) continue;
-            const long long line = c / strips_per_line, smp = (c - line * strips_per_line) * 64 + lane;
-            const bool in = smp < A.samples;
-            band_wave<T, TO, CR, false, 2>(L, A, line * A.samples + (in ? smp : A.samples - 1), in && ((m >> lane) & 1ULL) != 0ULL, lane,
-                                                                 slots[wv], res_[wv], false, c);
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
 }
 
 }  // namespace xsw

@@ -19,7 +19,7 @@
 //             search re-scores near-ties in the reference's operation order.
 // The bounds, their deflation and the exactness argument are co_block_search's.
 #pragma once
-#include "xsw_band.hpp"
+#include "xsw_band2.hpp"
 
 namespace xsw {
 
@@ -297,7 +297,23 @@ __device__ __forceinline__ void blocks_wave(const DevTables &L, const KArgs &A, 
         unsigned long long pend = __ballot(fin), redo = 0ULL;
         if (pend) {
             bool loose = false;
-            const CoWindow W = co_window_lanes<XSW_BAND_RAYS, XSW_BAND_RAY_D, XSW_BAND_SEEDED != 0>(L, P, A.inv_dsig_co, fabs(A.dsig_co), loose);
+            CoWindow W = co_window_lanes<XSW_BAND_RAYS, XSW_BAND_RAY_D, XSW_BAND_SEEDED != 0>(L, P, A.inv_dsig_co, fabs(A.dsig_co), loose);
+            if (L.inv_rows && L.mono_rows) {
+                // CONTOUR BOUND (round 5, xsw_band2.hpp): the rays look where the a-priori wind points; the best of the candidates where the
+                // window's directions cross the observed sigma0 (inverse-row table: the monotone rows) is a bound nearer to the minimum --
+                // a smaller disc, a tighter start for the pyramid
+                const bool scan = fin && W.band_d < 1e300;
+                const int mono1 = L.mono_rows[scan ? P.i_inc : 0];
+                const double ah = 0.5 * P.a_re, bh = 0.5 * P.b_eff, m2 = ah * ah + bh * bh;
+                const double jc = contour_scan(L, scan, P.i_inc, P.s_co, ah, bh, A.inv_dsig_co, W.ip_lo, W.ip_hi - W.ip_lo + 1, W.w_lo, min(W.w_hi, mono1 - 1));
+                const double rs = W.band_d * fabs(A.inv_dsig_co), jub2 = (jc + m2) * (1.0 + 1e-9) + 1e-9;
+                if (scan && jc < 1e300 && jub2 < rs * rs) {
+                    const CoWindow W2 = box_from_jub(L, P.mag, P.theta, jub2);
+                    W.w_lo = max(W.w_lo, W2.w_lo); W.w_hi = min(W.w_hi, W2.w_hi);
+                    W.ip_lo = max(W.ip_lo, W2.ip_lo); W.ip_hi = min(W.ip_hi, W2.ip_hi);
+                    W.band_d = (double)__builtin_sqrtf((float)jub2) * (1.0 + 1e-6) * fabs(A.dsig_co) + 1e-9;
+                }
+            }
             const int rows = W.w_lo | (W.w_hi << 16), dirs = (int)((unsigned)W.ip_lo | ((unsigned)W.ip_hi << 16));
             // (a bound so loose that its float32 square root overflowed: band_d = inf -- the wave-wide search handles it)
             if (!(W.band_d < 1e300)) pend &= ~__ballot(fin && !(W.band_d < 1e300));
@@ -318,7 +334,7 @@ __device__ __forceinline__ void blocks_wave(const DevTables &L, const KArgs &A, 
             }
         }
     }
-    wave_tail<T, TO, CR, true>(L, A, i, in, lane, flags, my_flat, -1, cand);  // (COUNT: the statistics are a run-time switch here)
+    wave_tail<T, TO, CR, true>(L, A, i, in, lane, flags, my_flat, -1, cand, 5);  // (COUNT: the statistics are a run-time switch here)
 }
 
 // Third kernel of the chain: the pixels k_invert_band left on list C, 64 per wave (fewer when the list is short: the passes of

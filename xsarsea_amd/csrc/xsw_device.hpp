@@ -86,14 +86,15 @@ struct KArgs {
     void *out_co, *out_cr;
     int *out_idx;
     unsigned *code_co, *code_cr;  // nullable: the answer as 4-byte grid codes (xsw.h: xsw_invert_args.out_code_*)
-    unsigned long long *stats;  // [4]: pixels_co, cand_co, pixels_exact, pixels_cr (nullable)
+    unsigned long long *stats;  // [8]: pixels_co, cand_co, pixels_exact, pixels_cr; chain mode: [4] candidates scored by k_invert_band2, [5] k_invert_blocks, [6] k_invert_list, [7] records k_invert_band2 refined (nullable)
+    int stats_chain;            // the statistics are those of the production chain (xsw_stats_enable(ctx, 2)): k_invert_band hands over as usual
     unsigned *list;             // two-kernel path (nullable): k_invert_band appends the flat index of every pixel it leaves
     unsigned *list_count;       // undecided; k_invert_list then inverts exactly those, 64 per wave
     unsigned list_cap;          // entries the list holds; the counter runs on past it (overflow: k_invert_list takes every tile)
     unsigned *list_b, *list_b_count;  // list B (nullable): pixels k_invert_band hands to k_invert_band2 (long runs of band rows; rise-then-fall columns)
     unsigned list_b_cap;
-    void *rec_b;                // nullable: list B as RECORDS (BandRec, xsw_band.hpp: the pixel's search parameters as stage 1 of k_invert_band built
-                                // them, 72 bytes) instead of pixel indices -- k_invert_band2 then neither gathers the rasters again nor redoes stage 1
+    void *rec_b;                // nullable: list B as RECORDS (BandRec, xsw_band.hpp: the pixel's search parameters as stage 1 of k_invert_band found
+                                // them, 48 bytes) instead of pixel indices -- k_invert_band2 then neither gathers the rasters again nor redoes stage 1
     unsigned *list_c, *list_c_count;  // list C (nullable): finite pixels the band rule is not for, k_invert_band -> k_invert_blocks (block pyramid, four pixels per wave at a time)
     unsigned list_c_cap;
     // one 64-bit word per strip of 64 samples (strip = line * ceil(samples / 64) + strip column; nullable): bit l of mask_g =
@@ -106,6 +107,9 @@ struct KArgs {
     int tail_max;               // rows past the monotone ones a window may hold for k_invert_band2's tail sweep (0: never)
     int area_max;               // k_invert_band, ROLE 1: band candidates (run x directions) beyond which a pixel skips k_invert_band2 (general kernel instead)
     int block_min;              // general kernel: windows of at least this many candidates are searched by the block pyramid (co_block_search)
+    int wide_min;               // k_invert_band, ROLE 1: windows of at least this many directions are handed to k_invert_band2 whatever their run (its live arc narrows them)
+    int b2_refine_min;          // k_invert_band2: records marked F_B2_HARD a wave of 64 must hold for the wave to run the refinement (it costs every lane of the wave)
+    int b2_rows_max;            // k_invert_band2: rows the live arc of a pixel may hold after the joint shrink's first step before the pixel is passed on to k_invert_blocks
     long long n, lines, samples;
     double dsig_co, inv_dsig_co, dsig_cr_scalar;
     int is_db, dual_select;
@@ -119,6 +123,7 @@ enum : unsigned { K_CODE_NAN_RE = 0xFFFFFFFFu /* (nan, 0) */, K_CODE_NAN = 0xFFF
 enum : int { F_NEED_CO = 1, F_NEED_CR = 2, F_EARLY_NAN = 4, F_CO_FINITE = 8, F_CR_RAW_NAN = 16 /* band kernel: a raw cross-pol input is NaN */,
              F_CO_LOOSE = 32 /* general kernel: finite inputs, but a bound far above the scale of the scores: block pyramid, no forward differences */,
              F_REC_DONE = 256 /* k_invert_band: the pixel's record is on list B: nothing more to do for it in this wave */,
+             F_B2_HARD = 512 /* list B's record: a long run x wide window, or a tail -- worth k_invert_band2's refinement (contour bound, live arc) */,
              F_TO_B = 64, F_TO_C = 128 /* band kernels: the pixel is list B's (k_invert_band2) / list C's (k_invert_blocks) if it is still undecided at the end of the wave */ };
 
 // ------------------------------------------------------------------------------------------------
@@ -1478,6 +1483,7 @@ __device__ __forceinline__ void invert_strip(const DevTables &L, const KArgs &A,
     if (A.stats && lane == 0) {
         atomicAdd(&A.stats[0], (unsigned long long)n_co);
         atomicAdd(&A.stats[1], (unsigned long long)cand);
+        if (A.stats_chain) atomicAdd(&A.stats[6], (unsigned long long)cand);
         atomicAdd(&A.stats[2], (unsigned long long)n_exact);
         atomicAdd(&A.stats[3], (unsigned long long)n_cr);
     }

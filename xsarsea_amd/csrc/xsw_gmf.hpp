@@ -15,11 +15,13 @@ enum GmfId : int {
     GMF_RCM_V4 = 11, GMF_RS2_V4 = 12, GMF_COUNT = 13
 };
 
-__constant__ double kCmod5[2][29] = {
-    {0.0, -0.688, -0.793, 0.338, -0.173, 0.0, 0.004, 0.111, 0.0162, 6.34, 2.57, -2.18, 0.4, -0.6, 0.045, 0.007, 0.33,
-     0.012, 22.0, 1.95, 3.0, 8.39, -3.44, 1.36, 5.35, 1.99, 0.29, 3.80, 1.53},
-    {0.0, -0.6878, -0.7957, 0.338, -0.1728, 0.0, 0.004, 0.1103, 0.0159, 6.7329, 2.7713, -2.2885, 0.4971, -0.725, 0.045,
-     0.0066, 0.3222, 0.012, 22.7, 2.0813, 3.0, 8.3659, -3.3428, 1.3236, 6.2437, 2.3893, 0.3249, 4.159, 1.693}};
+// (constexpr, not __constant__: with the model a template argument the terms that depend on the coefficients alone -- a, b,
+// pow(y0 - 1, pn - 1) -- fold at compile time and nothing is indexed at run time: round 4's one-kernel-for-all form carried the
+// table pointer through a switch and spilled, 181 VGPRs + 24 B of scratch)
+constexpr double kCmod5_c[29] = {0.0, -0.688, -0.793, 0.338, -0.173, 0.0, 0.004, 0.111, 0.0162, 6.34, 2.57, -2.18, 0.4, -0.6, 0.045, 0.007, 0.33,
+                                 0.012, 22.0, 1.95, 3.0, 8.39, -3.44, 1.36, 5.35, 1.99, 0.29, 3.80, 1.53};
+constexpr double kCmod5n_c[29] = {0.0, -0.6878, -0.7957, 0.338, -0.1728, 0.0, 0.004, 0.1103, 0.0159, 6.7329, 2.7713, -2.2885, 0.4971, -0.725, 0.045,
+                                  0.0066, 0.3222, 0.012, 22.7, 2.0813, 3.0, 8.3659, -3.3428, 1.3236, 6.2437, 2.3893, 0.3249, 4.159, 1.693};
 
 __constant__ double kIfr2[26] = {0.0, -2.437597, -1.5670307, 0.3708242, -0.040590, 0.404678, 0.188397, -0.027262,
                                  0.064650, 0.054500, 0.086350, 0.055100, -0.058450, -0.096100, 0.412754, 0.121785,
@@ -51,8 +53,10 @@ __constant__ double kVh[8][15] = {
      3.813107432709729e-08, 1.524883207000445, -0.01322253424944054, 0.00037527120092119504, -0.2222881984904166,
      13.118282628673661, 0.21426139278646567, 12.768845054319682, 1, 1.01}};
 
-__device__ inline double gmf_cmod5_family(const double *c, double inc, double v, double phi)
+template <bool NEUTRAL>
+__device__ __forceinline__ double gmf_cmod5_family(double inc, double v, double phi)
 {
+    constexpr const double *c = NEUTRAL ? kCmod5n_c : kCmod5_c;
     const double cosphi = cos(phi * (M_PI / 180.0));
     const double x = (inc - 40.0) / 25.0, x2 = x * x;
     const double y0 = c[19], pn = c[20];
@@ -105,33 +109,45 @@ __device__ inline double gmf_vh(const double *p, double inc, double u)
     return pow(10.0, (10.0 * log10(s1) * w1 + 10.0 * log10(s2) * w2) / 10.0);
 }
 
-__device__ inline double gmf_eval(int id, double inc, double v, double phi)
+// the model as a template argument (GMF_RS2_V2 stands for the whole cross-pol family: one code path, coefficients by `id`)
+template <int M>
+__device__ __forceinline__ double gmf_eval(int id, double inc, double v, double phi)
 {
-    switch (id) {
-    case GMF_CMOD5: return gmf_cmod5_family(kCmod5[0], inc, v, phi);
-    case GMF_CMOD5N: return gmf_cmod5_family(kCmod5[1], inc, v, phi);
-    case GMF_CMOD5N_ZHANGA: {
+    if (M == GMF_CMOD5) return gmf_cmod5_family<false>(inc, v, phi);
+    if (M == GMF_CMOD5N) return gmf_cmod5_family<true>(inc, v, phi);
+    if (M == GMF_CMOD5N_ZHANGA) {
         const double ar = 1.3794 + inc * (-3.19e-2 + inc * 1.4e-3), br = -0.1711 + inc * 2.6e-3;
-        return gmf_cmod5_family(kCmod5[1], inc, v, phi) / (ar * pow(v, br));
+        return gmf_cmod5_family<true>(inc, v, phi) / (ar * pow(v, br));
     }
-    case GMF_CMOD5N_MOUCHE1: {
+    if (M == GMF_CMOD5N_MOUCHE1) {
         const double p0 = 0.00650704 * exp(0.128983 * inc) + 0.992839, ph = 0.00782194 * exp(0.121405 * inc) + 0.992839;
         const double pp = 0.00598416 * exp(0.140952 * inc) + 0.992885, r = phi * (M_PI / 180.0);
         const double pr = (p0 + pp + 2 * ph) / 4 + (p0 - pp) / 2 * cos(r) + (p0 + pp - 2 * ph) / 4 * cos(2 * r);
-        return gmf_cmod5_family(kCmod5[1], inc, v, phi) / pr;
+        return gmf_cmod5_family<true>(inc, v, phi) / pr;
     }
-    case GMF_CMODIFR2: return gmf_ifr2(inc, v, phi);
-    default: return gmf_vh(kVh[id - GMF_RS2_V2], inc, v);
-    }
+    if (M == GMF_CMODIFR2) return gmf_ifr2(inc, v, phi);
+    return gmf_vh(kVh[id - GMF_RS2_V2], inc, v);
 }
 
 // out[i] = gmf(inc[i], wspd[i], phi[i]); phi may be NULL for the cross-pol models
+template <int M>
 __global__ __launch_bounds__(256) void k_gmf_eval(int id, long long n, const double *__restrict__ inc,
                                                   const double *__restrict__ wspd, const double *__restrict__ phi,
                                                   double *__restrict__ out)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        out[i] = gmf_eval(id, inc[i], wspd[i], phi ? phi[i] : 0.0);
+        out[i] = gmf_eval<M>(id, inc[i], wspd[i], phi ? phi[i] : 0.0);
 }
+
+// host side: the instantiation of model `id` (the cross-pol models share one)
+#define XSW_GMF_DISPATCH(id, CALL)                                   \
+    switch (id) {                                                    \
+    case GMF_CMOD5: { constexpr int M = GMF_CMOD5; CALL; } break;     \
+    case GMF_CMOD5N: { constexpr int M = GMF_CMOD5N; CALL; } break;   \
+    case GMF_CMOD5N_ZHANGA: { constexpr int M = GMF_CMOD5N_ZHANGA; CALL; } break;   \
+    case GMF_CMOD5N_MOUCHE1: { constexpr int M = GMF_CMOD5N_MOUCHE1; CALL; } break; \
+    case GMF_CMODIFR2: { constexpr int M = GMF_CMODIFR2; CALL; } break;             \
+    default: { constexpr int M = GMF_RS2_V2; CALL; } break;          \
+    }
 
 }  // namespace xsw

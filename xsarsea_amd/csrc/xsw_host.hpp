@@ -23,6 +23,7 @@ struct xsw_ctx {
     bool have_co = false, have_cr = false;
     unsigned long long *d_stats = nullptr;
     bool stats_on = false;
+    bool stats_chain = false;               // xsw_stats_enable(ctx, 2): the production chain keeps running, its kernels count what they score
     bool timing_on = false;                 // xsw_timing_enable: HIP events around the kernels of every device-memory inversion
     std::vector<hipEvent_t> timing_events;  // quintuples (start, after k_invert_band, k_invert_band2, k_invert_blocks, k_invert_list) on the launch stream
     unsigned *d_list = nullptr;  // hand-over k_invert_band -> k_invert_list: [0] = count, [16..] = pixel indices
@@ -78,18 +79,23 @@ struct LaunchCtl {
     bool timing;       // xsw_timing_enable events (context stream only)
     unsigned long long *masks = nullptr;  // strip masks (KArgs::mask_g, then mask_b), mask_strips words each; nullptr: none
     size_t mask_strips = 0;
-    void *rec_b = nullptr;  // list_cap records of XSW_REC_BYTES (KArgs::rec_b); nullptr: list B holds pixel indices
+    void *rec_b = nullptr;  // XSW_LIST_B_SHARE * list_cap records of XSW_REC_BYTES (KArgs::rec_b); nullptr: list B holds pixel indices
 };
 
 
-// Work lists of one launch, side by side in one allocation: [0..15] counters, then list G (k_invert_list) and list B
-// (k_invert_band2) of LaunchCtl::list_cap entries each, then list C (k_invert_blocks) of XSW_LIST_C_SHARE times as many: on the
-// scenes whose a-priori wind is far from the sigma0 contour HALF the pixels are the block kernel's.
+// Work lists of one launch, side by side in one allocation: [0..15] counters, then list G (k_invert_list) of LaunchCtl::list_cap
+// entries, list B (k_invert_band2) of XSW_LIST_B_SHARE times as many and list C (k_invert_blocks) of XSW_LIST_C_SHARE times as
+// many: on the scenes whose a-priori wind is far from the sigma0 contour HALF the pixels are k_invert_band2's (an overflowing
+// list B sends the rest through the strip mask, where stage 1 is redone for them).  With list_cap = an eighth of the raster the
+// lists take 4.5 B and list B's records 24 B per pixel of the largest raster seen.
+#ifndef XSW_LIST_B_SHARE
+#define XSW_LIST_B_SHARE 4
+#endif
 #ifndef XSW_LIST_C_SHARE
 #define XSW_LIST_C_SHARE 4
 #endif
-#define XSW_LISTS_TOTAL (2 + XSW_LIST_C_SHARE)
-#define XSW_REC_BYTES 72  // sizeof(BandRec) (xsw_band.hpp; static_assert in xsw_invert_tu.hip): list B's records follow the strip masks
+#define XSW_LISTS_TOTAL (1 + XSW_LIST_B_SHARE + XSW_LIST_C_SHARE)
+#define XSW_REC_BYTES 48  // sizeof(BandRec) (xsw_band.hpp; static_assert in xsw_invert_tu.hip): list B's records follow the strip masks
 
 // One (input dtype, output dtype) pair of the inversion launches per translation unit (xsw_invert_tu.hip, -DXSW_PAIR=0..3:
 // f32->f32, f32->f64, f64->f32, f64->f64), so that the four sets of kernel instantiations compile side by side.

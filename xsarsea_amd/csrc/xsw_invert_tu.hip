@@ -8,6 +8,7 @@
 
 #include "xsw_host.hpp"
 #include "xsw_band.hpp"
+#include "xsw_band2.hpp"
 #include "xsw_blocks.hpp"
 #include "xsw_exhaustive.hpp"
 
@@ -15,6 +16,12 @@ using namespace xsw;
 
 #ifndef XSW_B2_AREA
 #define XSW_B2_AREA 2048  // measured with list C at half the raster (profiles/sweep_b2_area.sh, Mpx/s at 1e6 / 8192 / 4096 / 2048 / 1024 / 512): outliers 5 % 727 / 2486 / 2675 / 2711 / 2624 / 2694, a-priori x 0.3 424 / 440 / 512 / 591 / 643 / 620, x 2.5 460 / 459 / 480 / 520 / 508 / 489, x 0.6 1148 / 1147 / 1161 / 1176 / 1128 / 910
+#endif
+#ifndef XSW_B2_WIDE
+#define XSW_B2_WIDE 0  // directions from which a window is k_invert_band2's whatever its run (0: never)
+#endif
+#ifndef XSW_B2_REFINE_MIN
+#define XSW_B2_REFINE_MIN 32  // records marked for the refinement a wave of k_invert_band2 must hold to run it (environment XSW_B2_REFINE_MIN)
 #endif
 #ifndef XSW_BLOCK_MIN
 #define XSW_BLOCK_MIN 1024
@@ -49,8 +56,9 @@ static int launch_invert(xsw_ctx *c, const KArgs &A_in, int algo, const LaunchCt
         // where the a-priori wind is far from the sigma0 contour most pixels are such.  XSW_LONG_RUN=0: never (k_invert_band
         // sweeps every window: A/B measurements); the statistics instantiation sweeps every window in k_invert_band as well.
         static const int long_run_env = getenv("XSW_LONG_RUN") ? std::max(0, atoi(getenv("XSW_LONG_RUN"))) : 4;
-        const bool band2 = long_run_env > 0 && !A.stats;
-        if (band2) { B.list_b_count = lc.list + 1; B.list_b = lc.list + 16 + lc.list_cap; B.list_b_cap = B.list_cap; }
+        const bool count_inst = A.stats && !A.stats_chain;  // the statistics instantiation: k_invert_band sweeps every window itself and counts
+        const bool band2 = long_run_env > 0 && !count_inst;
+        if (band2) { B.list_b_count = lc.list + 1; B.list_b = lc.list + 16 + lc.list_cap; B.list_b_cap = (unsigned)std::min<size_t>(XSW_LIST_B_SHARE * lc.list_cap, 0xfffffff0u); }
         static const bool records_off = getenv("XSW_NO_RECORDS") != nullptr;  // A/B measurements and the tests of the index-list route
         static_assert(sizeof(BandRec) == XSW_REC_BYTES, "XSW_REC_BYTES (xsw_host.hpp) is sizeof(BandRec)");
         B.rec_b = (band2 && !records_off) ? lc.rec_b : nullptr;
@@ -58,10 +66,16 @@ static int launch_invert(xsw_ctx *c, const KArgs &A_in, int algo, const LaunchCt
         // list G, i.e. with k_invert_list (A/B measurements and the tests of that route)
         static const bool blocks_kernel_off = getenv("XSW_NO_BLOCKS_KERNEL") != nullptr;
         const bool blocks3 = c->T.blk != nullptr && c->T.blk_span_ok && !blocks_kernel_off && c->T.n_w < 32768 && c->T.n_phi < 32768;
-        if (blocks3) { B.list_c_count = lc.list + 2; B.list_c = lc.list + 16 + 2 * lc.list_cap; B.list_c_cap = (unsigned)std::min<size_t>(XSW_LIST_C_SHARE * lc.list_cap, 0xfffffff0u); }
+        if (blocks3) { B.list_c_count = lc.list + 2; B.list_c = lc.list + 16 + (1 + XSW_LIST_B_SHARE) * lc.list_cap; B.list_c_cap = (unsigned)std::min<size_t>(XSW_LIST_C_SHARE * lc.list_cap, 0xfffffff0u); }
         B.long_run = long_run_env;
         static const int area_max_env = getenv("XSW_B2_AREA") ? std::max(1, atoi(getenv("XSW_B2_AREA"))) : XSW_B2_AREA;
         B.area_max = c->T.blk ? area_max_env : 0x7fffffff;  // (without the block tables the general kernel has nothing better to offer)
+        static const int wide_env = getenv("XSW_B2_WIDE") ? std::max(0, atoi(getenv("XSW_B2_WIDE"))) : XSW_B2_WIDE;
+        B.wide_min = wide_env > 0 ? wide_env : 0x7fffffff;
+        static const int refine_min_env = getenv("XSW_B2_REFINE_MIN") ? std::max(0, atoi(getenv("XSW_B2_REFINE_MIN"))) : XSW_B2_REFINE_MIN;
+        B.b2_refine_min = refine_min_env;
+        static const int b2_rows_env = getenv("XSW_B2_ROWS_MAX") ? std::max(1, atoi(getenv("XSW_B2_ROWS_MAX"))) : XSW_B2_ROWS_MAX;
+        B.b2_rows_max = b2_rows_env;
         static const int tail_max_env = getenv("XSW_TAIL_SWEEP") ? std::min(std::max(0, atoi(getenv("XSW_TAIL_SWEEP"))), 30000) : XSW_TAIL_SWEEP;
         B.tail_max = (band2 && c->T.tail_min) ? tail_max_env : 0;  // (the tail rows are k_invert_band2's to sweep)
         // strip masks: what the consumers walk when a list overflows (only the marked pixels instead of the whole raster)
@@ -79,7 +93,7 @@ static int launch_invert(xsw_ctx *c, const KArgs &A_in, int algo, const LaunchCt
         if (8 * band_groups > 0x7fffffffLL || cols_per_xcd > 65535) return seterr(err, XSW_EINVAL, "raster too large for one launch");
         const dim3 band_grid((unsigned)(8 * band_groups), (unsigned)cols_per_xcd), band_block(64 * XSW_BAND_WG_WAVES);
         if (lc.timing) timing_mark(c);
-        if (A.stats) {  // statistics instantiation (counts the scored candidates)
+        if (count_inst) {  // statistics instantiation (counts the scored candidates)
             if (mono) hipLaunchKernelGGL((k_invert_band<T, TO, false, true>), band_grid, band_block, 0, lc.stream, c->T, B);
             else hipLaunchKernelGGL((k_invert_band<T, TO, true, true>), band_grid, band_block, 0, lc.stream, c->T, B);
         } else if (band2) {

@@ -15,6 +15,7 @@
 
 namespace xsw {
 
+template <int M>
 __global__ __launch_bounds__(256) void k_gmf_grid(int id, const double *__restrict__ inc, const double *__restrict__ wspd,
                                                   const double *__restrict__ phi, int ni, int nw, int np, double *__restrict__ out)
 {
@@ -22,7 +23,7 @@ __global__ __launch_bounds__(256) void k_gmf_grid(int id, const double *__restri
     const long long n = (long long)ni * nw * npp;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
         const int k = (int)(t % npp), j = (int)((t / npp) % nw), i = (int)(t / ((long long)npp * nw));
-        out[t] = gmf_eval(id, inc[i], wspd[j], np > 0 ? phi[k] : 0.0);
+        out[t] = gmf_eval<M>(id, inc[i], wspd[j], np > 0 ? phi[k] : 0.0);
     }
 }
 
