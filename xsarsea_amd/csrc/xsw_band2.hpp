@@ -544,7 +544,8 @@ __device__ __forceinline__ void band2_run(const DevTables &L, const KArgs &A, co
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (big && pos >= 0) my_flat = res_[pos];
     }
-    if (A.stats && A.stats_chain && refine_wave && lane == 0) atomicAdd(&A.stats[7], (unsigned long long)__popcll(ballot64(mine)));
+    const unsigned long long mine_m = ballot64(mine);
+    if (A.stats && A.stats_chain && refine_wave && lane == 0) atomicAdd(&A.stats[7], (unsigned long long)__popcll(mine_m));
     wave_tail<T, TO, CR, true>(L, A, (long long)r.idx, in, lane, flags, my_flat, strip, cand, 4);
 }
 
