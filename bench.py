@@ -1063,7 +1063,13 @@ def main():
                                  "pixel the kernel decides itself, i.e. not handed to k_invert_band2 / k_invert_blocks / k_invert_list) / mean "
                                  "duration of the dominant kernel per step (HIP events on the launch stream, recorded by the library around each kernel); "
                                  "chain: all bytes of the step / the four kernels' time; "
-                                 "the search itself is bound by VALU issue and the texture-address path, not by HBM: see valu",
+                                 "the search itself is bound by VALU issue and the texture-address path, not by HBM: see valu.  "
+                                 "north_star's '>= 40 % of the HBM-read roofline' is OUT OF REACH for an exact search: at 40 % of 8 TB/s a pixel's 16 B of "
+                                 "input may cost 5 ps, i.e. ~5 wave-instructions (300 lane-instructions) end to end, while the exact branch-and-bound "
+                                 "spends 44 VALU + 18 SALU wave-instructions per pixel (~2 800 lane-instructions: 16 for stage 1 -- dB, incidence bin, three "
+                                 "rays, window --, 25 for the band passes, 3 for the store) at 86 % VALU issue: the binding roofline is VALU issue, "
+                                 "and the kernel sits at 3.5 % of HBM (2.3 % counting reads only) because it is 12x over that instruction budget, not because it wastes bytes "
+                                 "(counter traffic 1.1x the algorithmic bytes)",
                          "valu": valu},
             "lut": timings,
         }

@@ -169,25 +169,31 @@ int xsw_synchronize(xsw_ctx *ctx);
 /* Replaces Model.to_lut(...) -> closure arrays (windspeed.py:144-181).  Either may be NULL (kept).
  * Device memory held per context for the default co-pol table (501 x 499 x 181): 368 MB float64 + 184 MB float32 copies,
  * 363 MB transposed copy, 394 MB inverse-row table (first row of every direction at or above each of 2048 dB thresholds
- * per incidence slice: what the band search reads instead of bisecting), ~7 MB of small tables (XSW_BAND2=1: + 755 MB for
- * the rise-then-fall tables of k_invert_band2); all derived copies are produced on the device at install (a few ms). */
+ * per incidence slice: what the band search reads instead of bisecting), 6 MB of block / band {min, max} tables (block
+ * pyramid), 6 MB of tail minima, ~10 MB of small tables; all derived copies are produced on the device at install (a few ms). */
 int xsw_lut_upload(xsw_ctx *ctx, const xsw_lut *co, const xsw_lut *cr);
 
 /* Replaces _invert_from_model_numpy (windspeed.py:132-331).  Asynchronous on the context's stream
  * when mem == XSW_MEM_DEVICE; synchronous (returns with outputs filled) for host memory.
  * XSW_ALGO_PRUNED on a LUT whose columns rise monotonically with wind speed (every built-in GMF over most of its rows) runs
- * as four launches: k_invert_band decides the pixels its band rule can and hands those whose band holds a long run of rows
- * along the a-priori direction (XSW_LONG_RUN = 4 or more: one such pixel would hold up every pixel of its pass) to
- * k_invert_band2, which sweeps long runs only (rows in batches, clipped to the chord of the search disc); the finite pixels the
- * band rule is not for (windows past the monotone rows of the LUT, bands of thousands of candidates, sigma0 outliers) go to
- * k_invert_blocks, a branch-and-bound over min / max tables of LUT blocks that bounds both cost terms together; k_invert_list does
- * the rest from a work list owned by the context (three lists of 4 bytes per EIGHTH pixel of the largest raster seen, plus two
- * strip masks of one bit per pixel; a scene that hands on more than an eighth of its pixels overflows a list, which the
- * consumer answers by walking the strips of the raster and taking exactly the pixels marked in the mask; if the lists cannot
- * be allocated the one-kernel path runs); any other LUT, and XSW_ALGO_EXACT, take the general kernel.  Environment XSW_LONG_RUN=0 takes k_invert_band2 out of the chain (A/B measurements).  (Environment XSW_BAND2=1
- * gives the middle kernel another role instead: the band rule on both branches of LUT columns that rise and then fall, for the
- * pixels whose search window leaves the monotone rows; exact, tested, off by default -- it does not pay on CMOD5.N.)
- * Results do not depend on the route (environment variable XSW_NO_BAND=1 forces the general kernel: A/B measurements). */
+ * as FOUR launches on one stream:
+ *   k_invert_band    decides the pixels its band rule can (windows inside the monotone rows, short runs of band rows); hands the
+ *                    pixels whose band holds a long run of rows along the a-priori direction (XSW_LONG_RUN = 4 or more), or a
+ *                    window that reaches past the monotone rows by a tail it can sweep, to list B as 48-byte records;
+ *   k_invert_band2   list B: per record a bound from the sigma0 contour itself (inverse-row table), the live arc of directions,
+ *                    per direction the joint shrink of band and chord, batched sweep;
+ *   k_invert_blocks  list C: the finite pixels the band rule is not for (windows past the monotone rows, bands of thousands of
+ *                    candidates, sigma0 outliers): branch-and-bound over min / max tables of LUT blocks, both cost terms bound
+ *                    together, four pixels per wave;
+ *   k_invert_list    list G: the rest (non-finite inputs, near-ties, whatever overflowed), the general algorithm.
+ * The work lists are owned by the context and sized by the largest raster seen (n pixels): list G n/8 entries, lists B and C
+ * n/2 entries each (4 bytes per entry), list B's records 48 bytes x n/2, two strip masks of one bit per pixel -- 28.8 bytes per
+ * pixel in all (11.5 GB for a 20000 x 20000 raster; HBM holds 288 GB).  A list that overflows is continued in its strip mask:
+ * the consumer takes the list, then exactly the marked pixels (stage 1 is redone for those of list B).  If the lists cannot be
+ * allocated the one-kernel path runs; any other LUT, and XSW_ALGO_EXACT, take the general kernel (k_invert).
+ * Results do not depend on the route.  Environment switches for A/B measurements and the tests of every route: XSW_LONG_RUN=0
+ * (no k_invert_band2), XSW_NO_BLOCKS_KERNEL=1, XSW_NO_BAND=1 (general kernel only), XSW_NO_RECORDS=1, XSW_NO_STRIP_MASKS=1,
+ * XSW_B2_REFINE_MIN / XSW_B2_AREA / XSW_B2_ROWS_MAX / XSW_TAIL_SWEEP (routing thresholds: INTEGRATION.md). */
 int xsw_invert(xsw_ctx *ctx, const xsw_invert_args *args);
 
 /* Grid codes -> complex winds (the store of __invert_from_model_1d: wind_co = wspd * exp(1j * deg2rad(+-phi)) :235-247,
@@ -210,7 +216,8 @@ int xsw_host_free(xsw_ctx *ctx, void *p);
 /* Host worker threads of the XSW_MEM_HOST paths (0 = default: XSW_HOST_THREADS or 12; at most 32).  Every worker keeps one
  * page-locked staging buffer and one device buffer of a chunk between calls (~2 Mpx: 40 MB each for float32 mono rasters,
  * ~110 MB for float64 dual-pol), so a context holds up to threads x chunk of pinned host memory; after every host-memory call
- * what exceeds XSW_STAGING_KEEP_MB (environment, default 512 MB per context) is released again, and lowering the thread count
+ * what exceeds XSW_STAGING_KEEP_MB (environment, default 1536 MB per context, a worker counted with the larger of its page-locked
+ * and its device buffer: the device side also holds the chunk's work lists and records) is released again, and lowering the thread count
  * frees the workers that are no longer used at once. */
 int xsw_set_host_threads(xsw_ctx *ctx, int n);
 
@@ -229,8 +236,9 @@ typedef struct {
 int xsw_stats_read_chain(xsw_ctx *ctx, xsw_chain_stats *out);
 
 /* Measurement aid (no reference counterpart): while enabled, every XSW_ALGO_PRUNED inversion of DEVICE rasters that takes the
- * two-kernel path (k_invert_band, then k_invert_list on the pixels it left undecided) is bracketed by HIP events on the launch
- * stream.  xsw_timing_read synchronises, returns the summed durations since the last read and forgets them. */
+ * four-kernel chain (k_invert_band, k_invert_band2, k_invert_blocks, k_invert_list: see xsw_invert) is bracketed by HIP events on the
+ * launch stream, one between every two kernels.  xsw_timing_read synchronises, returns the summed durations since the last read and
+ * forgets them. */
 typedef struct {
     int64_t launches;        /* inversions measured                                                   */
     double first_kernel_ms;  /* k_invert_band, summed over the launches                               */

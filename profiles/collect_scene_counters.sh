@@ -12,7 +12,8 @@ i=0
 for set in \
  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
  "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" \
- "SQ_INST_CYCLES_VMEM_RD SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_WAVES SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_INSTS_VALU_INT32" ; do
+ "SQ_INST_CYCLES_VMEM_RD SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_WAVES SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_INSTS_VALU_INT32" \
+ "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCC_HIT_sum TCC_MISS_sum" ; do
   i=$((i+1))
   rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/profiles/scene_driver.py > $OUT/p$i.log 2>&1 || echo "pass $i failed"
 done
@@ -30,7 +31,9 @@ for kern, n_px in handled.items():
     if not acc or not n_px: continue
     out={k: v/max(n[k],1) for k,v in acc.items()}
     cyc=out.get("GRBM_GUI_ACTIVE",0)/8.0
-    d={"per_pixel": {k: round(v/n_px,2) for k,v in out.items() if k.startswith(("SQ_INSTS","SQ_WAVE_CYCLES","SQ_WAIT_ANY"))}}
+    d={"per_pixel": {k: round(v/n_px,2) for k,v in out.items() if k.startswith(("SQ_INSTS","SQ_WAVE_CYCLES","SQ_WAIT_ANY","TCP_","TCC_","SQ_INST_LEVEL_VMEM","SQ_INST_CYCLES_VMEM"))}}
+    if cyc and out.get("TA_TA_BUSY_sum"): d["ta_busy_frac"]=round(out["TA_TA_BUSY_sum"]/(256*cyc),3)
+    if out.get("SQ_INST_LEVEL_VMEM") and out.get("SQ_INSTS_VMEM_RD"): d["avg_vmem_latency_cycles"]=round(out["SQ_INST_LEVEL_VMEM"]/out["SQ_INSTS_VMEM_RD"],0)
     if cyc:
         d["valu_issue_frac"]=round(out.get("SQ_INSTS_VALU",0)*4/(1024*cyc),3)
         d["gpu_cycles"]=cyc

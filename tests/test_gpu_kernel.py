@@ -664,12 +664,21 @@ for scale, inc_lo, inc_hi in ((1.0, 17.0, 25.0), (1.6, 20.0, 36.0), (2.5, 30.0, 
     ex = ctx.invert_host(inc, sigma0_co=s_vv, anc=anc, algo="exhaustive", out_dtype=np.complex64)
     got = out.cpu().numpy()
     diff = int(np.sum(got.view(np.int32) != ex[0].view(np.int32)))
-    print("RESULT", scale, diff, tm["launches"], tm["last_band2_pixels"], tm["last_list_pixels"] + tm["last_blocks_pixels"])  # (left to k_invert_blocks / k_invert_list)
+    # the production chain once more with its own counters on (xsw_stats_enable(ctx, 2)): same answer, and k_invert_band2 reports what it scored
+    out.zero_()
+    ctx.stats_enable(2)
+    ctx.invert_raw(inc.shape[0], inc.shape[1], _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, t[0].data_ptr(), t[1].data_ptr(), None, None,
+                   t[2].data_ptr(), out.data_ptr(), None, algo=_lib.ALGO_PRUNED)
+    ch = ctx.stats_chain()
+    ctx.stats_enable(False)
+    diff += int(np.sum(out.cpu().numpy().view(np.int32) != ex[0].view(np.int32)))
+    print("RESULT", scale, diff, tm["launches"], tm["last_band2_pixels"], tm["last_list_pixels"] + tm["last_blocks_pixels"], ch["cand_band2"], ch["pixels_refined"])  # (left to k_invert_blocks / k_invert_list)
 """
 
 
 @pytest.mark.parametrize("long_run,list_cap", [(None, None), (None, "300"), ("1", None), ("1", "300"), ("0", None), (None, "300-nomask"),
-                                               (None, "norecords"), (None, "300-norecords")])
+                                               (None, "norecords"), (None, "300-norecords"), (None, "refine-always"), (None, "refine-never"),
+                                               ("1", "300-refine-always"), (None, "rows8-refine-always"), (None, "wide16-refine-always")])
 def test_long_run_kernel(long_run, list_cap):
     """The three-kernel chain in a fresh process: k_invert_band hands the pixels whose band holds XSW_LONG_RUN (default 4) or more
     rows along the a-priori direction to k_invert_band2 (batched sweeps clipped to the disc's chord).  Four scenes from friendly
@@ -681,7 +690,7 @@ def test_long_run_kernel(long_run, list_cap):
     import subprocess
     import sys
     from conftest import REPO
-    env = {k: v for k, v in os.environ.items() if k not in ("XSW_LONG_RUN", "XSW_NO_STRIP_MASKS", "XSW_NO_RECORDS")}
+    env = {k: v for k, v in os.environ.items() if k not in ("XSW_LONG_RUN", "XSW_NO_STRIP_MASKS", "XSW_NO_RECORDS", "XSW_B2_REFINE_MIN", "XSW_B2_ROWS_MAX", "XSW_B2_WIDE")}
     if long_run is not None:
         env["XSW_LONG_RUN"] = long_run
     if list_cap:
@@ -691,17 +700,32 @@ def test_long_run_kernel(long_run, list_cap):
             env["XSW_NO_STRIP_MASKS"] = "1"
         if list_cap.endswith("norecords"):  # list B as pixel indices (k_invert_band2 redoes stage 1) instead of records
             env["XSW_NO_RECORDS"] = "1"
+        # round 5: k_invert_band2's refinement (contour bound, live arc, joint shrink) forced for every wave / for none; records passed
+        # on to k_invert_blocks when the live arc still holds more than 8 rows; windows of 16 directions or more handed over by width
+        if list_cap.endswith("refine-always"):
+            env["XSW_B2_REFINE_MIN"] = "0"
+        if list_cap.endswith("refine-never"):
+            env["XSW_B2_REFINE_MIN"] = "65"
+        if list_cap.startswith("rows8"):
+            env["XSW_B2_ROWS_MAX"] = "8"
+        if list_cap.startswith("wide16"):
+            env["XSW_B2_WIDE"] = "16"
     r = subprocess.run([sys.executable, "-c", _BAND2_SCRIPT.format(repo=REPO)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     rows = [l.split() for l in r.stdout.splitlines() if l.startswith("RESULT")]
     assert len(rows) == 4
-    for _, scale, diff, launches, b2, _listed in rows:
+    for _, scale, diff, launches, b2, _listed, _cand2, _refined in rows:
         assert int(diff) == 0, f"scale {scale}: {diff} values differ from the exhaustive sweep"
         assert int(launches) == 1
     if long_run == "0":
         assert all(int(r_[4]) == 0 for r_ in rows)
     else:
         assert any(int(r_[4]) > 0 for r_ in rows), "no pixel was handed to k_invert_band2"
+        assert any(int(r_[6]) > 0 for r_ in rows), "k_invert_band2 reports no scored candidate (chain statistics)"
+    if list_cap and list_cap.endswith("refine-always") and not list_cap.startswith("rows8"):
+        assert any(int(r_[7]) > 0 for r_ in rows), "no record went through the refinement"
+    if list_cap and list_cap.endswith("refine-never"):
+        assert all(int(r_[7]) == 0 for r_ in rows)
 
 
 def test_tail_cut_keeps_saturating_windows_in_the_band_kernels():
@@ -724,7 +748,7 @@ def test_tail_cut_keeps_saturating_windows_in_the_band_kernels():
         assert r.returncode == 0, r.stderr[-2000:]
         rows = [l.split() for l in r.stdout.splitlines() if l.startswith("RESULT")]
         assert len(rows) == 4
-        for _, scale, diff, launches, _b2, n_list in rows:
+        for _, scale, diff, launches, _b2, n_list, _cand2, _refined in rows:
             assert int(diff) == 0, f"scale {scale}, {mode}: {diff} values differ from the exhaustive sweep"
             listed[(mode, float(scale))] = int(n_list)
     assert listed[("both", 1.6)] < listed[("cut", 1.6)] < listed[("none", 1.6)], listed

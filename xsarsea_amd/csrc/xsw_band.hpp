@@ -161,9 +161,6 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
     const unsigned inv0 = mul24_sv(inv_rowB, (unsigned)(i_inc * XSW_INV_BINS) + ((unsigned)B.inc_bin >> 16));
     const unsigned inv1 = mul24_sv(inv_rowB, (unsigned)(i_inc * XSW_INV_BINS) + (unsigned)max(B.bin_hi, 0));
     double best = inf, second = inf;
-#ifdef XSW_EXP_F32_SCREEN
-    float b32 = 3e38f, s32 = 3e38f;
-#endif
     int brow = 0, bip = 0;
     unsigned ncand = 0;
     bool overflow = false;
@@ -208,26 +205,6 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
                 // (a lane past its run -- masked below -- may read past the window, up to XSW_BAND_MAX rows: the table is padded by
                 // 260 rows, xsw.hip; r[j] <= n_w)
                 const int rc = min(r[j] + t, w_hi);  // (unclamped -- the table is padded -- measured slower: masked lanes then touch new cache lines)
-#ifdef XSW_EXP_F32_SCREEN
-                // EXPERIMENT (round-5 review item 3 ii; timing builds only, NOT exact: no float64 re-score behind it): the trip body in
-                // float32 from the float32 copy of the LUT (4-byte loads), second best by v_med3_f32 -- the upper bound of what float32
-                // screening could save in this loop.  Measured: LABBOOK section 10.
-                {
-                    const float v32 = *(const float *)((const char *)L.co32 + ((off0[j] + __umul24((unsigned)rc, rowB)) >> 1));
-                    const bool inb32 = t < nrow[j];
-                    const float wh32 = fmaf((float)rc, (float)whs, (float)wh0);
-                    const float dd32 = fmaf(v32, (float)inv_dsig, (float)sn);
-                    float J32 = fmaf(dd32, dd32, wh32 * (wh32 - (float)U[j]));
-                    J32 = inb32 ? J32 : 3e38f;
-                    s32 = __builtin_amdgcn_fmed3f(b32, s32, J32);
-                    const bool lt32 = J32 < b32;
-                    brow = lt32 ? rc : brow;
-                    if (K > 1 || S == 64) bip = lt32 ? ip[j] : bip;
-                    b32 = vminf(b32, J32);
-                    if (COUNT) ncand += inb32 ? 1u : 0u;
-                    continue;
-                }
-#endif
                 const double v = ld_co(base, off0[j], rc, rowB);
                 // the end rows may lie just outside the band: candidates of the window all the same, so scoring them is harmless
                 // and cheaper than the two comparisons that would mask them (band kernel at 20000^2: 35.65 -> 33.9 ms)
@@ -249,9 +226,6 @@ __device__ __forceinline__ void co_band_pass(const DevTables &L, double inv_dsig
         overflow = overflow || any;  // rows left after XSW_BAND_MAX trips
         if (K == 1 && S != 64) bip = ip[0];
     }
-#ifdef XSW_EXP_F32_SCREEN
-    best = b32 < 1e38f ? (double)b32 : inf; second = s32 < 1e38f ? (double)s32 : inf;
-#endif
     const int bflat = (int)__umul24((unsigned)brow, (unsigned)L.n_phi) + bip;
     const double gmin = S == 64 ? wave_min_d(best) : seg_min_d<S>(best);
     const double T = gmin + 1e-9 * (1.0 + fabs(gmin) + slots[owner].m2);  // re-read: not kept live through the sweep

@@ -16,9 +16,11 @@ devices_min_pixels = 1 << 22
 device_out_dtype = "complex128"
 
 #: worker threads of the host-memory paths of libxsw per context (0 = the library default: XSW_HOST_THREADS or 12).  Each worker
-#: keeps a page-locked staging buffer and a device buffer of one chunk between calls (~40 MB each for float32 mono rasters, ~110 MB
-#: for float64 dual-pol): up to threads x chunk of pinned host memory per context (and per GPU with `devices`); what exceeds
-#: XSW_STAGING_KEEP_MB (environment, default 512) is released after every call, lowering `host_threads` frees the surplus workers.
+#: keeps a page-locked staging buffer (~40 MB for float32 mono rasters, ~110 MB for float64 dual-pol) and a device buffer (the
+#: same + the chunk's work lists and records: ~90 MB) of one ~2 Mpx chunk between calls, per context (and per GPU with `devices`);
+#: what exceeds XSW_STAGING_KEEP_MB (environment, default 1536, a worker counted with the larger of its two buffers) is released
+#: after every call, lowering `host_threads` frees the surplus workers.  Device rasters: the context's work lists take 28.8 bytes
+#: per pixel of the largest raster inverted so far (include/xsw.h: xsw_invert).
 host_threads = 0
 
 #: sigma0 -> dB conversion (windspeed.py:126-130).
