@@ -478,6 +478,8 @@ static int install_co(xsw_ctx *c, const xsw_lut *l, const double *d_dense)
         std::vector<double> cs((size_t)2 * nP);
         for (int i = 0; i < nP; ++i) { cs[2 * i] = cp[i]; cs[2 * i + 1] = sp[i]; }
         if ((rc = upload(c, c->co_allocs, cs.data(), cs.size(), &T.csphi))) return rc;
+        std::vector<float> cs32(cs.begin(), cs.end());  // float32 copy: the bound arithmetic of k_invert_band2 (xsw_band2.hpp)
+        if ((rc = upload(c, c->co_allocs, cs32.data(), cs32.size(), &T.csphi32))) return rc;
     }
     // output-side tables: caller's values, or the host libm's (see xsw.h)
     {

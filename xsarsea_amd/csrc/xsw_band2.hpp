@@ -64,14 +64,28 @@ __device__ __forceinline__ void mag_theta(const DevTables &L, double a, double b
     theta = th;
 }
 
+// BOUND ARITHMETIC IN FLOAT32.  Everything between the bound and a row interval -- budgets, square roots, threshold bins, chord
+// ends -- is a BOUND, not a score: it only has to err on the keeping side.  Round 5's first version did it in float64 with libm's
+// fmin / fmax (NaN canonicalisation: three instructions each), the IEEE-correct expansion of sqrtf (~15), 64-bit selects and
+// conversions: 119 VALU instructions per chord, 166 per table step -- 4 500 per pass, which is why the joint shrink cost more
+// than the rows it saved (LABBOOK section 10).  Here: float32 throughout, v_sqrt_f32 itself (1 ulp), v_min / v_max without
+// canonicalisation (operands are never NaN), and every result widened by XSW_BOUND_SLACK (relative to the magnitudes that went
+// into it: float32 rounding of the inputs and of a handful of operations is ~1e-7 of those) -- ~20 and ~40 instructions.
+// tests/prune_model.py carries the same slack.
+#ifndef XSW_BOUND_SLACK
+#define XSW_BOUND_SLACK 4e-6f
+#endif
+__device__ __forceinline__ float sqrt_up(float x) { return __builtin_amdgcn_sqrtf(x) * (1.0f + 4e-6f); }  // >= sqrt(x), x >= 0
+
 // Threshold bins of a slice's inverse-row table around [thr_lo, thr_hi] WITH A BIN OF MARGIN instead of stage 1's exact search
 // (one bin is ~0.02 dB, a fraction of a row): t_(b_lo) <= thr_lo - width + rounding and t_(b_hi) >= thr_hi + width - rounding, so
-// rows below inv[b_lo] lie below thr_lo and rows from inv[b_hi] on lie above thr_hi whatever the last bits of the bin arithmetic.
-// b_hi = XSW_INV_BINS: no threshold above thr_hi on the grid.  (tests/prune_model.py: table_bins_margin)
-__device__ __forceinline__ void bins_margin(double t0, double inv_width, double thr_lo, double thr_hi, int &b_lo, int &b_hi)
+// rows below inv[b_lo] lie below thr_lo and rows from inv[b_hi] on lie above thr_hi whatever the last bits of the bin arithmetic
+// (float32: the bin coordinate is good to ~2e-4 of a bin).  b_hi = XSW_INV_BINS: no threshold above thr_hi on the grid.
+// (tests/prune_model.py: table_bins_margin)
+__device__ __forceinline__ void bins_margin(float t0, float inv_width, float thr_lo, float thr_hi, int &b_lo, int &b_hi)
 {
-    b_lo = max((int)fmin(fmax((thr_lo - t0) * inv_width, 0.0), (double)(XSW_INV_BINS - 1)) - 1, 0);
-    b_hi = min(max((int)floor(fmin(fmax((thr_hi - t0) * inv_width, -3.0), (double)XSW_INV_BINS)) + 2, 0), XSW_INV_BINS);  // (0: thr_hi lies below the whole grid)
+    b_lo = max((int)vminf(vmaxf((thr_lo - t0) * inv_width, 0.0f), (float)(XSW_INV_BINS - 1)) - 1, 0);
+    b_hi = min(max((int)__builtin_floorf(vminf(vmaxf((thr_hi - t0) * inv_width, -3.0f), (float)XSW_INV_BINS)) + 2, 0), XSW_INV_BINS);  // (0: thr_hi lies below the whole grid)
 }
 
 // The same bins WITHOUT margin, by stage 1's search (band_wave): the largest grid threshold <= thr_lo (bin 0 also stands for
@@ -91,22 +105,22 @@ __device__ __forceinline__ void bins_exact(double t0, double width, double inv_w
 
 // smallest wind term wh^2 - 2 uh wh + m2 over wh in [wa, wb] (the parabola's minimum clamped into the interval: a lower bound of
 // the minimum over the rows in between), deflated for its own rounding
-__device__ __forceinline__ double jw_lower(double uh, double m2, double wa, double wb)
+__device__ __forceinline__ float jw_lower(float uh, float m2, float wa, float wb)
 {
-    const double t = fmin(fmax(uh, wa), wb);
-    return fma(t, t - 2.0 * uh, m2) * (1.0 - 1e-9) - 1e-9 * m2;
+    const float t = vminf(vmaxf(uh, wa), wb);
+    return fmaf(t, t - 2.0f * uh, m2) - XSW_BOUND_SLACK * (m2 + t * (t + 2.0f * fabsf(uh)));
 }
 
-// rows with wh^2 - 2 uh wh + m2 <= bud, as index interval [c_lo, c_hi] (float32 root, inflated, XSW_CHORD_MRG index units of
-// slack: co_band_pass's chord); false: none
-__device__ __forceinline__ bool chord_budget(double uh, double m2, double bud, double wh0, double inv_whs, int &c_lo, int &c_hi)
+// rows with wh^2 - 2 uh wh + m2 <= bud, as index interval [c_lo, c_hi] (inflated; XSW_CHORD_MRG + relative slack in index units);
+// false: none
+__device__ __forceinline__ bool chord_budget(float uh, float m2, float bud, float wh0, float inv_whs, int &c_lo, int &c_hi)
 {
-    const double disc = fma(uh, uh, (bud - m2) + 1e-9 * (fabs(bud) + m2));
-    const double h = (double)__builtin_sqrtf((float)fmax(disc, 0.0)) * (1.0 + 1e-6) + 1e-6;
-    const double xc = (uh - wh0) * inv_whs, xh = fma(h, inv_whs, XSW_CHORD_MRG);
-    c_lo = (int)ceil(fmax(xc - xh, -4.0));
-    c_hi = (int)floor(fmin(xc + xh, 40000.0));
-    return disc >= 0.0;
+    const float disc = fmaf(uh, uh, bud - m2) + XSW_BOUND_SLACK * (fmaf(uh, uh, m2) + fabsf(bud));
+    const float h = sqrt_up(vmaxf(disc, 0.0f));
+    const float xc = (uh - wh0) * inv_whs, xh = fmaf(h, inv_whs, (float)XSW_CHORD_MRG + XSW_BOUND_SLACK * fabsf(xc));
+    c_lo = (int)__builtin_ceilf(vmaxf(xc - xh, -4.0f));
+    c_hi = (int)__builtin_floorf(vminf(xc + xh, 40000.0f));
+    return disc >= 0.0f;
 }
 
 // CONTOUR BOUND, one pixel per lane: the smallest screening score among the two rows around the crossing LUT = s (inverse-row
@@ -125,6 +139,16 @@ __device__ __forceinline__ double contour_scan(const DevTables &L, bool on, int 
     const unsigned rowB = (unsigned)L.phi_pad * 8u, slice0 = mul24_sv(rowB, mul24_sv((unsigned)L.n_w, (unsigned)ii));
     const double sn = on ? -s * inv_dsig : 0.0, wh0 = 0.5 * L.w0, whs = L.wstep_half;
     const double ahc = on ? ah : 0.0, bhc = on ? bh : 0.0;
+    // (the two rows of a probe are neighbours: ONE 16-byte read of the TRANSPOSED slice -- a direction's speeds are contiguous there --
+    // instead of two reads 1.5 KB apart in the row-major one: the kernel is bound by cache-line accesses, and every lane's probe is a line)
+    const unsigned tcol0 = mul24_sv((unsigned)L.n_phi, (unsigned)ii);
+    auto pair_of = [&](int ip, int ra, int rb, double &va, double &vb) {
+        const int rp = min(ra, L.n_w - 2);
+        const double *__restrict__ col = (const double *)((const char *)L.coT + mul24_sv((unsigned)L.w_pad * 8u, tcol0 + (unsigned)ip));
+        const double v0 = col[rp], v1 = col[rp + 1];  // (adjacent: one dwordx4)
+        va = ra == rp ? v0 : v1;
+        vb = rb == rp ? v0 : v1;
+    };
     auto rows_of = [&](int ip, int &ra, int &rb) {
         const int r0 = (int)inv[ip];
         ra = min(max(r0 - 1, lo_c), top_c);
@@ -155,10 +179,7 @@ __device__ __forceinline__ double contour_scan(const DevTables &L, bool on, int 
             rows_of(ip[u], ra[u], rb[u]);
         }
 #pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            va[u] = ld_co(base, slice0 + (unsigned)ip[u] * 8u, ra[u], rowB);
-            vb[u] = ld_co(base, slice0 + (unsigned)ip[u] * 8u, rb[u], rowB);
-        }
+        for (int u = 0; u < NB; ++u) pair_of(ip[u], ra[u], rb[u], va[u], vb[u]);
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             const double j = ok[u] ? score2(ip[u], ra[u], rb[u], va[u], vb[u]) : inf;
@@ -182,10 +203,7 @@ __device__ __forceinline__ double contour_scan(const DevTables &L, bool on, int 
             rows_of(ip[u], ra[u], rb[u]);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            va[u] = ld_co(base, slice0 + (unsigned)ip[u] * 8u, ra[u], rowB);
-            vb[u] = ld_co(base, slice0 + (unsigned)ip[u] * 8u, rb[u], rowB);
-        }
+        for (int u = 0; u < 2; ++u) pair_of(ip[u], ra[u], rb[u], va[u], vb[u]);
         double j2[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) j2[u] = ok[u] ? score2(ip[u], ra[u], rb[u], va[u], vb[u]) : inf;
@@ -198,25 +216,46 @@ __device__ __forceinline__ double contour_scan(const DevTables &L, bool on, int 
     return jc;
 }
 
+// The pixel's constants of the bound arithmetic, float32 (the bound itself inflated once more for their rounding)
+struct Bound32 {
+    float s, uhx, uhy /* ah, bh */, m2, jub, abs_dsig, abs_inv, wh0, whs, inv_whs, t0, width, inv_width;
+};
+__device__ __forceinline__ Bound32 bound32(const DevTables &L, int i_inc, double s, double ah, double bh, double jub, double dsig)
+{
+    Bound32 b;
+    const double *g = L.inv_grid + 3 * i_inc;
+    b.s = (float)s; b.uhx = (float)ah; b.uhy = (float)bh; b.m2 = (float)(ah * ah + bh * bh);
+    b.jub = (float)jub * (1.0f + 1e-5f) + 1e-5f;  // (float32 sigma0 and thresholds: ~1e-6 dB, i.e. 1e-5 of a dsig of 0.1 dB, twice that in the score)
+    b.abs_dsig = fabsf((float)dsig) * (1.0f + 1e-6f); b.abs_inv = 1.0f / b.abs_dsig;
+    b.wh0 = (float)(0.5 * L.w0); b.whs = (float)L.wstep_half; b.inv_whs = (float)(2.0 * L.inv_wstep);
+    b.t0 = (float)g[0]; b.width = (float)g[1]; b.inv_width = (float)g[2];
+    return b;
+}
+
 // Step B of the joint shrink for ONE direction: rows [lo, hi] of the monotone part -> the rows whose LUT value lies within
 // +- |dsig| sqrt(J_ub - min Jwind over [lo, hi]) of s, from two reads of the direction's inverse-row column; vlo <= LUT < vhi
-// holds for what is left (grid thresholds; -inf / +inf: none).  Returns false when nothing is left.
-__device__ __forceinline__ bool joint_b(const unsigned short *__restrict__ inv_col /* &inv_rows[slice][0][ip] */, unsigned pitch /* phi_pad */, double t0,
-                                        double width, double inv_width, double s, double abs_dsig, double jub, double uh, double m2, double wh0,
-                                        double whs, int &lo, int &hi, double &vlo, double &vhi)
+// holds for what is left (grid thresholds, widened by their float32 rounding; -inf / +inf: none).  false: nothing is left.
+__device__ __forceinline__ bool joint_b(const unsigned short *__restrict__ inv_col /* &inv_rows[slice][0][ip] */, unsigned pitch /* phi_pad */,
+                                        const Bound32 &b, float uh, int &lo, int &hi, float &vlo, float &vhi)
 {
-    const double inf = __builtin_inf();
-    const double bud = jub - jw_lower(uh, m2, fma((double)lo, whs, wh0), fma((double)hi, whs, wh0));
-    const double d = (double)__builtin_sqrtf((float)fmax(bud, 0.0)) * (1.0 + 1e-6) * abs_dsig + 1e-9;
+    const float inf = __builtin_inff();
+    const float bud = b.jub - jw_lower(uh, b.m2, fmaf((float)lo, b.whs, b.wh0), fmaf((float)hi, b.whs, b.wh0));
+    const float d = fmaf(sqrt_up(vmaxf(bud, 0.0f)), b.abs_dsig, 2e-5f);
     int b_lo, b_hi;
-    bins_margin(t0, inv_width, s - d, s + d, b_lo, b_hi);
+    bins_margin(b.t0, b.inv_width, b.s - d, b.s + d, b_lo, b_hi);
     const int ra = (int)inv_col[mul24_sv(pitch, (unsigned)b_lo)];
     const int rb = (int)inv_col[mul24_sv(pitch, (unsigned)min(b_hi, XSW_INV_BINS - 1))];
     lo = max(lo, ra);
     hi = b_hi < XSW_INV_BINS ? min(hi, rb - 1) : hi;
-    vlo = b_lo > 0 ? fma((double)b_lo, width, t0) : -inf;
-    vhi = b_hi < XSW_INV_BINS ? fma((double)b_hi, width, t0) : inf;
-    return bud >= 0.0 && lo <= hi;
+    vlo = b_lo > 0 ? fmaf((float)b_lo, b.width, b.t0) - 2e-5f : -inf;
+    vhi = b_hi < XSW_INV_BINS ? fmaf((float)b_hi, b.width, b.t0) + 2e-5f : inf;
+    return bud >= 0.0f && lo <= hi;
+}
+// smallest sigma0 term ((LUT - s) / dsig)^2 of rows whose LUT value lies in [vlo, vhi), deflated
+__device__ __forceinline__ float js_lower(const Bound32 &b, float vlo, float vhi)
+{
+    const float dmin = vmaxf(0.0f, vmaxf(vlo - b.s, b.s - vhi)) * b.abs_inv * (1.0f - 1e-5f);
+    return dmin * dmin;
 }
 
 // LIVE ARC, one pixel per lane: first / last direction of [ip_lo, ip_lo + ncols) in which the band of the refined bound (ONE pair of
@@ -226,15 +265,20 @@ __device__ __forceinline__ bool joint_b(const unsigned short *__restrict__ inv_c
 #ifndef XSW_ARC_UNROLL
 #define XSW_ARC_UNROLL 4
 #endif
-__device__ __forceinline__ void live_arc(const DevTables &L, bool on, int i_inc, double s, double ah, double bh, double m2, double jub, double abs_dsig,
+__device__ __forceinline__ void live_arc(const DevTables &L, bool on, int i_inc, double s, double ah, double bh, double jub, double dsig,
                                          int ip_lo, int ncols, int w_lo, int w_hi, int tail_n, int &first, int &last, int &total_rows)
 {
-    constexpr int UN = XSW_ARC_UNROLL;
-    const double inf = __builtin_inf();
+    // EIGHT directions per trip from ONE 16-byte read of each table row: the kernel is bound by the texture addresser (85 % busy, 557
+    // cache-line accesses per record: every lane is another record, so every load touches 64 lines) -- a 2-byte read per direction
+    // walked the same two table rows line by line, eight accesses where one does.  The walk starts at the aligned group of eight
+    // that holds the window's first direction (phi_pad is a multiple of 8; the pad entries and the directions outside the window
+    // are masked).
+    constexpr int G = 8;
+    const float inf = __builtin_inff();
     const int ii = on ? i_inc : 0;
+    const Bound32 B = bound32(L, ii, s, ah, bh, jub, dsig);
     const double *g = L.inv_grid + 3 * ii;
-    const double wh0 = 0.5 * L.w0, whs = L.wstep_half, inv_whs = 2.0 * L.inv_wstep, abs_inv = 1.0 / abs_dsig;
-    const double d = (double)__builtin_sqrtf((float)fmax(jub, 0.0)) * (1.0 + 1e-6) * abs_dsig + 1e-9;
+    const double d = (double)__builtin_sqrtf((float)fmax(jub, 0.0)) * (1.0 + 1e-6) * fabs(dsig) + 1e-9;
     int b_lo, b_hi;
     bins_exact(g[0], g[1], g[2], s - d, s + d, b_lo, b_hi);
     const unsigned short *__restrict__ inv_a = L.inv_rows + mul24_sv((unsigned)L.phi_pad, (unsigned)(ii * XSW_INV_BINS + (on ? b_lo : 0)));
@@ -243,47 +287,57 @@ __device__ __forceinline__ void live_arc(const DevTables &L, bool on, int i_inc,
     const double *__restrict__ tmin = L.tail_min ? L.tail_min + mul24_sv((unsigned)L.phi_pad, (unsigned)(ii * (XSW_TAIL_LEVELS + 1))) : nullptr;
     const bool rows_ok = w_hi >= w_lo;
     first = 0x7fffffff; last = -1; total_rows = 0;
-    const int nmax = wave_max_i(on ? ncols : 0);
+    const int g0 = on ? (ip_lo & ~(G - 1)) : 0, ip_end = on ? ip_lo + ncols : 0;  // directions [ip_lo, ip_end)
+    const int ngroups = wave_max_i(on ? (ip_end - g0 + G - 1) / G : 0);
     const unsigned long long any_tail = ballot64(on && tail_n > 0);
 #pragma unroll 1
-    for (int k0 = 0; k0 < nmax; k0 += UN) {
-        bool act[UN];
-        int ip[UN], ra[UN], rb[UN];
-        double uh[UN], tm[UN];
+    for (int k = 0; k < ngroups; ++k) {
+        const int gp = g0 + k * G;
+        const bool gact = on && gp < ip_end;
+        const int gc = gact ? gp : 0;  // (phi_pad >= the group's end: the tables are padded to a multiple of 8 directions... see below)
+        const uint4 qa = *(const uint4 *)(inv_a + gc), qb = *(const uint4 *)(inv_b + gc);
+        const unsigned wa[4] = {qa.x, qa.y, qa.z, qa.w}, wb[4] = {qb.x, qb.y, qb.z, qb.w};
+        float4 c4[G / 2];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            act[u] = on && k0 + u < ncols;
-            ip[u] = act[u] ? ip_lo + k0 + u : 0;
-            ra[u] = (int)inv_a[ip[u]];
-            rb[u] = (int)inv_b[ip[u]];
-            tm[u] = (any_tail != 0ULL && tmin) ? tmin[ip[u]] : -inf;  // level 0: the direction's own tail minimum
-            const double2 cs = ((const double2 *)L.csphi)[ip[u]];
-            uh[u] = ah * cs.x + bh * cs.y;
-        }
+        for (int u = 0; u < G / 2; ++u) c4[u] = ((const float4 *)((const float2 *)L.csphi32 + gc))[u];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int lo = max(w_lo, ra[u]), hi = capped ? min(w_hi, rb[u] - 1) : w_hi;
-            const bool fits = act[u] && rows_ok && lo <= hi && !(jw_lower(uh[u], m2, fma((double)lo, whs, wh0), fma((double)max(hi, lo), whs, wh0)) > jub);
+        for (int u = 0; u < G; ++u) {
+            const int ip = gc + u;
+            const bool act = gact && ip >= ip_lo && ip < ip_end;
+            const int ra = (int)((wa[u >> 1] >> ((u & 1) * 16)) & 0xffffu), rb = (int)((wb[u >> 1] >> ((u & 1) * 16)) & 0xffffu);
+            const float cx = (u & 1) ? c4[u >> 1].z : c4[u >> 1].x, cy = (u & 1) ? c4[u >> 1].w : c4[u >> 1].y;
+            const float uh = B.uhx * cx + B.uhy * cy;
+            const int lo = max(w_lo, ra), hi = capped ? min(w_hi, rb - 1) : w_hi;
+            const bool fits = act && rows_ok && lo <= hi && !(jw_lower(uh, B.m2, fmaf((float)lo, B.whs, B.wh0), fmaf((float)max(hi, lo), B.whs, B.wh0)) > B.jub);
             int n = fits ? hi - lo + 1 : 0;
             if (any_tail != 0ULL) {  // wave-uniform
-                const double dt = fmax(0.0, tm[u] - s) * abs_inv * (1.0 - 1e-9);
+                const float tm = tmin ? (float)tmin[act ? ip : 0] - 2e-5f : -inf;  // level 0: the direction's own tail minimum
                 int c_lo, c_hi;
-                const bool hit = chord_budget(uh[u], m2, jub - dt * dt, wh0, inv_whs, c_lo, c_hi);
+                const bool hit = chord_budget(uh, B.m2, B.jub - js_lower(B, tm, inf), B.wh0, B.inv_whs, c_lo, c_hi);
                 const int r2 = max(max(w_hi + 1, w_lo), c_lo), l2 = min(w_hi + tail_n, c_hi);
-                n += (act[u] && tail_n > 0 && hit && l2 >= r2) ? l2 - r2 + 1 : 0;
+                n += (act && tail_n > 0 && hit && l2 >= r2) ? l2 - r2 + 1 : 0;
             }
-            first = (n > 0 && first == 0x7fffffff) ? ip[u] : first;
-            last = n > 0 ? ip[u] : last;
+            first = (n > 0 && first == 0x7fffffff) ? ip : first;
+            last = n > 0 ? ip : last;
             total_rows += n;
         }
     }
 }
 
+// Lane layout of k_invert_band2's window classes (capacities 4, 6, 8, 12, ..., 96, 128 directions as in k_invert_band): S lanes per pixel
+// x K directions per lane.  XSW_B2_DEEP: more directions per lane on fewer lanes (K = 4 / 6 where k_invert_band has 2 / 3) -- twice
+// the pixels per pass, twice the independent loads per lane: the passes are chains of dependent round trips at 4 waves per SIMD.
+#ifndef XSW_B2_DEEP
+#define XSW_B2_DEEP 0
+#endif
+__host__ __device__ constexpr int b2_seg(int c) { return (XSW_B2_DEEP && c >= 2 && c <= 9) ? (1 << (c >> 1)) : (c > 10 ? 64 : (2 << (c >> 1))); }
+__host__ __device__ constexpr int b2_dirs(int c) { return (XSW_B2_DEEP && c >= 2 && c <= 9) ? ((c & 1) ? 6 : 4) : ((c & 1) ? 3 : 2); }
+
 // One pass of k_invert_band2: 64 / S pixels, one per S-lane segment, K directions per lane (blocked); per direction the joint
 // shrink (XSW_JOINT_ROUNDS x (B, A)) and the tail's chord, then the batched sweep and the settle of co_band_pass.
-template <int S, int K, int ROUNDS>
+template <int S, int K>
 __device__ __forceinline__ void co_band2_pass(const DevTables &L, double dsig, double inv_dsig, int lane, const Band2Slot *slots /* this wave's [64], sorted by class */,
-                                              int *res /* [64], by slot */, int first, int count, unsigned &cand, bool count_on)
+                                              int *res /* [64], by slot */, int first, int count, unsigned &cand, bool count_on, int rounds /* wave-uniform: joint-shrink rounds (0: band and chord of the pixel's bound only) */)
 {
     const double inf = __builtin_inf();
     const int q = lane / S, sl = lane & (S - 1);
@@ -293,13 +347,13 @@ __device__ __forceinline__ void co_band2_pass(const DevTables &L, double dsig, d
     if (!valid) { B.s = 0.0; B.ah = 0.0; B.bh = 0.0; B.jub = -1.0; B.i_inc = 0; B.rows = 0xffff0000 /* w_lo 0, w_hi -1 */; B.ipn = 0; B.tail_n = 0; B.b_lo = 0; B.b_hi = 0; }
     const int ip_lo = B.ipn & 0xffff, ncols = (int)((unsigned)B.ipn >> 16);
     const int w_lo = B.rows & 0xffff, w_hi = B.rows >> 16, tail_n = B.tail_n;
-    const double s = B.s, ah = B.ah, bh = B.bh, jub = B.jub, m2 = ah * ah + bh * bh, sn = -s * inv_dsig;
-    const double wh0 = 0.5 * L.w0, whs = L.wstep_half, inv_whs = 2.0 * L.inv_wstep, abs_dsig = fabs(dsig), abs_inv = fabs(inv_dsig);
+    const double s = B.s, ah = B.ah, bh = B.bh, m2 = ah * ah + bh * bh, sn = -s * inv_dsig;
+    const double wh0 = 0.5 * L.w0, whs = L.wstep_half;
+    const Bound32 Q = bound32(L, B.i_inc, s, ah, bh, B.jub, dsig);  // (idle segments: jub = -1: nothing passes)
+    const float finf = __builtin_inff();
     const char *__restrict__ base = (const char *)L.co;
     const unsigned rowB = (unsigned)L.phi_pad * 8u;
     const unsigned slice0 = mul24_sv(rowB, mul24_sv((unsigned)L.n_w, (unsigned)B.i_inc));
-    const double *g = L.inv_grid + 3 * B.i_inc;
-    const double t0 = g[0], width = g[1], inv_width = g[2];
     const unsigned short *__restrict__ inv_slice = L.inv_rows + mul24_sv((unsigned)L.phi_pad, (unsigned)(B.i_inc * XSW_INV_BINS));
     const double *__restrict__ tmin = L.tail_min ? L.tail_min + mul24_sv((unsigned)L.phi_pad, (unsigned)(B.i_inc * (XSW_TAIL_LEVELS + 1))) : nullptr;
     double best = inf, second = inf;
@@ -319,8 +373,8 @@ __device__ __forceinline__ void co_band2_pass(const DevTables &L, double dsig, d
             act[j] = valid && vcol < ncols;
             ip[j] = ip_lo + (act[j] ? vcol : 0);
             const double2 cs = ((const double2 *)L.csphi)[ip[j]];
-            const double uh = ah * cs.x + bh * cs.y;
-            U[j] = 2.0 * uh;
+            U[j] = 2.0 * (ah * cs.x + bh * cs.y);
+            const float uh = (float)(0.5 * U[j]);
             off0[j] = slice0 + (unsigned)ip[j] * 8u;
             // round 0: the band of the pixel's bound (one pair of bins per pixel) and the chord of the disc
             int lo, hi;
@@ -329,20 +383,19 @@ __device__ __forceinline__ void co_band2_pass(const DevTables &L, double dsig, d
                 const int ra = (int)inv_slice[mul24_sv((unsigned)L.phi_pad, (unsigned)B.b_lo) + (unsigned)ip[j]];
                 const int rb = (int)inv_slice[mul24_sv((unsigned)L.phi_pad, (unsigned)min(B.b_hi, XSW_INV_BINS - 1)) + (unsigned)ip[j]];
                 int c_lo, c_hi;
-                const bool hit = chord_budget(uh, m2, jub, wh0, inv_whs, c_lo, c_hi);
+                const bool hit = chord_budget(uh, Q.m2, Q.jub, Q.wh0, Q.inv_whs, c_lo, c_hi);
                 lo = max(max(w_lo, ra), c_lo);
                 hi = min(B.b_hi < XSW_INV_BINS ? min(w_hi, rb - 1) : w_hi, c_hi);
                 some = act[j] && hit && hi >= lo;
             }
-#pragma unroll
-            for (int it = 0; it < ROUNDS; ++it) {  // the joint shrink proper: per-direction budgets
-                double vlo, vhi;
+#pragma unroll 1
+            for (int it = 0; it < rounds; ++it) {  // the joint shrink proper: per-direction budgets (ONE copy of the code for every round count: the kernel's size is felt in the instruction cache)
+                float vlo, vhi;
                 // (a lane that is through keeps harmless bounds: its reads land in the table, its result is discarded)
                 int l2 = some ? lo : 0, h2 = some ? hi : 0;
-                const bool keep = joint_b(inv_slice + ip[j], (unsigned)L.phi_pad, t0, width, inv_width, s, abs_dsig, jub, uh, m2, wh0, whs, l2, h2, vlo, vhi);
-                const double dmin = fmax(0.0, fmax(vlo - s, s - vhi)) * abs_inv * (1.0 - 1e-9);
+                const bool keep = joint_b(inv_slice + ip[j], (unsigned)L.phi_pad, Q, uh, l2, h2, vlo, vhi);
                 int c_lo, c_hi;
-                const bool hit = chord_budget(uh, m2, jub - dmin * dmin, wh0, inv_whs, c_lo, c_hi);
+                const bool hit = chord_budget(uh, Q.m2, Q.jub - js_lower(Q, vlo, vhi), Q.wh0, Q.inv_whs, c_lo, c_hi);
                 some = some && keep && hit;
                 lo = max(l2, c_lo);
                 hi = min(h2, c_hi);
@@ -353,10 +406,9 @@ __device__ __forceinline__ void co_band2_pass(const DevTables &L, double dsig, d
             // the tail: rows w_hi + 1 .. w_hi + tail_n, inside the chord the direction's tail minimum leaves of the bound
             int n2 = 0, r2 = 0;
             if (tail_n > 0) {
-                const double tm = tmin ? tmin[ip[j]] : -inf;
-                const double dmin = fmax(0.0, tm - s) * abs_inv * (1.0 - 1e-9);
+                const float tm = tmin ? (float)tmin[ip[j]] - 2e-5f : -finf;
                 int c_lo, c_hi;
-                const bool hit = chord_budget(uh, m2, jub - dmin * dmin, wh0, inv_whs, c_lo, c_hi);
+                const bool hit = chord_budget(uh, Q.m2, Q.jub - js_lower(Q, tm, finf), Q.wh0, Q.inv_whs, c_lo, c_hi);
                 r2 = max(max(w_hi + 1, w_lo), c_lo);
                 const int l2 = min(w_hi + tail_n, c_hi);
                 n2 = (act[j] && hit && l2 >= r2) ? l2 - r2 + 1 : 0;
@@ -439,7 +491,7 @@ __device__ __forceinline__ BandRec band2_refine(const DevTables &L, const KArgs 
     const int w_hi = min(w_top, w_hi_o), tail_n = tail_old > 0 ? max(w_top - w_hi_o, 0) : 0;
     const int ip_lo = max(W.ip_lo, ip_lo_o), ip_hi = min(W.ip_hi, ip_lo_o + ncols_o - 1);
     int a_first, a_last, rows_total;
-    live_arc(L, searchable, i_inc, s, ah, bh, m2, jub, abs_dsig, ip_lo, ip_hi - ip_lo + 1, w_lo, w_hi, tail_n, a_first, a_last, rows_total);
+    live_arc(L, searchable, i_inc, s, ah, bh, jub, A.dsig_co, ip_lo, ip_hi - ip_lo + 1, w_lo, w_hi, tail_n, a_first, a_last, rows_total);
     // (the bound's own candidate is live, so a searchable record always has an arc; stay safe)
     const bool have = searchable && a_last >= a_first && a_first != 0x7fffffff;
     const bool too_many = have && rows_total > A.b2_rows_max && A.list_c != nullptr;  // the block pyramid's (list C)
@@ -494,7 +546,7 @@ __device__ __forceinline__ void band2_run(const DevTables &L, const KArgs &A, co
         }
 #pragma unroll
         for (int c = 0; c + 1 < NC; ++c) {  // part-filled last passes promoted into the next class (band_wave)
-            const int np = 64 / (2 << (c >> 1)), npn = 64 / (2 << ((c + 1) >> 1));
+            const int np = 64 / b2_seg(c), npn = 64 / b2_seg(c + 1);
             const int rem = ncls[c] % np;
             const int added = (ncls[c + 1] + rem + npn - 1) / npn - (ncls[c + 1] + npn - 1) / npn;
             if (rem > 0 && added == 0) { ncls[c] -= rem; ncls[c + 1] += rem; first[c + 1] -= rem; }
@@ -522,23 +574,14 @@ __device__ __forceinline__ void band2_run(const DevTables &L, const KArgs &A, co
         auto run = [&](auto seg, auto kk, int c) {
             constexpr int S = decltype(seg)::value, K = decltype(kk)::value;
             for (int p = 0; p < ncls[c]; p += 64 / S) {
-                if (refine_wave) co_band2_pass<S, K, XSW_JOINT_ROUNDS>(L, A.dsig_co, A.inv_dsig_co, lane, slots, res_, first[c] + p, min(64 / S, ncls[c] - p), cand, A.stats != nullptr);
-                else co_band2_pass<S, K, 0>(L, A.dsig_co, A.inv_dsig_co, lane, slots, res_, first[c] + p, min(64 / S, ncls[c] - p), cand, A.stats != nullptr);
+                co_band2_pass<S, K>(L, A.dsig_co, A.inv_dsig_co, lane, slots, res_, first[c] + p, min(64 / S, ncls[c] - p), cand, A.stats != nullptr,
+                                    refine_wave ? XSW_JOINT_ROUNDS : 0);
             }
         };
-        using two = std::integral_constant<int, 2>;
-        using three = std::integral_constant<int, 3>;
-        run(std::integral_constant<int, 2>{}, two{}, 0);
-        run(std::integral_constant<int, 2>{}, three{}, 1);
-        run(std::integral_constant<int, 4>{}, two{}, 2);
-        run(std::integral_constant<int, 4>{}, three{}, 3);
-        run(std::integral_constant<int, 8>{}, two{}, 4);
-        run(std::integral_constant<int, 8>{}, three{}, 5);
-        run(std::integral_constant<int, 16>{}, two{}, 6);
-        run(std::integral_constant<int, 16>{}, three{}, 7);
-        run(std::integral_constant<int, 32>{}, two{}, 8);
-        run(std::integral_constant<int, 32>{}, three{}, 9);
-        run(std::integral_constant<int, 64>{}, two{}, 10);
+#define XSW_B2_RUN(c) run(std::integral_constant<int, b2_seg(c)>{}, std::integral_constant<int, b2_dirs(c)>{}, c)
+        XSW_B2_RUN(0); XSW_B2_RUN(1); XSW_B2_RUN(2); XSW_B2_RUN(3); XSW_B2_RUN(4); XSW_B2_RUN(5);
+        XSW_B2_RUN(6); XSW_B2_RUN(7); XSW_B2_RUN(8); XSW_B2_RUN(9); XSW_B2_RUN(10);
+#undef XSW_B2_RUN
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -35,6 +35,7 @@ struct DevTables {
     const double *coT;   // [n_inc][n_phi][w_pad]   same slices transposed: one direction, all speeds
     const double *inc, *w, *wh, *phi, *cphi, *sphi;  // axes; wh = w/2; cphi/sphi = cos/sin(radians(phi))
     const double *csphi;     // [n_phi][2] the same cos / sin interleaved (one 16-byte load per direction in co_band_pass)
+    const float *csphi32;    // [n_phi][2] float32 copy (bound arithmetic of k_invert_band2)
     const float *co32;       // [n_inc][n_w][phi_pad] float copy of `co` (screening of the exhaustive kernel)
     const float *wh32;       // [n_w] float(w/2)
     double co_absmax;        // max |co|: bounds the float32 screening error
