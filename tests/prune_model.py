@@ -468,6 +468,9 @@ def block_pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig,
 # min Jwind over a row interval is analytic (a parabola in w/2); min Jsig over the rows between two table thresholds follows from
 # the thresholds themselves (rows >= inv[b] have LUT >= t_b; rows < inv[b'] have LUT < t_b').  B, A, B, A: two table reads per
 # B step, no LUT read at all; the rows that survive are swept and settled as before.
+# (The device evaluates the BOUND arithmetic of these steps -- budgets, square roots, bins, chord ends -- in float32 with every result
+# widened by 4e-6 of the magnitudes that went into it, xsw_band2.hpp: Bound32; the float64 forms below describe the same sets, a
+# hair narrower: device rows are a superset of these, which are a superset of the rows that can hold the argmin.)
 CONTOUR_PROBES = 16
 
 

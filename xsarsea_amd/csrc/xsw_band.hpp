@@ -569,6 +569,9 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
         };
         using two = std::integral_constant<int, 2>;
         using three = std::integral_constant<int, 3>;
+#ifndef XSW_BAND_WIDE_K
+#define XSW_BAND_WIDE_K three  // directions per lane of the widest class (chunks of 64 K directions)
+#endif
         run(std::integral_constant<int, 2>{}, two{}, 0);
         run(std::integral_constant<int, 2>{}, three{}, 1);
         run(std::integral_constant<int, 4>{}, two{}, 2);
@@ -579,7 +582,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
         run(std::integral_constant<int, 16>{}, three{}, 7);
         run(std::integral_constant<int, 32>{}, two{}, 8);
         run(std::integral_constant<int, 32>{}, three{}, 9);
-        run(std::integral_constant<int, 64>{}, two{}, 10);
+        run(std::integral_constant<int, 64>{}, XSW_BAND_WIDE_K{}, 10);
     }
 #endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

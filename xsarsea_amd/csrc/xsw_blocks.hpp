@@ -39,25 +39,30 @@ struct SegQEntry { int brbc; float lb; };  // block row | block column << 16; it
 __device__ __forceinline__ unsigned seg_bits(unsigned long long m, int q) { return (unsigned)(m >> (q * 16)) & 0xffffu; }
 
 // lower bound of J over block (br, bc) of a slice: the sigma0 term from the block's {min, max}, the wind term from the distance
-// of m/2 to the block's polar cell (co_block_search; tests/prune_model.py: sig_lb + cell_wind_lb)
-__device__ __forceinline__ double block_lb(const DevTables &L, float2 mm, int br, int bc, double s, double ainv, double ah, double bh, double m2,
-                                           double mh, double tol, double wh0, double whs)
+// of m/2 to the block's polar cell (co_block_search; tests/prune_model.py: sig_lb + cell_wind_lb).
+// FLOAT32, deflated (round 5): it is a bound, and the float64 form with libm's fmax / fmin cost 165 VALU instructions per step of
+// 16 blocks where the sweep of a block costs 250 -- a third of the kernel.  The block tables are float32 already; everything that
+// goes into the bound is rounded once more (~1e-7 of its magnitude), the result is lowered by XSW_BOUND_SLACK x those magnitudes,
+// and a direction within 1e-5 |m| of a cell's edge counts as inside it (the smaller bound).
+struct BlockBound32 { float s, ainv, ah, bh, m2, mh, tol, wh0, whs; };
+__device__ __forceinline__ float block_lb(const DevTables &L, float2 mm, int br, int bc, const BlockBound32 &q)
 {
     const int r0 = min(br * XSW_BLK_R, L.n_w - 1), r1 = min(br * XSW_BLK_R + XSW_BLK_R, L.n_w) - 1;
     const int c0 = min(bc * XSW_BLK_C, L.n_phi - 1), c1 = min(bc * XSW_BLK_C + XSW_BLK_C, L.n_phi) - 1;
-    const double wha = fma((double)r0, whs, wh0), whb = fma((double)max(r1, r0), whs, wh0);
-    const double dsg = fmax(0.0, fmax((double)mm.x - s, s - (double)mm.y)) * ainv;
-    const double rad = fmax(0.0, fmax(wha - mh, mh - whb));
-    double lbw = rad * rad;
+    const float wha = fmaf((float)r0, q.whs, q.wh0), whb = fmaf((float)max(r1, r0), q.whs, q.wh0);
+    const float dsg = vmaxf(0.0f, vmaxf(mm.x - q.s, q.s - mm.y)) * q.ainv;
+    const float rad = vmaxf(0.0f, vmaxf(wha - q.mh, q.mh - whb));
+    float lbw = rad * rad;
     if (L.blk_span_ok) {
-        const double2 ea = ((const double2 *)L.csphi)[c0], eb = ((const double2 *)L.csphi)[max(c1, c0)];
-        const bool inside = (ea.x * bh - ea.y * ah >= -tol) && (ah * eb.y - bh * eb.x >= -tol);
-        const double pmx = fmax(ah * ea.x + bh * ea.y, ah * eb.x + bh * eb.y);
-        const double tt = fmin(fmax(pmx, wha), whb);
-        const double e2 = m2 + tt * (tt - 2.0 * pmx);
-        lbw = inside ? lbw : fmax(lbw, e2);
+        const float2 ea = ((const float2 *)L.csphi32)[c0], eb = ((const float2 *)L.csphi32)[max(c1, c0)];
+        const bool inside = (ea.x * q.bh - ea.y * q.ah >= -q.tol) && (q.ah * eb.y - q.bh * eb.x >= -q.tol);
+        const float pmx = vmaxf(q.ah * ea.x + q.bh * ea.y, q.ah * eb.x + q.bh * eb.y);
+        const float tt = vminf(vmaxf(pmx, wha), whb);
+        const float e2 = fmaf(tt, tt - 2.0f * pmx, q.m2);
+        lbw = inside ? lbw : vmaxf(lbw, e2);
     }
-    return fma(dsg, dsg, lbw);
+    const float lb = fmaf(dsg, dsg, lbw);
+    return lb - XSW_BOUND_SLACK * (lb + q.m2 + whb * whb) - 1e-6f;
 }
 
 // Up to four pending pixels of the wave (lane l owns pixel l: P_*), one per segment.  Decided pixels: my_flat of the owner lane;
@@ -86,6 +91,9 @@ __device__ __forceinline__ void co_seg16_pass(const DevTables &L, double inv_dsi
     const double ah = 0.5 * a, bh = 0.5 * b, m2 = ah * ah + bh * bh, mh = sqrt(m2), sn = -s * inv_dsig, ainv = fabs(inv_dsig);
     const double wh0 = 0.5 * L.w0, whs = L.wstep_half;
     const double slack = 1e-8 * (1.0 + m2), tol = 1e-9 * mh + 1e-300;
+    BlockBound32 Q;
+    Q.s = (float)s; Q.ainv = (float)ainv * (1.0f - 1e-6f); Q.ah = (float)ah; Q.bh = (float)bh; Q.m2 = (float)m2; Q.mh = (float)mh;
+    Q.tol = 1e-5f * Q.mh + 1e-30f; Q.wh0 = (float)wh0; Q.whs = (float)whs;
     const double rs = bd * ainv;  // >= sqrt(J_ub) (co_window_lanes: band_d = |dsig| sqrt(J_ub), inflated)
     double jub = rs * rs * (1.0 + 1e-12);
     const int w_lo = (int)(rows & 0xffffu), w_hi = min(max((int)(rows >> 16), w_lo), L.n_w - 1);
@@ -122,10 +130,11 @@ __device__ __forceinline__ void co_seg16_pass(const DevTables &L, double inv_dsi
             const int tc = min(tb_lo + t, L.nbands - 1);
             const float2 mm = bnd[tv[j] ? tc : 0];
             const int r0 = tc * G * R, r1 = min((tc + 1) * G * R, L.n_w) - 1;
-            const double wha = fma((double)r0, whs, wh0), whb = fma((double)r1, whs, wh0);
-            const double dsg = fmax(0.0, fmax((double)mm.x - s, s - (double)mm.y)) * ainv;
-            const double rad = fmax(0.0, fmax(wha - mh, mh - whb));
-            lb1[j] = tv[j] ? fma(dsg, dsg, rad * rad) : inf;
+            const float wha = fmaf((float)r0, Q.whs, Q.wh0), whb = fmaf((float)r1, Q.whs, Q.wh0);
+            const float dsg = vmaxf(0.0f, vmaxf(mm.x - Q.s, Q.s - mm.y)) * Q.ainv;
+            const float rad = vmaxf(0.0f, vmaxf(wha - Q.mh, Q.mh - whb));
+            const float lb = fmaf(dsg, dsg, rad * rad);
+            lb1[j] = tv[j] ? (double)(lb - XSW_BOUND_SLACK * (lb + Q.m2 + whb * whb) - 1e-6f) : inf;
         }
         if (!mask) {
             double mn = 1e308;
@@ -167,13 +176,13 @@ __device__ __forceinline__ void co_seg16_pass(const DevTables &L, double inv_dsi
             const int dr = bv ? (int)(((float)idx + 0.5f) * inv_ncb) : 0, dc = bv ? idx - dr * ncb : 0;
             const int br = curA + dr, bc = bc_lo + dc;
             const float2 mm = blk[bv ? br * L.nbc + bc : 0];
-            const double lb = block_lb(L, mm, br, bc, s, ainv, ah, bh, m2, mh, tol, wh0, whs);
-            const bool keep = bv && !(lb * (1.0 - 1e-8) > jub + slack);
+            const float lb = block_lb(L, mm, br, bc, Q);
+            const bool keep = bv && !((double)lb > jub + slack);
             const unsigned kb = seg_bits(ballot64(keep), q);
             if (keep) {
                 SegQEntry e;
                 e.brbc = br | (bc << 16);
-                e.lb = __double2float_rd(lb);
+                e.lb = lb;
                 qseg[qn + __popc(kb & ((1u << sl) - 1u))] = e;
             }
             qn += __popc(kb);
