@@ -455,7 +455,15 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                 // (and a WIDE window with a long run -- sigma0 far above what any wind near the a-priori one explains: every direction
                 // searched, bands on the saturated top -- costs k_invert_band2 run x chunks of 128 directions trips: beyond
                 // A.area_max band candidates (run x directions) the general kernel's block pyramid is cheaper)
-                if (eligb && (run > ((w_hi_e < W.w_hi && !has_tail) ? XSW_LONG_RUN_MAX_CUT : XSW_LONG_RUN_MAX) || run * ncols_p > A.area_max)) {
+                // (round 5: ... unless the wave's strip is CROWDED with such pixels -- A.b2_crowd or more of its 64: a scene whose a-priori
+                // wind is far from the sigma0 contour everywhere, not a ship or a rain cell.  Their records reach k_invert_band2 side by
+                // side, its waves run the refinement (contour bound, live arc), and a record then costs 0.6 ns where the pyramid costs
+                // 1.9: a-priori x 0.3 944 -> 1115 Mpx/s.  A lone such pixel in a wave that is not refined would be swept as it is.)
+                const bool long_one = eligb && run > ((w_hi_e < W.w_hi && !has_tail) ? XSW_LONG_RUN_MAX_CUT : XSW_LONG_RUN_MAX);
+                const bool big_area = eligb && !long_one && run * ncols_p > A.area_max;
+                const bool crowded = __popcll(__ballot(big_area)) >= A.b2_crowd;
+                if (big_area && crowded && run * ncols_p <= A.area_crowd_max) flags |= F_B2_CROWD;
+                if (long_one || (big_area && (flags & F_B2_CROWD) == 0)) {
                     myc = NC;
                     eligb = false;
                     if (ROLE == 2) skip = true;
@@ -539,7 +547,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                         r.inc_tail = P.i_inc | ((has_tail ? W.w_hi - w_hi_e : 0) << 16);
                         r.rows = W.w_lo | (w_hi_e << 16); r.ipn = W.ip_lo | (ncols_p << 16);
                         r.idx = (unsigned)i;
-                        r.flags = (flags & ~F_TO_B) | (hard ? F_B2_HARD : 0);
+                        r.flags = (flags & ~F_TO_B) | (hard ? F_B2_HARD : 0);  // (F_B2_CROWD rides in `flags`)
                         ((BandRec *)A.rec_b)[at] = r;
                         flags |= F_REC_DONE;
                     }

@@ -517,7 +517,8 @@ __device__ __forceinline__ void band2_run(const DevTables &L, const KArgs &A, co
     // On a friendly scene a wave of list B holds two or three such records and takes them as they are -- round 3's search.
     double jub;
     BandRec r = r_in;
-    const bool refine_wave = __popcll(ballot64(searchable && (r_in.flags & F_B2_HARD) != 0)) >= A.b2_refine_min;
+    const bool refine_wave = __popcll(ballot64(searchable && (r_in.flags & F_B2_HARD) != 0)) >= A.b2_refine_min ||
+                             ballot64(searchable && (r_in.flags & F_B2_CROWD) != 0) != 0ULL;  // (a record beyond XSW_B2_AREA is only here to be refined)
     if (refine_wave) {
         r = band2_refine(L, A, r_in, searchable, jub);
     } else {

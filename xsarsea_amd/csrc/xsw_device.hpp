@@ -107,6 +107,7 @@ struct KArgs {
     int long_run;               // k_invert_band, ROLE 1: rows along the a-priori direction from which a pixel is handed to k_invert_band2
     int tail_max;               // rows past the monotone ones a window may hold for k_invert_band2's tail sweep (0: never)
     int area_max;               // k_invert_band, ROLE 1: band candidates (run x directions) beyond which a pixel skips k_invert_band2 (general kernel instead)
+    int b2_crowd, area_crowd_max;  // k_invert_band, ROLE 1: pixels beyond area_max stay k_invert_band2's when b2_crowd or more of the wave's 64 are such (and their area is at most area_crowd_max)
     int block_min;              // general kernel: windows of at least this many candidates are searched by the block pyramid (co_block_search)
     int wide_min;               // k_invert_band, ROLE 1: windows of at least this many directions are handed to k_invert_band2 whatever their run (its live arc narrows them)
     int b2_refine_min;          // k_invert_band2: records marked F_B2_HARD a wave of 64 must hold for the wave to run the refinement (it costs every lane of the wave)
@@ -125,6 +126,7 @@ enum : int { F_NEED_CO = 1, F_NEED_CR = 2, F_EARLY_NAN = 4, F_CO_FINITE = 8, F_C
              F_CO_LOOSE = 32 /* general kernel: finite inputs, but a bound far above the scale of the scores: block pyramid, no forward differences */,
              F_REC_DONE = 256 /* k_invert_band: the pixel's record is on list B: nothing more to do for it in this wave */,
              F_B2_HARD = 512 /* list B's record: a long run x wide window, or a tail -- worth k_invert_band2's refinement (contour bound, live arc) */,
+             F_B2_CROWD = 1024 /* list B's record: beyond XSW_B2_AREA band candidates, kept for k_invert_band2 because its wave was crowded with such pixels: its wave there MUST refine */,
              F_TO_B = 64, F_TO_C = 128 /* band kernels: the pixel is list B's (k_invert_band2) / list C's (k_invert_blocks) if it is still undecided at the end of the wave */ };
 
 // ------------------------------------------------------------------------------------------------

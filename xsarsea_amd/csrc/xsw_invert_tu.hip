@@ -17,6 +17,9 @@ using namespace xsw;
 #ifndef XSW_B2_AREA
 #define XSW_B2_AREA 2048  // measured with list C at half the raster (profiles/sweep_b2_area.sh, Mpx/s at 1e6 / 8192 / 4096 / 2048 / 1024 / 512): outliers 5 % 727 / 2486 / 2675 / 2711 / 2624 / 2694, a-priori x 0.3 424 / 440 / 512 / 591 / 643 / 620, x 2.5 460 / 459 / 480 / 520 / 508 / 489, x 0.6 1148 / 1147 / 1161 / 1176 / 1128 / 910
 #endif
+#ifndef XSW_B2_CROWD
+#define XSW_B2_CROWD 24  // pixels beyond XSW_B2_AREA a wave of k_invert_band must hold (of 64) for them to stay k_invert_band2's (environment XSW_B2_CROWD; 65: never)
+#endif
 #ifndef XSW_B2_WIDE
 #define XSW_B2_WIDE 0  // directions from which a window is k_invert_band2's whatever its run (0: never)
 #endif
@@ -70,6 +73,9 @@ static int launch_invert(xsw_ctx *c, const KArgs &A_in, int algo, const LaunchCt
         B.long_run = long_run_env;
         static const int area_max_env = getenv("XSW_B2_AREA") ? std::max(1, atoi(getenv("XSW_B2_AREA"))) : XSW_B2_AREA;
         B.area_max = c->T.blk ? area_max_env : 0x7fffffff;  // (without the block tables the general kernel has nothing better to offer)
+        static const int crowd_env = getenv("XSW_B2_CROWD") ? std::max(1, atoi(getenv("XSW_B2_CROWD"))) : XSW_B2_CROWD;
+        B.b2_crowd = crowd_env;  // (65: never)
+        B.area_crowd_max = 1 << 20;
         static const int wide_env = getenv("XSW_B2_WIDE") ? std::max(0, atoi(getenv("XSW_B2_WIDE"))) : XSW_B2_WIDE;
         B.wide_min = wide_env > 0 ? wide_env : 0x7fffffff;
         static const int refine_min_env = getenv("XSW_B2_REFINE_MIN") ? std::max(0, atoi(getenv("XSW_B2_REFINE_MIN"))) : XSW_B2_REFINE_MIN;
