@@ -60,6 +60,9 @@ def main():
         ctx.stats_enable(True)
         run(o)
         st = ctx.stats()
+        ctx.stats_enable(2)  # the production chain with per-kernel counters: candidates k_invert_band2 / k_invert_blocks score per pixel handed
+        run(o)
+        ch = ctx.stats_chain()
         ctx.stats_enable(False)
         n = max(tm["launches"], 1)
         b, b2, bl, ls = tm["first_kernel_ms"] / n, tm["band2_kernel_ms"] / n, tm["blocks_kernel_ms"] / n, tm["second_kernel_ms"] / n
@@ -67,7 +70,9 @@ def main():
         line = (f"{name:<22s} band {b:8.2f} ms  band2 {b2:8.2f} ms ({100 * tm['last_band2_pixels'] / px:6.2f} %)"
                 f"  blocks {bl:8.2f} ms ({100 * tm['last_blocks_pixels'] / px:6.2f} %)  list {ls:8.2f} ms"
                 f"  -> {px / (b + b2 + bl + ls) / 1e3:8.0f} Mpx/s  listed {100 * tm['last_list_pixels'] / px:6.2f} %"
-                f"  cand/px {st['cand_co'] / max(st['pixels_co'], 1):8.1f}  exact {st.get('pixels_exact', 0)}")
+                f"  cand/px {st['cand_co'] / max(st['pixels_co'], 1):8.1f}  exact {st.get('pixels_exact', 0)}"
+                f"  chain cand/px b2 {ch['cand_band2'] / max(tm['last_band2_pixels'], 1):7.1f} blk {ch['cand_blocks'] / max(tm['last_blocks_pixels'], 1):7.1f}"
+                f" refined {100.0 * ch['pixels_refined'] / max(tm['last_band2_pixels'], 1):5.1f} %")
         if args.verify:
             run(o)
             run(o2, _lib.ALGO_EXHAUSTIVE)

@@ -390,10 +390,29 @@ def block_keep(lb, j_ub, m2):
     return not (lb * (1.0 - 1e-8) > j_ub + 1e-8 * (1.0 + m2))
 
 
-def block_pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig, j_ub=np.inf, window=None, tables=None):
+BLK_C4 = 4  # directions of a SUB-BLOCK (round 5, k_invert_blocks): a kept block is bounded once more per quarter before it is swept
+
+
+def subblock_tables(slice_wp):
+    """(lo, hi) float32 [nbr, nbc4]: block_tables per sub-block of BLK_R speed rows x BLK_C4 directions."""
+    n_w, n_phi = slice_wp.shape
+    nbr, nbc4 = -(-n_w // BLK_R), -(-n_phi // BLK_C4)
+    lo, hi = np.empty((nbr, nbc4), np.float32), np.empty((nbr, nbc4), np.float32)
+    for br in range(nbr):
+        for bc in range(nbc4):
+            blk = slice_wp[br * BLK_R:(br + 1) * BLK_R, bc * BLK_C4:(bc + 1) * BLK_C4]
+            lo[br, bc], hi[br, bc] = f32_down(float(blk.min())), f32_up(float(blk.max()))
+    return lo, hi
+
+
+def block_pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig, j_ub=np.inf, window=None, tables=None, sub_tables=None):
     """The reference's argmin of one pixel by the block pyramid.  j_ub: any valid upper bound of the minimum of J (inf: none);
     window = (w_lo, w_hi, ip_lo, ip_hi): only blocks that touch it are looked at (the disc's bounding box; None: the grid).
-    Returns (i_wspd, i_phi, blocks swept, bands kept)."""
+    sub_tables = subblock_tables(slice): a kept block is not swept whole -- each of its quarters (BLK_C4 directions) is bounded
+    once more from its own {min, max} and its own, narrower polar cell, and only the quarters that survive are swept (round 5:
+    where the GMF saturates sigma0 varies faster with the direction than with the speed, a block 16 directions wide nearly always
+    straddles the contour and its sigma0 bound is zero).
+    Returns (i_wspd, i_phi, blocks swept -- quarters count as 1/4 --, bands kept)."""
     n_w, n_phi = slice_wp.shape
     if phi_180:
         b = abs(b)
@@ -420,14 +439,31 @@ def block_pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig,
     cand = {}  # flat -> screening score
     state = {"jub": j_ub, "swept": 0, "bands": 0}
 
-    def sweep(br, bc):
-        state["swept"] += 1
+    def sweep_cols(br, c_from, c_to):
         for r in range(br * BLK_R, min(br * BLK_R + BLK_R, n_w)):
-            for c in range(bc * BLK_C, min(bc * BLK_C + BLK_C, n_phi)):
+            for c in range(c_from, c_to):
                 u = 2.0 * (ah * cphi[c] + bh * sphi[c])
                 js = wh[r] * (wh[r] - u) + (slice_wp[r, c] * inv + sn) ** 2
                 cand[r * n_phi + c] = js
                 state["jub"] = min(state["jub"], (js + m2) * (1.0 + 1e-9) + 1e-9)
+
+    def sweep(br, bc):
+        if sub_tables is None:
+            state["swept"] += 1
+            sweep_cols(br, bc * BLK_C, min(bc * BLK_C + BLK_C, n_phi))
+            return
+        lo4, hi4 = sub_tables
+        r0, r1 = br * BLK_R, min(br * BLK_R + BLK_R, n_w) - 1
+        for bc4 in range(bc * (BLK_C // BLK_C4), (bc + 1) * (BLK_C // BLK_C4)):
+            c0 = bc4 * BLK_C4
+            if c0 >= n_phi:
+                break
+            c1 = min(c0 + BLK_C4, n_phi) - 1
+            lb4 = sig_lb(lo4[br, bc4], hi4[br, bc4], s, inv) + cell_wind_lb(ah, bh, wh[r0], wh[r1], cphi[c0], sphi[c0], cphi[c1], sphi[c1],
+                                                                                (c1 - c0) * dphi)
+            if block_keep(lb4, state["jub"], m2):
+                state["swept"] += BLK_C4 / BLK_C
+                sweep_cols(br, c0, c1 + 1)
 
     for t in range(br_lo // g, br_hi // g + 1):
         rows0, rows1 = t * g * BLK_R, min((t + 1) * g * BLK_R, n_w) - 1

@@ -316,8 +316,9 @@ def test_block_pyramid_finds_the_oracle_argmin(kind):
     idx = cport.invert_numpy(p, inc, s, nan, nan, anc, return_idx=True, reference_layout=False)[2]
     cphi, sphi = np.cos(np.radians(phi_ax)), np.sin(np.radians(phi_ax))
     tabs = [pm.block_tables(co[i]) for i in range(len(inc_ax))]
+    tabs4 = [pm.subblock_tables(co[i]) for i in range(len(inc_ax))]
     n_w, n_phi = len(w_ax), len(phi_ax)
-    swept_bound, swept_free = [], []
+    swept_bound, swept_free, swept_sub = [], [], []
     for i in range(n):
         ii = int(np.argmin(np.abs(inc_ax - inc[i])))
         a, b = anc[i].real, anc[i].imag
@@ -332,6 +333,10 @@ def test_block_pyramid_finds_the_oracle_argmin(kind):
         r = pm.block_pruned_argmin(co[ii], w_ax, phi_ax, cphi, sphi, p.phi_180, s[i], a, b, 0.1, j_ub=j_ub, tables=tabs[ii])
         assert (r[0], r[1]) == (idx[i, 0], idx[i, 1]), (kind, "bound", i, r, idx[i])
         swept_bound.append(r[2])
+        # round 5: the kept blocks bounded once more per quarter (sub-block tables) -- the same argmin from fewer candidates
+        r4 = pm.block_pruned_argmin(co[ii], w_ax, phi_ax, cphi, sphi, p.phi_180, s[i], a, b, 0.1, j_ub=j_ub, tables=tabs[ii], sub_tables=tabs4[ii])
+        assert (r4[0], r4[1]) == (idx[i, 0], idx[i, 1]), (kind, "quarters", i, r4, idx[i])
+        swept_sub.append(r4[2])
         if i % 5 == 0:  # no bound at all: the pyramid finds its own
             r = pm.block_pruned_argmin(co[ii], w_ax, phi_ax, cphi, sphi, p.phi_180, s[i], a, b, 0.1, tables=tabs[ii])
             assert (r[0], r[1]) == (idx[i, 0], idx[i, 1]), (kind, "free", i, r, idx[i])
@@ -346,6 +351,10 @@ def test_block_pyramid_finds_the_oracle_argmin(kind):
     assert np.mean(swept_bound) < 0.08 * nblocks, (np.mean(swept_bound), nblocks)
     # outliers alone (their windows are the whole grid): still a small part of the table
     assert np.mean(swept_bound[:150]) < 0.15 * nblocks, np.mean(swept_bound[:150])
+    # the quarters: never more, and on the smooth GMF well under half of the candidates (outliers and far-off a-priori winds alike)
+    assert all(q <= w + 1e-9 for q, w in zip(swept_sub, swept_bound))
+    if kind in ("cmod5n", "rolloff", "wrap360"):
+        assert np.mean(swept_sub) < 0.6 * np.mean(swept_bound), (np.mean(swept_sub), np.mean(swept_bound))
 
 
 def _lut_for(kind, rng):

@@ -425,9 +425,10 @@ static int install_co(xsw_ctx *c, const xsw_lut *l, const double *d_dense)
         // block pyramid of the general kernel (co_block_search): min / max per block of XSW_BLK_R x XSW_BLK_C candidates and per
         // band of blk_g block rows (6 MB at the default size).  Absent (allocation failure, XSW_NO_BLOCKS=1: A/B measurements and
         // the tests of the old routes): the general kernel sweeps windows and falls back to the exact scan as before.
-        T.blk = nullptr; T.bandmm = nullptr;
-        T.nbr = (nW + XSW_BLK_R - 1) / XSW_BLK_R; T.nbc = (nP + XSW_BLK_C - 1) / XSW_BLK_C;
-        T.blk_g = std::max(1, 64 / T.nbc); T.nbands = (T.nbr + T.blk_g - 1) / T.blk_g;
+        T.blk = nullptr; T.bandmm = nullptr; T.blk4 = nullptr;
+        T.nbr = (nW + XSW_BLK_R - 1) / XSW_BLK_R; T.nbc = (nP + XSW_BLK_C - 1) / XSW_BLK_C; T.nbc4 = (nP + XSW_BLK_C4 - 1) / XSW_BLK_C4;
+        T.blk_g = std::max(1, 64 / T.nbc);
+        T.nbands = (T.nbr + T.blk_g - 1) / T.blk_g;
         static const bool blocks_off = getenv("XSW_NO_BLOCKS") != nullptr;
         if (e == hipSuccess && !blocks_off && (long long)nI * T.nbr * T.nbc < (1LL << 31)) {
             float2 *d_blk = nullptr, *d_band = nullptr;
@@ -442,6 +443,22 @@ static int install_co(xsw_ctx *c, const xsw_lut *l, const double *d_dense)
             }
             if (e2 == hipSuccess) { T.blk = d_blk; T.bandmm = d_band; }
             else (void)hipGetLastError();
+            // the same per sub-block of XSW_BLK_C4 directions (k_invert_blocks bounds the quarters of a kept block before sweeping:
+            // sigma0 varies faster with the direction than with the speed where the GMF saturates, so a block 16 directions wide
+            // nearly always straddles the contour); 23 MB at the default size.  XSW_NO_BLK4=1: not built (A/B, tests of the old sweep)
+            static const bool blk4_off = getenv("XSW_NO_BLK4") != nullptr;
+            if (T.blk && !blk4_off && (long long)nI * T.nbr * T.nbc4 < (1LL << 31)) {
+                float2 *d_blk4 = nullptr;
+                const long long nblk4 = (long long)nI * T.nbr * T.nbc4;
+                hipError_t e3 = hipMalloc((void **)&d_blk4, (size_t)nblk4 * sizeof(float2) + 64);
+                if (e3 == hipSuccess) {
+                    c->co_allocs.push_back(d_blk4);
+                    hipLaunchKernelGGL(k_block_minmax, dim3((unsigned)((nblk4 + 255) / 256)), dim3(256), 0, c->stream, d_dense, nI, nW, nP, T.nbr, T.nbc4, d_blk4, XSW_BLK_C4);
+                    e3 = hipGetLastError();
+                }
+                if (e3 == hipSuccess) T.blk4 = d_blk4;
+                else (void)hipGetLastError();
+            }
         }
         if (e == hipSuccess) e = hipMemcpyAsync(h_flags, d_flags, sizeof h_flags, hipMemcpyDeviceToHost, c->stream);
         hipError_t se = hipStreamSynchronize(c->stream);

@@ -459,6 +459,8 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                 // wind is far from the sigma0 contour everywhere, not a ship or a rain cell.  Their records reach k_invert_band2 side by
                 // side, its waves run the refinement (contour bound, live arc), and a record then costs 0.6 ns where the pyramid costs
                 // 1.9: a-priori x 0.3 944 -> 1115 Mpx/s.  A lone such pixel in a wave that is not refined would be swept as it is.)
+                // (round 5, measured: handing the long runs to k_invert_band2 marked for its refinement moves 12 % of the pixels of the x 2.5 scene
+                // there and nearly all of them come back as too many rows -- 49 + 57 ms where 41 + 63 were; they are the pyramid's)
                 const bool long_one = eligb && run > ((w_hi_e < W.w_hi && !has_tail) ? XSW_LONG_RUN_MAX_CUT : XSW_LONG_RUN_MAX);
                 const bool big_area = eligb && !long_one && run * ncols_p > A.area_max;
                 const bool crowded = __popcll(__ballot(big_area)) >= A.b2_crowd;

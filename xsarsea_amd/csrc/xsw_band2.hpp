@@ -266,7 +266,7 @@ __device__ __forceinline__ float js_lower(const Bound32 &b, float vlo, float vhi
 #define XSW_ARC_UNROLL 4
 #endif
 __device__ __forceinline__ void live_arc(const DevTables &L, bool on, int i_inc, double s, double ah, double bh, double jub, double dsig,
-                                         int ip_lo, int ncols, int w_lo, int w_hi, int tail_n, int &first, int &last, int &total_rows)
+                                         int ip_lo, int ncols, int w_lo, int w_hi, int tail_n, int &first, int &last, int &total_rows, int &max_rows)
 {
     // EIGHT directions per trip from ONE 16-byte read of each table row: the kernel is bound by the texture addresser (85 % busy, 557
     // cache-line accesses per record: every lane is another record, so every load touches 64 lines) -- a 2-byte read per direction
@@ -286,7 +286,7 @@ __device__ __forceinline__ void live_arc(const DevTables &L, bool on, int i_inc,
     const bool capped = b_hi < XSW_INV_BINS;
     const double *__restrict__ tmin = L.tail_min ? L.tail_min + mul24_sv((unsigned)L.phi_pad, (unsigned)(ii * (XSW_TAIL_LEVELS + 1))) : nullptr;
     const bool rows_ok = w_hi >= w_lo;
-    first = 0x7fffffff; last = -1; total_rows = 0;
+    first = 0x7fffffff; last = -1; total_rows = 0; max_rows = 0;
     const int g0 = on ? (ip_lo & ~(G - 1)) : 0, ip_end = on ? ip_lo + ncols : 0;  // directions [ip_lo, ip_end)
     const int ngroups = wave_max_i(on ? (ip_end - g0 + G - 1) / G : 0);
     const unsigned long long any_tail = ballot64(on && tail_n > 0);
@@ -320,6 +320,7 @@ __device__ __forceinline__ void live_arc(const DevTables &L, bool on, int i_inc,
             first = (n > 0 && first == 0x7fffffff) ? ip : first;
             last = n > 0 ? ip : last;
             total_rows += n;
+            max_rows = max(max_rows, n);
         }
     }
 }
@@ -490,11 +491,11 @@ __device__ __forceinline__ BandRec band2_refine(const DevTables &L, const KArgs 
     const int w_lo = max(W.w_lo, w_lo_o), w_top = min(W.w_hi, w_hi_o + tail_old);
     const int w_hi = min(w_top, w_hi_o), tail_n = tail_old > 0 ? max(w_top - w_hi_o, 0) : 0;
     const int ip_lo = max(W.ip_lo, ip_lo_o), ip_hi = min(W.ip_hi, ip_lo_o + ncols_o - 1);
-    int a_first, a_last, rows_total;
-    live_arc(L, searchable, i_inc, s, ah, bh, jub, A.dsig_co, ip_lo, ip_hi - ip_lo + 1, w_lo, w_hi, tail_n, a_first, a_last, rows_total);
+    int a_first, a_last, rows_total, rows_dir;
+    live_arc(L, searchable, i_inc, s, ah, bh, jub, A.dsig_co, ip_lo, ip_hi - ip_lo + 1, w_lo, w_hi, tail_n, a_first, a_last, rows_total, rows_dir);
     // (the bound's own candidate is live, so a searchable record always has an arc; stay safe)
     const bool have = searchable && a_last >= a_first && a_first != 0x7fffffff;
-    const bool too_many = have && rows_total > A.b2_rows_max && A.list_c != nullptr;  // the block pyramid's (list C)
+    const bool too_many = have && (rows_total > A.b2_rows_max || rows_dir > XSW_SWEEP_MAX) && A.list_c != nullptr;  // (a direction beyond the sweep's XSW_SWEEP_MAX rows would leave the pixel undecided: list G)  // the block pyramid's (list C)
     BandRec q = r;
     q.inc_tail = i_inc | (tail_n << 16);
     q.rows = (w_lo & 0xffff) | (w_hi << 16);

@@ -45,10 +45,11 @@ __device__ __forceinline__ unsigned seg_bits(unsigned long long m, int q) { retu
 // goes into the bound is rounded once more (~1e-7 of its magnitude), the result is lowered by XSW_BOUND_SLACK x those magnitudes,
 // and a direction within 1e-5 |m| of a cell's edge counts as inside it (the smaller bound).
 struct BlockBound32 { float s, ainv, ah, bh, m2, mh, tol, wh0, whs; };
+template <int C = XSW_BLK_C>
 __device__ __forceinline__ float block_lb(const DevTables &L, float2 mm, int br, int bc, const BlockBound32 &q)
 {
     const int r0 = min(br * XSW_BLK_R, L.n_w - 1), r1 = min(br * XSW_BLK_R + XSW_BLK_R, L.n_w) - 1;
-    const int c0 = min(bc * XSW_BLK_C, L.n_phi - 1), c1 = min(bc * XSW_BLK_C + XSW_BLK_C, L.n_phi) - 1;
+    const int c0 = min(bc * C, L.n_phi - 1), c1 = min(bc * C + C, L.n_phi) - 1;
     const float wha = fmaf((float)r0, q.whs, q.wh0), whb = fmaf((float)max(r1, r0), q.whs, q.wh0);
     const float dsg = vmaxf(0.0f, vmaxf(mm.x - q.s, q.s - mm.y)) * q.ainv;
     const float rad = vmaxf(0.0f, vmaxf(wha - q.mh, q.mh - whb));
@@ -68,7 +69,7 @@ __device__ __forceinline__ float block_lb(const DevTables &L, float2 mm, int br,
 // Up to four pending pixels of the wave (lane l owns pixel l: P_*), one per segment.  Decided pixels: my_flat of the owner lane;
 // the others are flagged in `redo`.
 __device__ __forceinline__ void co_seg16_pass(const DevTables &L, double inv_dsig, int lane, double P_s, double P_a, double P_b, double P_bd, int P_iinc,
-                                              int P_rows, int P_dirs, unsigned long long &pend, SegQEntry *__restrict__ qlds /* this wave's [4][XSW_SEGQ_CAP] */,
+                                              int P_rows, int P_dirs, unsigned long long &pend, SegQEntry *__restrict__ qlds /* this wave's [4][XSW_SEGQ_CAP], then [4][16] */,
                                               int &my_flat, unsigned long long &redo, unsigned &cand)
 {
     constexpr int R = XSW_BLK_R, C = XSW_BLK_C, CAP = XSW_SEGQ_CAP;
@@ -109,6 +110,7 @@ __device__ __forceinline__ void co_seg16_pass(const DevTables &L, double inv_dsi
     const float2 *__restrict__ blk = L.blk + (size_t)i_inc * L.nbr * L.nbc;
     const float2 *__restrict__ bnd = L.bandmm + (size_t)i_inc * L.nbands;
     SegQEntry *__restrict__ qseg = qlds + q * CAP;
+    SegQEntry *__restrict__ fseg = qlds + 4 * CAP + q * 16;  // the quarter blocks of the current four queue entries
 
     double best = inf, second = inf;
     int bflat = 0;
@@ -196,7 +198,89 @@ __device__ __forceinline__ void co_seg16_pass(const DevTables &L, double inv_dsi
         }
     };
     // sweeps the queued blocks: lane = direction, four speed rows per lane; the running minimum tightens the bound
+    // one sweep step: lane = direction `dir` (okd: a candidate's), rows row0 .. row0 + 3
+    auto sweep_rows = [&](bool act, int row0_in, int dir) {
+        const int dirc = act ? min(dir, L.n_phi - 1) : 0;
+        const bool okd = act && dir < L.n_phi;
+        const int row0 = act ? row0_in : 0;
+        const unsigned off0 = slice0 + (unsigned)dirc * 8u;
+        double v[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[k] = ld_co(base, off0, min(row0 + k, L.n_w - 1), rowB);
+        const double2 cs = ((const double2 *)L.csphi)[dirc];
+        const double U = 2.0 * (ah * cs.x + bh * cs.y);
+        int flat = row0 * L.n_phi + dirc;
+        double wh = fma((double)row0, whs, wh0);
+        const double snl = okd ? sn : 1e150;  // a lane without a candidate scores ~1e300: never the minimum, never within eps of it
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const double dd = fma(v[k], inv_dsig, (row0 + k < L.n_w) ? snl : 1e150);
+            const double J = fma(dd, dd, wh * (wh - U));
+            second = vmin(second, vmax(J, best));
+            bflat = J < best ? flat : bflat;
+            best = vmin(best, J);
+            wh += whs;
+            flat += L.n_phi;
+        }
+    };
+    auto tighten = [&]() {
+        const double g = seg_min_d<16>(best);
+        jub = (g < 1e290) ? fmin(jub, (g + m2) * (1.0 + 1e-9) + 1e-9) : jub;
+    };
+    // SUB-BLOCK sweep (round 5): where the GMF saturates sigma0 varies faster with the direction than with the speed, so a block
+    // 16 directions wide nearly always straddles the contour -- its sigma0 bound is zero, and with the EXACT bound the pyramid
+    // still swept 2 100 candidates per pixel (33 blocks: a-priori x 2.5; scratch study: 440 in as many quarter blocks).  A kept
+    // block is bounded once more per QUARTER (XSW_BLK_C4 = 4 directions, table L.blk4: lane = quarter sl & 3 of queue entry
+    // sl >> 2: four entries per step), the quarters that survive are noted (<= 16 per step) and swept four at a time (lane =
+    // direction sl & 3 of quarter sl >> 2, four rows per lane as before).
+    auto sweep_queue4 = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int jmax = wave_max_i(qn);
+        const float2 *__restrict__ blk4 = L.blk4 + (size_t)i_inc * L.nbr * L.nbc4;
+        const int sub = sl & 3, ent = sl >> 2;
+#pragma unroll 1
+        for (int j0 = 0; j0 < jmax; j0 += 4) {
+            const SegQEntry e = qseg[min(j0 + ent, CAP - 1)];
+            const bool actc = j0 + ent < qn && !((double)e.lb * (1.0 - 1e-8) > jub + slack);
+            const int br = e.brbc & 0xffff, bc4 = (int)((unsigned)e.brbc >> 16) * 4 + sub;
+            const bool v4 = actc && bc4 * XSW_BLK_C4 < L.n_phi;
+            const float2 mm4 = blk4[v4 ? br * L.nbc4 + bc4 : 0];
+            const float lb4 = block_lb<XSW_BLK_C4>(L, mm4, v4 ? br : 0, v4 ? bc4 : 0, Q);
+            const bool keep4 = v4 && !((double)lb4 > jub + slack);
+            const unsigned long long kw = ballot64(keep4);
+            if (kw == 0ULL) continue;
+            const unsigned kb = seg_bits(kw, q);
+            if (keep4) {
+                SegQEntry f;
+                f.brbc = br | (bc4 << 16);
+                f.lb = lb4;
+                fseg[__popc(kb & ((1u << sl) - 1u))] = f;
+            }
+            const int nf = __popc(kb);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int steps = (__popc((unsigned)(kw | (kw >> 16) | (kw >> 32) | (kw >> 48)) & 0xffffu) + 3) >> 2;  // (an upper bound of every segment's count, exact when one segment holds the most in every position)
+#pragma unroll 1
+            for (int t = 0; t < steps; ++t) {
+                const int fi = t * 4 + ent;
+                const SegQEntry f = fseg[min(fi, 15)];
+                const bool act = fi < nf && !((double)f.lb * (1.0 - 1e-8) > jub + slack);
+                const unsigned long long am = ballot64(act);
+                if (am == 0ULL) continue;
+                sweep_rows(act, (f.brbc & 0xffff) * R, (int)((unsigned)f.brbc >> 16) * XSW_BLK_C4 + sub);
+                tighten();
+                cand += (unsigned)__popcll(am) * 4u;
+            }
+            __builtin_amdgcn_wave_barrier();  // the quarter list is rewritten by the next group
+        }
+        qn = 0;
+        __builtin_amdgcn_wave_barrier();  // the queue is rewritten by the next round
+    };
     auto sweep_queue = [&]() {
+        if (L.blk4) { sweep_queue4(); return; }  // (uniform)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -207,33 +291,8 @@ __device__ __forceinline__ void co_seg16_pass(const DevTables &L, double inv_dsi
             const bool act = j < qn && !((double)e.lb * (1.0 - 1e-8) > jub + slack);
             const unsigned long long am = ballot64(act);
             if (am == 0ULL) continue;
-            const int br = e.brbc & 0xffff, bc = (int)((unsigned)e.brbc >> 16);
-            const int dir = bc * C + sl, dirc = act ? min(dir, L.n_phi - 1) : 0;
-            const bool okd = act && dir < L.n_phi;
-            const int row0 = act ? br * R : 0;
-            const unsigned off0 = slice0 + (unsigned)dirc * 8u;
-            double v[R];
-#pragma unroll
-            for (int k = 0; k < R; ++k) v[k] = ld_co(base, off0, min(row0 + k, L.n_w - 1), rowB);
-            const double2 cs = ((const double2 *)L.csphi)[dirc];
-            const double U = 2.0 * (ah * cs.x + bh * cs.y);
-            int flat = row0 * L.n_phi + dirc;
-            double wh = fma((double)row0, whs, wh0);
-            const double snl = okd ? sn : 1e150;  // a lane without a candidate scores ~1e300: never the minimum, never within eps of it
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const double dd = fma(v[k], inv_dsig, (row0 + k < L.n_w) ? snl : 1e150);
-                const double J = fma(dd, dd, wh * (wh - U));
-                second = vmin(second, vmax(J, best));
-                bflat = J < best ? flat : bflat;
-                best = vmin(best, J);
-                wh += whs;
-                flat += L.n_phi;
-            }
-            if ((j & 1) != 0 || j + 1 >= jmax) {  // every other block: the bound follows the segment's running minimum
-                const double g = seg_min_d<16>(best);
-                jub = (g < 1e290) ? fmin(jub, (g + m2) * (1.0 + 1e-9) + 1e-9) : jub;
-            }
+            sweep_rows(act, (e.brbc & 0xffff) * R, (int)((unsigned)e.brbc >> 16) * C + sl);
+            if ((j & 1) != 0 || j + 1 >= jmax) tighten();  // every other block: the bound follows the segment's running minimum
             cand += (unsigned)__popcll(am) * 4u;
         }
         qn = 0;
@@ -352,7 +411,7 @@ template <typename T, typename TO, bool CR>
 __global__ __launch_bounds__(256, XSW_BLOCKS_WAVES) void k_invert_blocks(DevTables L, KArgs A)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __shared__ SegQEntry qlds[4][4 * XSW_SEGQ_CAP];
+    __shared__ SegQEntry qlds[4][4 * XSW_SEGQ_CAP + 64];
     const long long count = (long long)*A.list_c_count;
     const long long nlist = count < (long long)A.list_c_cap ? count : (long long)A.list_c_cap;  // (what did not fit went to k_invert_list's list)
     const long long nwaves = (long long)gridDim.x * 4;

@@ -59,6 +59,8 @@ struct DevTables {
     // direction (blk_g = the block rows one wave trip covers, one lane per block).  Null: not built.
     const float2 *blk;     // [n_inc][nbr][nbc]
     const float2 *bandmm;  // [n_inc][nbands]
+    const float2 *blk4;    // [n_inc][nbr][nbc4]: the same per SUB-BLOCK of XSW_BLK_R rows x XSW_BLK_C4 directions (k_invert_blocks, round 5); null: not built
+    int nbc4;
     int nbr, nbc, blk_g, nbands;
     int blk_span_ok;       // a block spans less than 170 deg of direction: the sector bound of co_block_search holds
     double w0, inv_wstep, phi0, phi_last, inv_dphi;
@@ -733,7 +735,9 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
 #ifndef XSW_BLK_C
 #define XSW_BLK_C 16
 #endif
+#define XSW_BLK_C4 4  // directions of a sub-block (k_invert_blocks: a kept block is bounded once more per quarter before it is swept)
 static_assert(XSW_BLK_R * XSW_BLK_C == 64, "one candidate of a block per lane");
+static_assert(XSW_BLK_C == 4 * XSW_BLK_C4, "four sub-blocks per block");
 __device__ __forceinline__ int co_block_search(const DevTables &L, int i_inc, double s, double a, double b, double jub_in, int w_lo, int w_hi,
                                                int ip_lo, int ip_hi, double dsig, double inv_dsig, int lane, unsigned &cand, bool &went_exact)
 {
