@@ -405,14 +405,32 @@ def subblock_tables(slice_wp):
     return lo, hi
 
 
-def block_pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig, j_ub=np.inf, window=None, tables=None, sub_tables=None):
+CELL_R, CELL_C = 8, 2  # blocks per level-1 CELL of k_invert_blocks (round 5): 32 speed rows x 32 directions
+
+
+def cell_tables(lo, hi):
+    """(lo, hi) float32 [ncr, ncc] of the cells of CELL_R x CELL_C blocks, from block_tables' arrays."""
+    nbr, nbc = lo.shape
+    ncr, ncc = -(-nbr // CELL_R), -(-nbc // CELL_C)
+    clo, chi = np.empty((ncr, ncc), np.float32), np.empty((ncr, ncc), np.float32)
+    for i in range(ncr):
+        for j in range(ncc):
+            clo[i, j] = lo[i * CELL_R:(i + 1) * CELL_R, j * CELL_C:(j + 1) * CELL_C].min()
+            chi[i, j] = hi[i * CELL_R:(i + 1) * CELL_R, j * CELL_C:(j + 1) * CELL_C].max()
+    return clo, chi
+
+
+def block_pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig, j_ub=np.inf, window=None, tables=None, sub_tables=None, cells=False):
     """The reference's argmin of one pixel by the block pyramid.  j_ub: any valid upper bound of the minimum of J (inf: none);
     window = (w_lo, w_hi, ip_lo, ip_hi): only blocks that touch it are looked at (the disc's bounding box; None: the grid).
     sub_tables = subblock_tables(slice): a kept block is not swept whole -- each of its quarters (BLK_C4 directions) is bounded
     once more from its own {min, max} and its own, narrower polar cell, and only the quarters that survive are swept (round 5:
     where the GMF saturates sigma0 varies faster with the direction than with the speed, a block 16 directions wide nearly always
     straddles the contour and its sigma0 bound is zero).
-    Returns (i_wspd, i_phi, blocks swept -- quarters count as 1/4 --, bands kept)."""
+    cells = True: level 1 is k_invert_blocks's (round 5) -- cells of CELL_R x CELL_C blocks, each with its own {min, max} AND its own
+    polar cell (a band over all directions has a sigma0 range that holds nearly any s, and only the radial wind bound), the most
+    promising cell first, then every cell the tightened bound keeps.
+    Returns (i_wspd, i_phi, blocks swept -- quarters count as 1/4 --, bands (cells) kept)."""
     n_w, n_phi = slice_wp.shape
     if phi_180:
         b = abs(b)
@@ -465,7 +483,31 @@ def block_pruned_argmin(slice_wp, wspd, phi, cphi, sphi, phi_180, s, a, b, dsig,
                 state["swept"] += BLK_C4 / BLK_C
                 sweep_cols(br, c0, c1 + 1)
 
-    for t in range(br_lo // g, br_hi // g + 1):
+    if cells:
+        clo, chi = cell_tables(lo, hi)
+
+        def cell_lb(i, j):
+            r0, r1 = i * CELL_R * BLK_R, min((i + 1) * CELL_R * BLK_R, n_w) - 1
+            c0, c1 = j * CELL_C * BLK_C, min((j + 1) * CELL_C * BLK_C, n_phi) - 1
+            return sig_lb(clo[i, j], chi[i, j], s, inv) + cell_wind_lb(ah, bh, wh[r0], wh[r1], cphi[c0], sphi[c0], cphi[c1], sphi[c1], (c1 - c0) * dphi)
+
+        def do_cell(i, j):
+            state["bands"] += 1
+            for br in range(max(i * CELL_R, br_lo), min((i + 1) * CELL_R, nbr, br_hi + 1)):
+                for bc in range(max(j * CELL_C, bc_lo), min((j + 1) * CELL_C, nbc, bc_hi + 1)):
+                    if block_keep(lb_of(br, bc), state["jub"], m2):
+                        sweep(br, bc)
+
+        todo = [(i, j) for i in range(br_lo // CELL_R, br_hi // CELL_R + 1) for j in range(bc_lo // CELL_C, bc_hi // CELL_C + 1)]
+        first = min(todo, key=lambda ij: cell_lb(*ij))
+        do_cell(*first)
+        for ij in todo:
+            if ij != first and block_keep(cell_lb(*ij), state["jub"], m2):
+                do_cell(*ij)
+        todo_bands = ()
+    else:
+        todo_bands = range(br_lo // g, br_hi // g + 1)
+    for t in todo_bands:
         rows0, rows1 = t * g * BLK_R, min((t + 1) * g * BLK_R, n_w) - 1
         lb1 = sig_lb(blo[t], bhi[t], s, inv) + radial_lb(mh, wh[rows0], wh[rows1])
         if not block_keep(lb1, state["jub"], m2):

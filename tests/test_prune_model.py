@@ -337,6 +337,9 @@ def test_block_pyramid_finds_the_oracle_argmin(kind):
         r4 = pm.block_pruned_argmin(co[ii], w_ax, phi_ax, cphi, sphi, p.phi_180, s[i], a, b, 0.1, j_ub=j_ub, tables=tabs[ii], sub_tables=tabs4[ii])
         assert (r4[0], r4[1]) == (idx[i, 0], idx[i, 1]), (kind, "quarters", i, r4, idx[i])
         swept_sub.append(r4[2])
+        if i % 2 == 0:  # ... and with level 1 by cells of 8 x 2 blocks (k_invert_blocks) instead of bands over all directions
+            rc = pm.block_pruned_argmin(co[ii], w_ax, phi_ax, cphi, sphi, p.phi_180, s[i], a, b, 0.1, j_ub=j_ub, tables=tabs[ii], sub_tables=tabs4[ii], cells=True)
+            assert (rc[0], rc[1]) == (idx[i, 0], idx[i, 1]), (kind, "cells", i, rc, idx[i])
         if i % 5 == 0:  # no bound at all: the pyramid finds its own
             r = pm.block_pruned_argmin(co[ii], w_ax, phi_ax, cphi, sphi, p.phi_180, s[i], a, b, 0.1, tables=tabs[ii])
             assert (r[0], r[1]) == (idx[i, 0], idx[i, 1]), (kind, "free", i, r, idx[i])

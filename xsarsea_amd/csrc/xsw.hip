@@ -425,8 +425,9 @@ static int install_co(xsw_ctx *c, const xsw_lut *l, const double *d_dense)
         // block pyramid of the general kernel (co_block_search): min / max per block of XSW_BLK_R x XSW_BLK_C candidates and per
         // band of blk_g block rows (6 MB at the default size).  Absent (allocation failure, XSW_NO_BLOCKS=1: A/B measurements and
         // the tests of the old routes): the general kernel sweeps windows and falls back to the exact scan as before.
-        T.blk = nullptr; T.bandmm = nullptr; T.blk4 = nullptr;
+        T.blk = nullptr; T.bandmm = nullptr; T.blk4 = nullptr; T.cellmm = nullptr;
         T.nbr = (nW + XSW_BLK_R - 1) / XSW_BLK_R; T.nbc = (nP + XSW_BLK_C - 1) / XSW_BLK_C; T.nbc4 = (nP + XSW_BLK_C4 - 1) / XSW_BLK_C4;
+        T.ncr = (T.nbr + XSW_CELL_R - 1) / XSW_CELL_R; T.ncc = (T.nbc + XSW_CELL_C - 1) / XSW_CELL_C;
         T.blk_g = std::max(1, 64 / T.nbc);
         T.nbands = (T.nbr + T.blk_g - 1) / T.blk_g;
         static const bool blocks_off = getenv("XSW_NO_BLOCKS") != nullptr;
@@ -441,7 +442,18 @@ static int install_co(xsw_ctx *c, const xsw_lut *l, const double *d_dense)
                 hipLaunchKernelGGL(k_band_minmax, dim3((unsigned)((nband + 255) / 256)), dim3(256), 0, c->stream, d_blk, nI, T.nbr, T.nbc, T.blk_g, T.nbands, d_band);
                 e2 = hipGetLastError();
             }
-            if (e2 == hipSuccess) { T.blk = d_blk; T.bandmm = d_band; }
+            // level 1 of k_invert_blocks: cells of XSW_CELL_R x XSW_CELL_C blocks (a band over ALL directions has a sigma0 range that
+            // holds nearly any s and no sector bound: 401 blocks left to bound per outlier pixel where these cells leave 70)
+            float2 *d_cell = nullptr;
+            const long long ncell = (long long)nI * T.ncr * T.ncc;
+            if (e2 == hipSuccess) e2 = hipMalloc((void **)&d_cell, (size_t)ncell * sizeof(float2) + 64);
+            if (e2 == hipSuccess) {
+                c->co_allocs.push_back(d_cell);
+                hipLaunchKernelGGL(k_block_minmax, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, c->stream, d_dense, nI, nW, nP, T.ncr, T.ncc, d_cell,
+                                   XSW_CELL_C * XSW_BLK_C, XSW_CELL_R * XSW_BLK_R);
+                e2 = hipGetLastError();
+            }
+            if (e2 == hipSuccess) { T.blk = d_blk; T.bandmm = d_band; T.cellmm = d_cell; }
             else (void)hipGetLastError();
             // the same per sub-block of XSW_BLK_C4 directions (k_invert_blocks bounds the quarters of a kept block before sweeping:
             // sigma0 varies faster with the direction than with the speed where the GMF saturates, so a block 16 directions wide
@@ -558,6 +570,7 @@ static int install_co(xsw_ctx *c, const xsw_lut *l, const double *d_dense)
     T.band_mul24 = ((uint64_t)nI * nW <= 0xFFFFFFu && (uint64_t)(nI + 1) * XSW_INV_BINS <= 0xFFFFFFu && (uint64_t)ppad * 8u <= 0xFFFFFFu &&
                     (uint64_t)(nI + 1) * nP <= 0xFFFFFFu && (uint64_t)wpad * 8u <= 0xFFFFFFu && (uint64_t)nI * nP * wpad * 8u < ((uint64_t)1 << 32)) ? 1 : 0;
     T.blk_span_ok = (nP > 1 && (XSW_BLK_C - 1) * (l->phi[nP - 1] - l->phi[0]) / (nP - 1) < 170.0) ? 1 : 0;
+    T.cell_span_ok = (nP > 1 && (XSW_CELL_C * XSW_BLK_C - 1) * (l->phi[nP - 1] - l->phi[0]) / (nP - 1) < 170.0) ? 1 : 0;
     // transposed slices for the ray scan
     double *dT = nullptr;
     HIPCHK(c, hipMalloc((void **)&dT, (size_t)nI * nP * wpad * sizeof(double) + 512 * sizeof(double)));

@@ -45,16 +45,16 @@ __device__ __forceinline__ unsigned seg_bits(unsigned long long m, int q) { retu
 // goes into the bound is rounded once more (~1e-7 of its magnitude), the result is lowered by XSW_BOUND_SLACK x those magnitudes,
 // and a direction within 1e-5 |m| of a cell's edge counts as inside it (the smaller bound).
 struct BlockBound32 { float s, ainv, ah, bh, m2, mh, tol, wh0, whs; };
-template <int C = XSW_BLK_C>
-__device__ __forceinline__ float block_lb(const DevTables &L, float2 mm, int br, int bc, const BlockBound32 &q)
+template <int C = XSW_BLK_C, int RR = XSW_BLK_R>
+__device__ __forceinline__ float block_lb(const DevTables &L, float2 mm, int br, int bc, const BlockBound32 &q, bool span_ok)
 {
-    const int r0 = min(br * XSW_BLK_R, L.n_w - 1), r1 = min(br * XSW_BLK_R + XSW_BLK_R, L.n_w) - 1;
+    const int r0 = min(br * RR, L.n_w - 1), r1 = min(br * RR + RR, L.n_w) - 1;
     const int c0 = min(bc * C, L.n_phi - 1), c1 = min(bc * C + C, L.n_phi) - 1;
     const float wha = fmaf((float)r0, q.whs, q.wh0), whb = fmaf((float)max(r1, r0), q.whs, q.wh0);
     const float dsg = vmaxf(0.0f, vmaxf(mm.x - q.s, q.s - mm.y)) * q.ainv;
     const float rad = vmaxf(0.0f, vmaxf(wha - q.mh, q.mh - whb));
     float lbw = rad * rad;
-    if (L.blk_span_ok) {
+    if (span_ok) {
         const float2 ea = ((const float2 *)L.csphi32)[c0], eb = ((const float2 *)L.csphi32)[max(c1, c0)];
         const bool inside = (ea.x * q.bh - ea.y * q.ah >= -q.tol) && (q.ah * eb.y - q.bh * eb.x >= -q.tol);
         const float pmx = vmaxf(q.ah * ea.x + q.bh * ea.y, q.ah * eb.x + q.bh * eb.y);
@@ -101,14 +101,16 @@ __device__ __forceinline__ void co_seg16_pass(const DevTables &L, double inv_dsi
     const int ip_lo = (int)(dirs & 0xffffu), ip_hi = min(max((int)(dirs >> 16), ip_lo), L.n_phi - 1);
     const int br_lo = w_lo / R, br_hi = w_hi / R, bc_lo = ip_lo / C, bc_hi = ip_hi / C, ncb = bc_hi - bc_lo + 1;
     const int nbw = (br_hi - br_lo + 1) * ncb;
-    const float inv_ncb = 1.0f / (float)ncb;
-    const int G = L.blk_g, tb_lo = br_lo / G, nbd = br_hi / G - tb_lo + 1;
+    // level-1 cells of XSW_CELL_R x XSW_CELL_C blocks the window touches: ncr x ncc of them, cell t = (t / ncc, t % ncc) from (cr_lo, cc_lo)
+    constexpr int GR = XSW_CELL_R, GC = XSW_CELL_C;
+    const int cr_lo = br_lo / GR, cc_lo = bc_lo / GC, ncc = bc_hi / GC - cc_lo + 1, ncell = (br_hi / GR - cr_lo + 1) * ncc;
+    const float inv_ncc = 1.0f / (float)ncc, inv_ncb = 1.0f / (float)ncb;
     const bool bandmode = valid && nbw > XSW_SEG_DIRECT;
-    bool bad = bandmode && nbd > 64;  // (LUTs of thousands of speed rows: the wave-wide search of k_invert_list)
+    bool bad = bandmode && ncell > 128;  // (LUTs of thousands of speed rows: the wave-wide search of k_invert_list)
     const char *__restrict__ base = (const char *)L.co;
     const unsigned rowB = (unsigned)L.phi_pad * 8u, slice0 = (unsigned)(i_inc * L.n_w) * rowB;
     const float2 *__restrict__ blk = L.blk + (size_t)i_inc * L.nbr * L.nbc;
-    const float2 *__restrict__ bnd = L.bandmm + (size_t)i_inc * L.nbands;
+    const float2 *__restrict__ cel = L.cellmm + (size_t)i_inc * L.ncr * L.ncc;
     SegQEntry *__restrict__ qseg = qlds + q * CAP;
     SegQEntry *__restrict__ fseg = qlds + 4 * CAP + q * 16;  // the quarter blocks of the current four queue entries
 
@@ -116,69 +118,62 @@ __device__ __forceinline__ void co_seg16_pass(const DevTables &L, double inv_dsi
     int bflat = 0;
     int qn = 0;
 
-    // level 1, one lane per band (band tb_lo + 16 j + sl): the segment's most promising band (mask = false), or the set of bands
-    // the current bound keeps (mask = true), as a bit mask relative to tb_lo
-    const int nj = (wave_max_i(bandmode && !bad ? nbd : 0) + 15) >> 4;  // wave-uniform, <= 4
-    auto level1 = [&](bool mask, int &first, unsigned long long &bands) {
-        double lb1[4];
-        bool tv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            lb1[j] = inf;
-            tv[j] = false;
-            if (j >= nj) continue;  // wave-uniform
+    // level 1, one lane per cell (cell 16 j + sl of the window's): the segment's most promising cell (mask = false), or the set of
+    // cells the current bound keeps (mask = true), as a bit mask of 128
+    const int nj = (wave_max_i(bandmode && !bad ? ncell : 0) + 15) >> 4;  // wave-uniform, <= 8
+    auto level1 = [&](bool mask, int &first, unsigned long long &m0, unsigned long long &m1) {
+        float mn = 3e38f;
+        int tmin = -1;
+        m0 = 0ULL;
+        m1 = 0ULL;
+#pragma unroll 1
+        for (int j = 0; j < nj; ++j) {  // wave-uniform trip count (ONE copy of the bound's code: the kernel's size is felt in the instruction cache)
             const int t = 16 * j + sl;
-            tv[j] = bandmode && !bad && t < nbd;
-            const int tc = min(tb_lo + t, L.nbands - 1);
-            const float2 mm = bnd[tv[j] ? tc : 0];
-            const int r0 = tc * G * R, r1 = min((tc + 1) * G * R, L.n_w) - 1;
-            const float wha = fmaf((float)r0, Q.whs, Q.wh0), whb = fmaf((float)r1, Q.whs, Q.wh0);
-            const float dsg = vmaxf(0.0f, vmaxf(mm.x - Q.s, Q.s - mm.y)) * Q.ainv;
-            const float rad = vmaxf(0.0f, vmaxf(wha - Q.mh, Q.mh - whb));
-            const float lb = fmaf(dsg, dsg, rad * rad);
-            lb1[j] = tv[j] ? (double)(lb - XSW_BOUND_SLACK * (lb + Q.m2 + whb * whb) - 1e-6f) : inf;
+            const bool tv = bandmode && !bad && t < ncell;
+            const int cr = tv ? (int)(((float)t + 0.5f) * inv_ncc) : 0, cc = tv ? t - cr * ncc : 0;
+            const int cra = min(cr_lo + cr, L.ncr - 1), cca = min(cc_lo + cc, L.ncc - 1);
+            const float2 mm = cel[cra * L.ncc + cca];
+            const float lb = block_lb<GC * C, GR * R>(L, mm, cra, cca, Q, L.cell_span_ok != 0);
+            if (!mask) {  // (uniform)
+                tmin = (tv && lb < mn) ? t : tmin;
+                mn = (tv && lb < mn) ? lb : mn;
+            } else {
+                const unsigned long long bits = (unsigned long long)seg_bits(ballot64(tv && !((double)lb * (1.0 - 1e-8) > jub + slack)), q);
+                if (j < 4) m0 |= bits << (16 * j);
+                else m1 |= bits << (16 * (j - 4));
+            }
         }
-        if (!mask) {
-            double mn = 1e308;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) mn = vmin(mn, tv[j] ? lb1[j] : 1e308);
-            mn = seg_min_d<16>(mn);
-            first = -1;
-#pragma unroll
-            for (int j = 3; j >= 0; --j) {
-                if (j >= nj) continue;
-                const unsigned bits = seg_bits(ballot64(tv[j] && lb1[j] == mn), q);
-                first = bits ? 16 * j + (__ffs((int)bits) - 1) : first;
-            }
-        } else {
-            bands = 0ULL;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j >= nj) continue;
-                const unsigned bits = seg_bits(ballot64(tv[j] && !(lb1[j] * (1.0 - 1e-8) > jub + slack)), q);
-                bands |= (unsigned long long)bits << (16 * j);
-            }
+        if (!mask) {  // the segment's smallest bound: the cell of the lowest lane that holds it
+            const float g = (float)seg_min_d<16>((double)mn);
+            const unsigned bits = seg_bits(ballot64(tmin >= 0 && mn == g), q);
+            const int t_of = __shfl(tmin, bits ? q * 16 + (__ffs((int)bits) - 1) : lane);
+            first = bits ? t_of : -1;
         }
     };
-    // the block rows [curA, ...) and the number of blocks curN of band t (relative to tb_lo) inside the window
-    auto band_range = [&](int t, int &curA, int &curN) {
-        curA = max((tb_lo + t) * G, br_lo);
-        curN = (min(min((tb_lo + t + 1) * G, L.nbr), br_hi + 1) - curA) * ncb;
+    // the blocks of cell t inside the window: block rows from curA, block columns from curC, curW columns wide, curN blocks
+    int curA = br_lo, curC = bc_lo, curW = ncb, curN = 0, k0 = 0;
+    float inv_curW = inv_ncb;
+    auto cell_range = [&](int t) {
+        const int cr = (int)(((float)t + 0.5f) * inv_ncc), cc = t - cr * ncc;
+        const int a0 = max((cr_lo + cr) * GR, br_lo), a1 = min(min((cr_lo + cr + 1) * GR, L.nbr) - 1, br_hi);
+        const int b0 = max((cc_lo + cc) * GC, bc_lo), b1 = min(min((cc_lo + cc + 1) * GC, L.nbc) - 1, bc_hi);
+        curA = a0; curC = b0; curW = max(b1 - b0 + 1, 1);
+        inv_curW = curW == 1 ? 1.0f : (curW == 2 ? 0.5f : 1.0f / (float)curW);
+        curN = max(a1 - a0 + 1, 0) * curW;
     };
     // bounds the blocks of the segment's current band [curA.., curN blocks, from block k0 on), then of the bands left in `bands`, 16
     // per step; the kept ones are queued.  A segment whose queue is nearly full pauses (its position is kept): the queues are
     // swept, the bound tightens, and bound_blocks is called again.
-    int curA = br_lo, curN = 0, k0 = 0;
-    unsigned long long bands = 0ULL;
+    unsigned long long bands = 0ULL, bands1 = 0ULL;
     auto bound_blocks = [&]() {
         while (ballot64(k0 < curN && qn <= CAP - 16) != 0ULL) {
             const bool go = k0 < curN && qn <= CAP - 16;
             const int idx = k0 + sl;
             const bool bv = go && idx < curN;
-            const int dr = bv ? (int)(((float)idx + 0.5f) * inv_ncb) : 0, dc = bv ? idx - dr * ncb : 0;
-            const int br = curA + dr, bc = bc_lo + dc;
+            const int dr = bv ? (int)(((float)idx + 0.5f) * inv_curW) : 0, dc = bv ? idx - dr * curW : 0;
+            const int br = curA + dr, bc = curC + dc;
             const float2 mm = blk[bv ? br * L.nbc + bc : 0];
-            const float lb = block_lb(L, mm, br, bc, Q);
+            const float lb = block_lb(L, mm, br, bc, Q, L.blk_span_ok != 0);
             const bool keep = bv && !((double)lb > jub + slack);
             const unsigned kb = seg_bits(ballot64(keep), q);
             if (keep) {
@@ -189,10 +184,11 @@ __device__ __forceinline__ void co_seg16_pass(const DevTables &L, double inv_dsi
             }
             qn += __popc(kb);
             k0 += go ? 16 : 0;
-            while (go && k0 >= curN && bands != 0ULL) {  // the segment's next band
-                const int t = __ffsll((long long)bands) - 1;
-                bands &= bands - 1;
-                band_range(t, curA, curN);
+            while (go && k0 >= curN && (bands | bands1) != 0ULL) {  // the segment's next cell
+                const int t = bands ? __ffsll((long long)bands) - 1 : 64 + __ffsll((long long)bands1) - 1;
+                if (bands) bands &= bands - 1;
+                else bands1 &= bands1 - 1;
+                cell_range(t);
                 k0 = 0;
             }
         }
@@ -247,7 +243,7 @@ __device__ __forceinline__ void co_seg16_pass(const DevTables &L, double inv_dsi
             const int br = e.brbc & 0xffff, bc4 = (int)((unsigned)e.brbc >> 16) * 4 + sub;
             const bool v4 = actc && bc4 * XSW_BLK_C4 < L.n_phi;
             const float2 mm4 = blk4[v4 ? br * L.nbc4 + bc4 : 0];
-            const float lb4 = block_lb<XSW_BLK_C4>(L, mm4, v4 ? br : 0, v4 ? bc4 : 0, Q);
+            const float lb4 = block_lb<XSW_BLK_C4>(L, mm4, v4 ? br : 0, v4 ? bc4 : 0, Q, L.blk_span_ok != 0);
             const bool keep4 = v4 && !((double)lb4 > jub + slack);
             const unsigned long long kw = ballot64(keep4);
             if (kw == 0ULL) continue;
@@ -303,24 +299,27 @@ __device__ __forceinline__ void co_seg16_pass(const DevTables &L, double inv_dsi
     int first = -1;
     curN = (valid && !bandmode) ? nbw : 0;
     if (nj > 0) {
-        level1(false, first, bands);
+        level1(false, first, bands, bands1);
         bands = 0ULL;
-        if (bandmode && !bad && first >= 0) band_range(first, curA, curN);
+        bands1 = 0ULL;
+        if (bandmode && !bad && first >= 0) cell_range(first);
     }
     do {
         bound_blocks();
         sweep_queue();
     } while (ballot64(k0 < curN) != 0ULL);
-    if (nj > 0) {  // round 2: the bands the tightened bound keeps
+    if (nj > 0) {  // round 2: the cells the tightened bound keeps
         int dummy;
-        level1(true, dummy, bands);
-        if (first >= 0) bands &= ~(1ULL << first);
+        level1(true, dummy, bands, bands1);
+        if (first >= 0 && first < 64) bands &= ~(1ULL << first);
+        if (first >= 64) bands1 &= ~(1ULL << (first - 64));
         curN = 0;
         k0 = 0;
-        if (bands != 0ULL) {
-            const int t = __ffsll((long long)bands) - 1;
-            bands &= bands - 1;
-            band_range(t, curA, curN);
+        if ((bands | bands1) != 0ULL) {
+            const int t = bands ? __ffsll((long long)bands) - 1 : 64 + __ffsll((long long)bands1) - 1;
+            if (bands) bands &= bands - 1;
+            else bands1 &= bands1 - 1;
+            cell_range(t);
         }
         do {
             bound_blocks();

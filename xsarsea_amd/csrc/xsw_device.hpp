@@ -61,6 +61,8 @@ struct DevTables {
     const float2 *bandmm;  // [n_inc][nbands]
     const float2 *blk4;    // [n_inc][nbr][nbc4]: the same per SUB-BLOCK of XSW_BLK_R rows x XSW_BLK_C4 directions (k_invert_blocks, round 5); null: not built
     int nbc4;
+    const float2 *cellmm;  // [n_inc][ncr][ncc]: the same per CELL of XSW_CELL_R block rows x XSW_CELL_C block columns (level 1 of k_invert_blocks, round 5); with blk or not at all
+    int ncr, ncc, cell_span_ok;
     int nbr, nbc, blk_g, nbands;
     int blk_span_ok;       // a block spans less than 170 deg of direction: the sector bound of co_block_search holds
     double w0, inv_wstep, phi0, phi_last, inv_dphi;
@@ -734,6 +736,12 @@ __device__ __forceinline__ int co_box_search(const DevTables &L, int i_inc, doub
 #endif
 #ifndef XSW_BLK_C
 #define XSW_BLK_C 16
+#endif
+#ifndef XSW_CELL_R
+#define XSW_CELL_R 8  // block rows ...
+#endif
+#ifndef XSW_CELL_C
+#define XSW_CELL_C 2  // ... x block columns of a level-1 cell of k_invert_blocks (32 speed rows x 32 directions: 16 blocks, one bounding step)
 #endif
 #define XSW_BLK_C4 4  // directions of a sub-block (k_invert_blocks: a kept block is bounded once more per quarter before it is swept)
 static_assert(XSW_BLK_R * XSW_BLK_C == 64, "one candidate of a block per lane");

@@ -173,14 +173,15 @@ __global__ __launch_bounds__(256) void k_inv_rows(const double *__restrict__ den
 // directions, float32 rounded OUTWARD (a bound must never be tighter than the table), and per band of `g` block rows over all
 // directions.  One thread per block / per band.
 __global__ __launch_bounds__(256) void k_block_minmax(const double *__restrict__ dense, int n_inc, int n_w, int n_phi, int nbr, int nbc,
-                                                      float2 *__restrict__ blk, int blk_c = XSW_BLK_C /* directions per block: XSW_BLK_C, or XSW_BLK_C4 for the sub-blocks */)
+                                                      float2 *__restrict__ blk, int blk_c = XSW_BLK_C /* directions per block: XSW_BLK_C, XSW_BLK_C4 for the sub-blocks, XSW_CELL_C XSW_BLK_C for the cells */,
+                                                      int blk_r = XSW_BLK_R /* rows per block (XSW_CELL_R XSW_BLK_R for the cells) */)
 {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)n_inc * nbr * nbc) return;
     const int bc = (int)(t % nbc), br = (int)((t / nbc) % nbr), i = (int)(t / ((long long)nbc * nbr));
     const double *sl = dense + (size_t)i * n_w * n_phi;
     double lo = __builtin_inf(), hi = -__builtin_inf();
-    for (int r = br * XSW_BLK_R; r < min(br * XSW_BLK_R + XSW_BLK_R, n_w); ++r)
+    for (int r = br * blk_r; r < min(br * blk_r + blk_r, n_w); ++r)
         for (int c = bc * blk_c; c < min(bc * blk_c + blk_c, n_phi); ++c) {
             const double v = sl[(size_t)r * n_phi + c];
             lo = fmin(lo, v);
