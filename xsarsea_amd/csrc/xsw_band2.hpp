@@ -520,7 +520,11 @@ __device__ __forceinline__ void band2_run(const DevTables &L, const KArgs &A, co
     BandRec r = r_in;
     const bool refine_wave = __popcll(ballot64(searchable && (r_in.flags & F_B2_HARD) != 0)) >= A.b2_refine_min ||
                              ballot64(searchable && (r_in.flags & F_B2_CROWD) != 0) != 0ULL;  // (a record beyond XSW_B2_AREA is only here to be refined)
+#if defined(XSW_EXP_B2) && XSW_EXP_B2 == 2
+    if (false) {
+#else
     if (refine_wave) {
+#endif
         r = band2_refine(L, A, r_in, searchable, jub);
     } else {
         const double rs = (double)r_in.d * fabs(A.inv_dsig_co);
@@ -581,8 +585,12 @@ __device__ __forceinline__ void band2_run(const DevTables &L, const KArgs &A, co
             }
         };
 #define XSW_B2_RUN(c) run(std::integral_constant<int, b2_seg(c)>{}, std::integral_constant<int, b2_dirs(c)>{}, c)
+#ifndef XSW_EXP_B2
         XSW_B2_RUN(0); XSW_B2_RUN(1); XSW_B2_RUN(2); XSW_B2_RUN(3); XSW_B2_RUN(4); XSW_B2_RUN(5);
         XSW_B2_RUN(6); XSW_B2_RUN(7); XSW_B2_RUN(8); XSW_B2_RUN(9); XSW_B2_RUN(10);
+#else
+        if (big) res_[pos] = 0;  // (timing experiment: no passes, results invalid)
+#endif
 #undef XSW_B2_RUN
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
