@@ -610,6 +610,21 @@ def _chord_from_budget(uh, m2, bud, w0, inv_wstep):
     return int(np.ceil(max(xc - xh, -4.0))), int(np.floor(min(xc + xh, 40000.0)))
 
 
+def direction_is_live(inv_col, b_lo, b_hi, bins, j_ub, uh, m2, wh0, whs, w_lo, w_hi):
+    """LIVE ARC test of one direction (stage 1 of k_invert_band: window_arc; k_invert_band2: live_arc): the rows of the band
+    [inv_col[b_lo], inv_col[b_hi]) inside [w_lo, w_hi] (b_lo / b_hi: the pixel's threshold bins, table_bins; b_hi = bins: no
+    threshold above the band) -- the direction is dead when there is none, or when the smallest wind term the parabola
+    wh^2 - 2 uh wh + m2 takes over them (its minimum clamped into the interval, deflated by the float32 slack of the device)
+    exceeds the bound.  A window narrowed to [first live, last live] direction holds every candidate with J <= j_ub."""
+    lo = max(w_lo, int(inv_col[b_lo]))
+    hi = min(w_hi, int(inv_col[b_hi]) - 1) if b_hi < bins else w_hi
+    if lo > hi:
+        return False
+    t = min(max(uh, wh0 + lo * whs), wh0 + hi * whs)
+    jw = (m2 + t * (t - 2.0 * uh)) - 4e-6 * (m2 + t * (t + 2.0 * abs(uh)))
+    return not (jw > j_ub * (1.0 + 1e-5) + 1e-5)
+
+
 def joint_rows(inv_col, grid, s, dsig, j_ub, uh, m2, wh0, whs, w0, inv_wstep, w_lo, w_hi, rounds=2):
     """Rows [lo, hi] of ONE direction (monotone part of the window, [w_lo, w_hi]) that can hold a candidate with J <= j_ub
     (j_ub already inflated): steps B, A, B, A, ... as described above.  inv_col[b] = the direction's inverse-row table.

@@ -678,7 +678,7 @@ for scale, inc_lo, inc_hi in ((1.0, 17.0, 25.0), (1.6, 20.0, 36.0), (2.5, 30.0, 
 
 @pytest.mark.parametrize("long_run,list_cap", [(None, None), (None, "300"), ("1", None), ("1", "300"), ("0", None), (None, "300-nomask"),
                                                (None, "norecords"), (None, "300-norecords"), (None, "refine-always"), (None, "refine-never"),
-                                               ("1", "300-refine-always"), (None, "rows8-refine-always"), (None, "wide16-refine-always"), (None, "crowd1"), (None, "noblk4"), ("0", "noblk4")])
+                                               ("1", "300-refine-always"), (None, "rows8-refine-always"), (None, "wide16-refine-always"), (None, "crowd1"), (None, "noblk4"), ("0", "noblk4"), (None, "arc-always"), (None, "300-arc-always"), ("1", "arc-never")])
 def test_long_run_kernel(long_run, list_cap):
     """The three-kernel chain in a fresh process: k_invert_band hands the pixels whose band holds XSW_LONG_RUN (default 4) or more
     rows along the a-priori direction to k_invert_band2 (batched sweeps clipped to the disc's chord).  Four scenes from friendly
@@ -690,7 +690,7 @@ def test_long_run_kernel(long_run, list_cap):
     import subprocess
     import sys
     from conftest import REPO
-    env = {k: v for k, v in os.environ.items() if k not in ("XSW_LONG_RUN", "XSW_NO_STRIP_MASKS", "XSW_NO_RECORDS", "XSW_B2_REFINE_MIN", "XSW_B2_ROWS_MAX", "XSW_B2_WIDE", "XSW_B2_CROWD", "XSW_NO_BLK4")}
+    env = {k: v for k, v in os.environ.items() if k not in ("XSW_LONG_RUN", "XSW_NO_STRIP_MASKS", "XSW_NO_RECORDS", "XSW_B2_REFINE_MIN", "XSW_B2_ROWS_MAX", "XSW_B2_WIDE", "XSW_B2_CROWD", "XSW_NO_BLK4", "XSW_ARC_MIN", "XSW_ARC_CROWD")}
     if long_run is not None:
         env["XSW_LONG_RUN"] = long_run
     if list_cap:
@@ -709,6 +709,13 @@ def test_long_run_kernel(long_run, list_cap):
             env["XSW_B2_CROWD"] = "65"  # (a pixel kept beyond XSW_B2_AREA by the crowd rule makes its wave refine whatever the count)
         if list_cap.startswith("rows8"):
             env["XSW_B2_ROWS_MAX"] = "8"
+        # stage 1's live arc (window_arc): every window of 8 directions or more narrowed whatever the wave holds (also on the overflow
+        # routes, where k_invert_band2 redoes stage 1 on its own LDS block) / never
+        if list_cap.endswith("arc-always"):
+            env["XSW_ARC_MIN"] = "8"
+            env["XSW_ARC_CROWD"] = "1"
+        if list_cap.endswith("arc-never"):
+            env["XSW_ARC_MIN"] = "0"
         if list_cap == "noblk4":  # k_invert_blocks without the sub-block tables: kept blocks are swept whole (round 4's sweep)
             env["XSW_NO_BLK4"] = "1"
         if list_cap == "crowd1":  # every pixel beyond XSW_B2_AREA stays with k_invert_band2 (its wave refines) instead of k_invert_blocks

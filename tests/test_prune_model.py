@@ -435,6 +435,13 @@ def test_joint_rows_keep_every_candidate_under_the_bound(seed):
             under = np.nonzero(J[w_lo:w_hi + 1] <= j_ub)[0] + w_lo
             if under.size:
                 assert lo <= under.min() and under.max() <= hi, (case, rounds, lo, hi, under.min(), under.max())
+        # the live-arc test of a direction (window_arc in stage 1 of k_invert_band, live_arc in k_invert_band2): with the pixel's own
+        # band bins, a direction that holds a candidate under the bound is never declared dead
+        d = np.sqrt(max(j_ub, 0.0)) * dsig * (1 + 1e-6) + 1e-9
+        tb_lo, tb_hi = pm.table_bins(grid[0], width, grid[2], bins, s - d, s + d)
+        live = pm.direction_is_live(inv_col, tb_lo, tb_hi if tb_hi >= 0 else bins, bins, j_ub, uh, m2, wh[0], wh[1] - wh[0], int(w_lo), int(w_hi))
+        if (J[w_lo:w_hi + 1] <= j_ub).any():
+            assert live, (case, "live arc", tb_lo, tb_hi)
         thr_lo, thr_hi = s - rng.uniform(0, 2), s + rng.uniform(0, 2)
         b_lo, b_hi = pm.table_bins_margin(grid[0], grid[2], bins, thr_lo, thr_hi)
         assert b_lo == 0 or b_lo * width + grid[0] <= thr_lo

@@ -119,11 +119,75 @@ struct BandRec {  // what k_invert_band hands to k_invert_band2 per pixel (KArgs
     int flags;         // the pixel's class bits
 };
 struct Band2Slot;
+constexpr int kBand2SlotBytes = 56;  // sizeof(Band2Slot) (xsw_band2.hpp asserts it): band_wave<ROLE 2> runs on k_invert_band2's LDS block, whose slots are these
 template <typename T, typename TO, bool CR>
 __device__ __forceinline__ void band2_core(const DevTables &L, const KArgs &A, const BandRec &r, bool in, bool searchable, int lane, Band2Slot *__restrict__ slots,
                                            int *__restrict__ res_, long long strip);
 
 __device__ __forceinline__ unsigned long long ballot64(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
+#ifndef XSW_BOUND_SLACK
+#define XSW_BOUND_SLACK 4e-6f  // outward slack of the float32 bound arithmetic (xsw_band2.hpp: Bound32)
+#endif
+// LIVE ARC OF A WIDE WINDOW in stage 1 (round 5), one pixel per lane: first / last direction of [ip_lo, ip_lo + ncols) in which a row of
+// the band (rows [inv[bin], inv[bhi]) of the direction's inverse-row column, inside [w_lo, w_hi]) can have its WIND term within
+// the bound (the smallest of the parabola wh^2 - 2 uh wh + m2 over those rows, deflated, against jub).  A window is the polar
+// bounding box of the disc: with an a-priori wind at 0.3 ... 0.6 of the truth it spans +-40 ... 180 deg although the band only
+// meets the disc in a few of those directions -- and a wide window with short runs costs stage 2 a wave-pass of its own (~300
+// wave-instructions where a friendly pixel costs 50) whatever the directions hold.  Eight directions per 16-byte read of the two
+// table rows (k_invert_band2's live arc without tails and row counts: xsw_band2.hpp).
+// Stage 1 of k_invert_band sits on a register-allocation edge (63 VGPRs at 8 waves per SIMD): eight directions per step (16-byte
+// reads as in k_invert_band2) put 28 bytes of the kernel's state into scratch and cost the benchmark scene 1.1 ms although its
+// waves never take the branch; as a real call (noinline) the kernel ran 46 ms instead of 34.  XSW_ARC_G directions per step.
+// Returns first | last << 16 (first > last: no live direction).
+#ifndef XSW_ARC_G
+#define XSW_ARC_G 8
+#endif
+__device__ __forceinline__ unsigned window_arc(const unsigned short *__restrict__ inv_rows, const float *__restrict__ csphi32, int phi_pad, float wh0, float whs,
+                                               bool on, int i_inc, int bin, int bhi, float uhx, float uhy, float jub, int ip_lo, int ncols, int w_lo, int w_hi)
+{
+    constexpr int G = XSW_ARC_G;
+    static_assert(G == 4 || G == 8, "directions per table read");
+    const int ii = on ? i_inc : 0;
+    const unsigned short *__restrict__ inv_a = inv_rows + mul24_sv((unsigned)phi_pad, (unsigned)(ii * XSW_INV_BINS + (on ? bin : 0)));
+    const unsigned short *__restrict__ inv_b = inv_rows + mul24_sv((unsigned)phi_pad, (unsigned)(ii * XSW_INV_BINS + (on ? min(bhi, XSW_INV_BINS - 1) : 0)));
+    const bool capped = bhi < XSW_INV_BINS;
+    const float m2 = uhx * uhx + uhy * uhy;
+    int first = 0x7fff, last = -1;
+    const int g0 = on ? (ip_lo & ~(G - 1)) : 0, ip_end = on ? ip_lo + ncols : 0;
+    const int ngroups = wave_max_i(on ? (ip_end - g0 + G - 1) / G : 0);
+#pragma unroll 1
+    for (int k = 0; k < ngroups; ++k) {
+        const int gp = g0 + k * G;
+        const bool gact = on && gp < ip_end;
+        const int gc = gact ? gp : 0;  // (phi_pad is a multiple of 8: the group's read stays inside the padded row)
+        unsigned wa[G / 2], wb[G / 2];
+        if constexpr (G == 8) {
+            const uint4 qa = *(const uint4 *)(inv_a + gc), qb = *(const uint4 *)(inv_b + gc);
+            wa[0] = qa.x; wa[1] = qa.y; wa[2] = qa.z; wa[3] = qa.w; wb[0] = qb.x; wb[1] = qb.y; wb[2] = qb.z; wb[3] = qb.w;
+        } else {
+            const uint2 qa = *(const uint2 *)(inv_a + gc), qb = *(const uint2 *)(inv_b + gc);
+            wa[0] = qa.x; wa[1] = qa.y; wb[0] = qb.x; wb[1] = qb.y;
+        }
+#pragma unroll
+        for (int h = 0; h < G / 2; ++h) {  // two directions per 16-byte read of the cos / sin table
+            const float4 c4 = ((const float4 *)((const float2 *)csphi32 + gc))[h];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int ip = gc + 2 * h + e;
+                const int ra = (int)((wa[h] >> (e * 16)) & 0xffffu), rb = (int)((wb[h] >> (e * 16)) & 0xffffu);
+                const float uh = e ? uhx * c4.z + uhy * c4.w : uhx * c4.x + uhy * c4.y;
+                const int lo = max(w_lo, ra), hi = capped ? min(w_hi, rb - 1) : w_hi;
+                const float t = vminf(vmaxf(uh, fmaf((float)lo, whs, wh0)), fmaf((float)max(hi, lo), whs, wh0));
+                const float jw = fmaf(t, t - 2.0f * uh, m2) - XSW_BOUND_SLACK * (m2 + t * (t + 2.0f * fabsf(uh)));
+                const bool live = gact && ip >= ip_lo && ip < ip_end && lo <= hi && !(jw > jub);
+                first = (live && first == 0x7fff) ? ip : first;
+                last = live ? ip : last;
+            }
+        }
+    }
+    return last >= 0 ? (unsigned)first | ((unsigned)last << 16) : 0x00007fffu;
+}
 __device__ __forceinline__ double ld_co(const char *__restrict__ base, unsigned off0, int row, unsigned rowB)
 {
     return *(const double *)(base + (off0 + __umul24((unsigned)row, rowB)));
@@ -375,7 +439,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
         int ncols_p = 0;
         if (todo) {
             bool loose = false;
-            const CoWindow W = co_window_lanes<XSW_BAND_RAYS, XSW_BAND_RAY_D, XSW_BAND_SEEDED != 0>(L, P, A.inv_dsig_co, fabs(A.dsig_co), loose);
+            CoWindow W = co_window_lanes<XSW_BAND_RAYS, XSW_BAND_RAY_D, XSW_BAND_SEEDED != 0>(L, P, A.inv_dsig_co, fabs(A.dsig_co), loose);
             // A window that reaches past the slice's monotone rows is still the band rule's if no row up there can be in the band:
             // every LUT value of the rows >= mono_rows in the window's directions lies above s + d (L.tail_min, a sparse table over
             // the directions: CMOD5.N saturates and then falls back slowly, so this is the common case of an a-priori wind well
@@ -413,7 +477,7 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
             // threshold bins of the slice's inverse table: the largest grid threshold <= s - d (bin 0 also stands for anything
             // below the grid; the check repeats the builder's own expression, k_inv_rows), and the smallest grid threshold
             // > s + d (none: the band may reach the window's last row)
-            const double thr_lo = P.s_co - W.band_d, thr_hi = P.s_co + W.band_d;
+            double thr_lo = P.s_co - W.band_d, thr_hi = P.s_co + W.band_d;
             int bin = 0, bhi = XSW_INV_BINS;
             if (eligb) {
                 const double *g = L.inv_grid + 3 * P.i_inc;
@@ -424,6 +488,34 @@ __device__ __forceinline__ void band_wave(const DevTables &L, const KArgs &A, lo
                 bhi = (int)fmin(fmax((thr_hi - t0) * g[2], -1.0), (double)XSW_INV_BINS) + 1;
                 if (bhi < XSW_INV_BINS && !(fma((double)bhi, width, t0) > thr_hi)) ++bhi;
                 if (bhi < XSW_INV_BINS && !(fma((double)bhi, width, t0) > thr_hi)) bhi = XSW_INV_BINS;
+            }
+            if (ROLE != 0 && A.arc_min < 0x7fffffff) {
+                // WIDE windows narrowed to their live arc before they are classed (window_arc) -- when enough of the wave's pixels are wide
+                // to pay for the walk (every lane waits for the widest window: 23 groups of 8 directions for 181)
+                // (a window with a tail keeps its directions: the table says nothing about the rows past the monotone ones -- k_invert_band2's
+                // live arc, which knows the tail's chord, narrows it)
+                const bool widep = eligb && !has_tail && ncols_p >= A.arc_min;
+                if (__popcll(__ballot(widep)) >= A.arc_crowd) {
+                    const double rs = W.band_d * fabs(A.inv_dsig_co);
+                    const float jub32 = (float)(rs * rs) * (1.0f + 1e-5f) + 1e-5f;
+                    // (stage 1 holds 63 live VGPRs here: the walk's own state does not fit beside them, and a compiler spill costs the
+                    // kernel scratch -- four doubles wait in the lane's own, still unused LDS slot instead)
+                    // (ROLE 2 runs on k_invert_band2's LDS block: 64 slots of kBand2SlotBytes, not of sizeof(BandSlot))
+                    double *park;
+                    if constexpr (ROLE == 2) park = (double *)((char *)slots + lane * kBand2SlotBytes);
+                    else park = (double *)&slots[lane];
+                    park[0] = thr_lo; park[1] = thr_hi; park[2] = W.band_d; park[3] = P.s_co;
+                    __asm__ volatile("" ::: "memory");
+                    const unsigned arc = window_arc(L.inv_rows, (const float *)L.csphi32, L.phi_pad, (float)(0.5 * L.w0), (float)L.wstep_half, widep, P.i_inc, bin, bhi,
+                                                    (float)(0.5 * P.a_re), (float)(0.5 * P.b_eff), jub32, W.ip_lo, ncols_p, W.w_lo, w_hi_e);
+                    __asm__ volatile("" ::: "memory");
+                    thr_lo = park[0]; thr_hi = park[1]; W.band_d = park[2]; P.s_co = park[3];
+                    const int a_first = (int)(arc & 0xffffu), a_last = (int)(arc >> 16);
+                    if (widep && a_last >= a_first) {  // (the bound's own candidate is live: there always is an arc; stay safe)
+                        W.ip_lo = a_first;
+                        ncols_p = a_last - a_first + 1;
+                    }
+                }
             }
             bool hard = false;  // ROLE 1: the handed pixel is worth k_invert_band2's refinement (long run x wide window, or a tail)
             int myc = NC;

@@ -55,6 +55,8 @@ struct Band2Slot {  // 56 bytes per pixel in LDS, read by every lane of its segm
     int b_lo, b_hi;  // threshold bins of the band s -+ |dsig| sqrt(jub) (bins_margin; b_hi = XSW_INV_BINS: none above)
 };
 
+static_assert(sizeof(Band2Slot) == kBand2SlotBytes && kBand2SlotBytes >= 32, "band_wave<ROLE 2> parks four doubles per lane in these slots");
+
 // |m| and its direction in degrees within [phi0, phi0 + 360), as load_pixel forms them (float32 root / arctangent: box_from_jub's margins cover them)
 __device__ __forceinline__ void mag_theta(const DevTables &L, double a, double b, double &mag, double &theta)
 {
@@ -520,11 +522,7 @@ __device__ __forceinline__ void band2_run(const DevTables &L, const KArgs &A, co
     BandRec r = r_in;
     const bool refine_wave = __popcll(ballot64(searchable && (r_in.flags & F_B2_HARD) != 0)) >= A.b2_refine_min ||
                              ballot64(searchable && (r_in.flags & F_B2_CROWD) != 0) != 0ULL;  // (a record beyond XSW_B2_AREA is only here to be refined)
-#if defined(XSW_EXP_B2) && XSW_EXP_B2 == 2
-    if (false) {
-#else
     if (refine_wave) {
-#endif
         r = band2_refine(L, A, r_in, searchable, jub);
     } else {
         const double rs = (double)r_in.d * fabs(A.inv_dsig_co);
@@ -585,12 +583,8 @@ __device__ __forceinline__ void band2_run(const DevTables &L, const KArgs &A, co
             }
         };
 #define XSW_B2_RUN(c) run(std::integral_constant<int, b2_seg(c)>{}, std::integral_constant<int, b2_dirs(c)>{}, c)
-#ifndef XSW_EXP_B2
         XSW_B2_RUN(0); XSW_B2_RUN(1); XSW_B2_RUN(2); XSW_B2_RUN(3); XSW_B2_RUN(4); XSW_B2_RUN(5);
         XSW_B2_RUN(6); XSW_B2_RUN(7); XSW_B2_RUN(8); XSW_B2_RUN(9); XSW_B2_RUN(10);
-#else
-        if (big) res_[pos] = 0;  // (timing experiment: no passes, results invalid)
-#endif
 #undef XSW_B2_RUN
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

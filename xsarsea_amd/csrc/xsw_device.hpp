@@ -113,6 +113,7 @@ struct KArgs {
     int area_max;               // k_invert_band, ROLE 1: band candidates (run x directions) beyond which a pixel skips k_invert_band2 (general kernel instead)
     int b2_crowd, area_crowd_max;  // k_invert_band, ROLE 1: pixels beyond area_max stay k_invert_band2's when b2_crowd or more of the wave's 64 are such (and their area is at most area_crowd_max)
     int block_min;              // general kernel: windows of at least this many candidates are searched by the block pyramid (co_block_search)
+    int arc_min, arc_crowd;     // k_invert_band: windows of at least arc_min directions are narrowed to their live arc in stage 1 when arc_crowd or more of the wave's 64 pixels are such (0x7fffffff: never)
     int wide_min;               // k_invert_band, ROLE 1: windows of at least this many directions are handed to k_invert_band2 whatever their run (its live arc narrows them)
     int b2_refine_min;          // k_invert_band2: records marked F_B2_HARD a wave of 64 must hold for the wave to run the refinement (it costs every lane of the wave)
     int b2_rows_max;            // k_invert_band2: rows the live arc of a pixel may hold after the joint shrink's first step before the pixel is passed on to k_invert_blocks

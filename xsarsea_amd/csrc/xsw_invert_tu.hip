@@ -17,6 +17,12 @@ using namespace xsw;
 #ifndef XSW_B2_AREA
 #define XSW_B2_AREA 2048  // measured with list C at half the raster (profiles/sweep_b2_area.sh, Mpx/s at 1e6 / 8192 / 4096 / 2048 / 1024 / 512): outliers 5 % 727 / 2486 / 2675 / 2711 / 2624 / 2694, a-priori x 0.3 424 / 440 / 512 / 591 / 643 / 620, x 2.5 460 / 459 / 480 / 520 / 508 / 489, x 0.6 1148 / 1147 / 1161 / 1176 / 1128 / 910
 #endif
+#ifndef XSW_ARC_MIN
+#define XSW_ARC_MIN 48    // directions from which a window is narrowed to its live arc in stage 1 of k_invert_band (environment XSW_ARC_MIN; 0: never)
+#endif
+#ifndef XSW_ARC_CROWD
+#define XSW_ARC_CROWD 32  // ... when this many of the wave's 64 pixels are such (environment XSW_ARC_CROWD)
+#endif
 #ifndef XSW_B2_CROWD
 #define XSW_B2_CROWD 24  // pixels beyond XSW_B2_AREA a wave of k_invert_band must hold (of 64) for them to stay k_invert_band2's (environment XSW_B2_CROWD; 65: never)
 #endif
@@ -78,6 +84,10 @@ static int launch_invert(xsw_ctx *c, const KArgs &A_in, int algo, const LaunchCt
         B.area_crowd_max = 1 << 20;
         static const int wide_env = getenv("XSW_B2_WIDE") ? std::max(0, atoi(getenv("XSW_B2_WIDE"))) : XSW_B2_WIDE;
         B.wide_min = wide_env > 0 ? wide_env : 0x7fffffff;
+        static const int arc_min_env = getenv("XSW_ARC_MIN") ? atoi(getenv("XSW_ARC_MIN")) : XSW_ARC_MIN;
+        static const int arc_crowd_env = getenv("XSW_ARC_CROWD") ? std::max(1, atoi(getenv("XSW_ARC_CROWD"))) : XSW_ARC_CROWD;
+        B.arc_min = (arc_min_env > 0 && c->T.csphi32) ? arc_min_env : 0x7fffffff;
+        B.arc_crowd = arc_crowd_env;
         static const int refine_min_env = getenv("XSW_B2_REFINE_MIN") ? std::max(0, atoi(getenv("XSW_B2_REFINE_MIN"))) : XSW_B2_REFINE_MIN;
         B.b2_refine_min = refine_min_env;
         static const int b2_rows_env = getenv("XSW_B2_ROWS_MAX") ? std::max(1, atoi(getenv("XSW_B2_ROWS_MAX"))) : XSW_B2_ROWS_MAX;
