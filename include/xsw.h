@@ -178,7 +178,7 @@ int xsw_lut_upload(xsw_ctx *ctx, const xsw_lut *co, const xsw_lut *cr);
  * XSW_ALGO_PRUNED on a LUT whose columns rise monotonically with wind speed (every built-in GMF over most of its rows) runs
  * as FOUR launches on one stream:
  *   k_invert_band    decides the pixels its band rule can (windows inside the monotone rows, short runs of band rows); hands the
- *                    pixels whose band holds a long run of rows along the a-priori direction (XSW_LONG_RUN = 4 or more), or a
+ *                    pixels whose band holds a long run of rows along the a-priori direction (XSW_LONG_RUN = 5 or more), or a
  *                    window that reaches past the monotone rows by a tail it can sweep, to list B as 48-byte records;
  *   k_invert_band2   list B: per record a bound from the sigma0 contour itself (inverse-row table), the live arc of directions,
  *                    per direction the joint shrink of band and chord, batched sweep;

@@ -680,7 +680,7 @@ for scale, inc_lo, inc_hi in ((1.0, 17.0, 25.0), (1.6, 20.0, 36.0), (2.5, 30.0, 
                                                (None, "norecords"), (None, "300-norecords"), (None, "refine-always"), (None, "refine-never"),
                                                ("1", "300-refine-always"), (None, "rows8-refine-always"), (None, "wide16-refine-always"), (None, "crowd1"), (None, "noblk4"), ("0", "noblk4"), (None, "arc-always"), (None, "300-arc-always"), ("1", "arc-never")])
 def test_long_run_kernel(long_run, list_cap):
-    """The three-kernel chain in a fresh process: k_invert_band hands the pixels whose band holds XSW_LONG_RUN (default 4) or more
+    """The three-kernel chain in a fresh process: k_invert_band hands the pixels whose band holds XSW_LONG_RUN (default 5) or more
     rows along the a-priori direction to k_invert_band2 (batched sweeps clipped to the disc's chord).  Four scenes from friendly
     to far-off a-priori winds == the exhaustive sweep on every pixel -- with the default threshold, with XSW_LONG_RUN=1 (every
     eligible pixel goes through k_invert_band2) and 0 (none does); with list capacities of 300 pixels the strip walk (only the

@@ -26,6 +26,9 @@ namespace xsw {
 #ifndef XSW_SEGQ_CAP
 #define XSW_SEGQ_CAP 64  // kept blocks a segment queues before they are swept (and the bound tightened)
 #endif
+#ifndef XSW_FINEQ_CAP
+#define XSW_FINEQ_CAP 64  // surviving quarter blocks a segment collects before they are swept
+#endif
 #ifndef XSW_SEG_DIRECT
 #define XSW_SEG_DIRECT 96  // windows of at most this many blocks are bounded block by block, without the band level
 #endif
@@ -69,7 +72,7 @@ __device__ __forceinline__ float block_lb(const DevTables &L, float2 mm, int br,
 // Up to four pending pixels of the wave (lane l owns pixel l: P_*), one per segment.  Decided pixels: my_flat of the owner lane;
 // the others are flagged in `redo`.
 __device__ __forceinline__ void co_seg16_pass(const DevTables &L, double inv_dsig, int lane, double P_s, double P_a, double P_b, double P_bd, int P_iinc,
-                                              int P_rows, int P_dirs, unsigned long long &pend, SegQEntry *__restrict__ qlds /* this wave's [4][XSW_SEGQ_CAP], then [4][16] */,
+                                              int P_rows, int P_dirs, unsigned long long &pend, SegQEntry *__restrict__ qlds /* this wave's [4][XSW_SEGQ_CAP], then [4][XSW_FINEQ_CAP] */,
                                               int &my_flat, unsigned long long &redo, unsigned &cand)
 {
     constexpr int R = XSW_BLK_R, C = XSW_BLK_C, CAP = XSW_SEGQ_CAP;
@@ -112,7 +115,7 @@ __device__ __forceinline__ void co_seg16_pass(const DevTables &L, double inv_dsi
     const float2 *__restrict__ blk = L.blk + (size_t)i_inc * L.nbr * L.nbc;
     const float2 *__restrict__ cel = L.cellmm + (size_t)i_inc * L.ncr * L.ncc;
     SegQEntry *__restrict__ qseg = qlds + q * CAP;
-    SegQEntry *__restrict__ fseg = qlds + 4 * CAP + q * 16;  // the quarter blocks of the current four queue entries
+    SegQEntry *__restrict__ fseg = qlds + 4 * CAP + q * XSW_FINEQ_CAP;  // the surviving quarter blocks of the current groups of queue entries
 
     double best = inf, second = inf;
     int bflat = 0;
@@ -236,6 +239,10 @@ __device__ __forceinline__ void co_seg16_pass(const DevTables &L, double inv_dsi
         const int jmax = wave_max_i(qn);
         const float2 *__restrict__ blk4 = L.blk4 + (size_t)i_inc * L.nbr * L.nbc4;
         const int sub = sl & 3, ent = sl >> 2;
+        // the surviving quarters of several groups of four entries are collected (XSW_FINEQ_CAP per segment) before they are swept: a
+        // sweep step takes four quarters per segment, and swept group by group the last step of every group was part-filled (5.8
+        // steps per pixel at 47 % of the lanes on a-priori x 2.5)
+        int fn = 0;
 #pragma unroll 1
         for (int j0 = 0; j0 < jmax; j0 += 4) {
             const SegQEntry e = qseg[min(j0 + ent, CAP - 1)];
@@ -245,32 +252,33 @@ __device__ __forceinline__ void co_seg16_pass(const DevTables &L, double inv_dsi
             const float2 mm4 = blk4[v4 ? br * L.nbc4 + bc4 : 0];
             const float lb4 = block_lb<XSW_BLK_C4>(L, mm4, v4 ? br : 0, v4 ? bc4 : 0, Q, L.blk_span_ok != 0);
             const bool keep4 = v4 && !((double)lb4 > jub + slack);
-            const unsigned long long kw = ballot64(keep4);
-            if (kw == 0ULL) continue;
-            const unsigned kb = seg_bits(kw, q);
+            const unsigned kb = seg_bits(ballot64(keep4), q);
             if (keep4) {
                 SegQEntry f;
                 f.brbc = br | (bc4 << 16);
                 f.lb = lb4;
-                fseg[__popc(kb & ((1u << sl) - 1u))] = f;
+                fseg[fn + __popc(kb & ((1u << sl) - 1u))] = f;
             }
-            const int nf = __popc(kb);
+            fn += __popc(kb);
+            const bool last = j0 + 4 >= jmax;
+            if (!last && ballot64(fn > XSW_FINEQ_CAP - 16) == 0ULL) continue;  // room for another group in every segment
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int steps = (__popc((unsigned)(kw | (kw >> 16) | (kw >> 32) | (kw >> 48)) & 0xffffu) + 3) >> 2;  // (an upper bound of every segment's count, exact when one segment holds the most in every position)
+            const int steps = (wave_max_i(fn) + 3) >> 2;
 #pragma unroll 1
             for (int t = 0; t < steps; ++t) {
                 const int fi = t * 4 + ent;
-                const SegQEntry f = fseg[min(fi, 15)];
-                const bool act = fi < nf && !((double)f.lb * (1.0 - 1e-8) > jub + slack);
+                const SegQEntry f = fseg[min(fi, XSW_FINEQ_CAP - 1)];
+                const bool act = fi < fn && !((double)f.lb * (1.0 - 1e-8) > jub + slack);
                 const unsigned long long am = ballot64(act);
                 if (am == 0ULL) continue;
                 sweep_rows(act, (f.brbc & 0xffff) * R, (int)((unsigned)f.brbc >> 16) * XSW_BLK_C4 + sub);
-                tighten();
+                tighten();  // (every step: tightening every other step swept 2 % more candidates and cost 3 % of the kernel)
                 cand += (unsigned)__popcll(am) * 4u;
             }
-            __builtin_amdgcn_wave_barrier();  // the quarter list is rewritten by the next group
+            fn = 0;
+            __builtin_amdgcn_wave_barrier();  // the quarter list is rewritten by the next groups
         }
         qn = 0;
         __builtin_amdgcn_wave_barrier();  // the queue is rewritten by the next round
@@ -410,7 +418,7 @@ template <typename T, typename TO, bool CR>
 __global__ __launch_bounds__(256, XSW_BLOCKS_WAVES) void k_invert_blocks(DevTables L, KArgs A)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __shared__ SegQEntry qlds[4][4 * XSW_SEGQ_CAP + 64];
+    __shared__ SegQEntry qlds[4][4 * XSW_SEGQ_CAP + 4 * XSW_FINEQ_CAP];
     const long long count = (long long)*A.list_c_count;
     const long long nlist = count < (long long)A.list_c_cap ? count : (long long)A.list_c_cap;  // (what did not fit went to k_invert_list's list)
     const long long nwaves = (long long)gridDim.x * 4;

@@ -17,6 +17,9 @@ using namespace xsw;
 #ifndef XSW_B2_AREA
 #define XSW_B2_AREA 2048  // measured with list C at half the raster (profiles/sweep_b2_area.sh, Mpx/s at 1e6 / 8192 / 4096 / 2048 / 1024 / 512): outliers 5 % 727 / 2486 / 2675 / 2711 / 2624 / 2694, a-priori x 0.3 424 / 440 / 512 / 591 / 643 / 620, x 2.5 460 / 459 / 480 / 520 / 508 / 489, x 0.6 1148 / 1147 / 1161 / 1176 / 1128 / 910
 #endif
+#ifndef XSW_LONG_RUN_DEFAULT
+#define XSW_LONG_RUN_DEFAULT 5
+#endif
 #ifndef XSW_ARC_MIN
 #define XSW_ARC_MIN 48    // directions from which a window is narrowed to its live arc in stage 1 of k_invert_band (environment XSW_ARC_MIN; 0: never)
 #endif
@@ -60,11 +63,14 @@ static int launch_invert(xsw_ctx *c, const KArgs &A_in, int algo, const LaunchCt
         B.list_count = lc.list;
         B.list = lc.list + 16;
         B.list_cap = (unsigned)std::min<size_t>(lc.list_cap, 0xfffffff0u);
-        // list B (k_invert_band -> k_invert_band2) follows list G: a pixel whose band holds XSW_LONG_RUN (4) or more rows along the
+        // list B (k_invert_band -> k_invert_band2) follows list G: a pixel whose band holds XSW_LONG_RUN (5) or more rows along the
         // a-priori direction is handed to k_invert_band2 -- one such pixel holds up every pixel of its pass in k_invert_band, and
         // where the a-priori wind is far from the sigma0 contour most pixels are such.  XSW_LONG_RUN=0: never (k_invert_band
         // sweeps every window: A/B measurements); the statistics instantiation sweeps every window in k_invert_band as well.
-        static const int long_run_env = getenv("XSW_LONG_RUN") ? std::max(0, atoi(getenv("XSW_LONG_RUN"))) : 4;
+        // (5 since round 5: with the stage-1 live arc and the cheaper k_invert_band2 re-measured on the hard scenes, 4 / 5 / 6 / 8 rows: cyclone band
+        // 7669 / 8052 / 7971 / 7489 Mpx/s, outliers 5 % 3640 / 3885 / 3955 / 3860, a-priori x 0.6 1925 / 2073 / 2081 / 1908, x 1.6 1586 / 1610 /
+        // 1571 / 1480, inc 17-33 x 1.6 979 / 1009 / 1030 / 990; the 20000 x 20000 benchmark scene 37.31 / 37.44 / 37.77 ms: within its noise for 4 / 5)
+        static const int long_run_env = getenv("XSW_LONG_RUN") ? std::max(0, atoi(getenv("XSW_LONG_RUN"))) : XSW_LONG_RUN_DEFAULT;
         const bool count_inst = A.stats && !A.stats_chain;  // the statistics instantiation: k_invert_band sweeps every window itself and counts
         const bool band2 = long_run_env > 0 && !count_inst;
         if (band2) { B.list_b_count = lc.list + 1; B.list_b = lc.list + 16 + lc.list_cap; B.list_b_cap = (unsigned)std::min<size_t>(XSW_LIST_B_SHARE * lc.list_cap, 0xfffffff0u); }
