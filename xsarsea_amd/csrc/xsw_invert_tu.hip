@@ -33,7 +33,7 @@ using namespace xsw;
 #define XSW_B2_WIDE 0  // directions from which a window is k_invert_band2's whatever its run (0: never)
 #endif
 #ifndef XSW_B2_REFINE_MIN
-#define XSW_B2_REFINE_MIN 32  // records marked for the refinement a wave of k_invert_band2 must hold to run it (environment XSW_B2_REFINE_MIN)
+#define XSW_B2_REFINE_MIN 16  // records marked for the refinement a wave of k_invert_band2 must hold to run it (environment XSW_B2_REFINE_MIN)
 #endif
 #ifndef XSW_BLOCK_MIN
 #define XSW_BLOCK_MIN 1024
