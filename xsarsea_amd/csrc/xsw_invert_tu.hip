@@ -21,10 +21,10 @@ using namespace xsw;
 #define XSW_LONG_RUN_DEFAULT 5
 #endif
 #ifndef XSW_ARC_MIN
-#define XSW_ARC_MIN 48    // directions from which a window is narrowed to its live arc in stage 1 of k_invert_band (environment XSW_ARC_MIN; 0: never)
+#define XSW_ARC_MIN 32    // directions from which a window is narrowed to its live arc in stage 1 of k_invert_band (environment XSW_ARC_MIN; 0: never).  48 / 40 / 32 / 24 at 48 pixels per wave: a-priori x 1.6 1651 / 1663 / 1711 / 1736 Mpx/s, inc 17-33 x 1.6 1012 / 1059 / 1081 / 1071, cyclone band 7816 / 7885 / 7865 / 7637
 #endif
 #ifndef XSW_ARC_CROWD
-#define XSW_ARC_CROWD 32  // ... when this many of the wave's 64 pixels are such (environment XSW_ARC_CROWD)
+#define XSW_ARC_CROWD 48  // ... when this many of the wave's 64 pixels are such (environment XSW_ARC_CROWD)
 #endif
 #ifndef XSW_B2_CROWD
 #define XSW_B2_CROWD 24  // pixels beyond XSW_B2_AREA a wave of k_invert_band must hold (of 64) for them to stay k_invert_band2's (environment XSW_B2_CROWD; 65: never)
