@@ -29,7 +29,16 @@ out = torch.empty((lines, samples), dtype=torch.complex64, device=dev)
 det = torch.empty((lines, samples), dtype=torch.float64, device=dev)
 torch.cuda.synchronize()
 ctx.detrend_raw(lines, samples, _lib.XSW_F32, _lib.XSW_F64, _lib.MEM_DEVICE, s_vv.data_ptr(), np.ones(samples), det.data_ptr())
-ctx.invert_raw(lines, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, inc.data_ptr(), s_vv.data_ptr(), None, None,
-               anc.data_ptr(), out.data_ptr(), None, algo=_lib.ALGO_PRUNED)
+if os.environ.get("XSW_TRAFFIC_DUAL"):  # the dual-pol workload (bench config 3): cross-pol LUT, sigma0_vh + per-pixel dsig, fused select
+    from xsarsea_amd.windspeed import _engine, get_model
+    ctx.upload_luts(cr=_engine._cr_dict(get_model("gmf_s1_v2")._lut(units="dB")))
+    s_vh, dsig = bench.make_crosspol(inc, anc, 777, dev)
+    out_dual = torch.empty((lines, samples), dtype=torch.complex64, device=dev)
+    torch.cuda.synchronize()
+    ctx.invert_raw(lines, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, inc.data_ptr(), s_vv.data_ptr(), s_vh.data_ptr(), dsig.data_ptr(),
+                   anc.data_ptr(), out.data_ptr(), out_dual.data_ptr(), algo=_lib.ALGO_PRUNED, dual_select=True)
+else:
+    ctx.invert_raw(lines, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, inc.data_ptr(), s_vv.data_ptr(), None, None,
+                   anc.data_ptr(), out.data_ptr(), None, algo=_lib.ALGO_PRUNED)
 torch.cuda.synchronize()
 print("done", lines, samples)
