@@ -18,8 +18,8 @@ ctx.upload_luts(co=_engine._co_dict(get_model("gmf_cmod5n")._lut(units="dB")),
                 cr=_engine._cr_dict(get_model("gmf_s1_v2")._lut(units="dB")))
 
 
-def scene(lines, samples, seed, dtype):
-    inc, s_vv, anc = bench.make_scene(lines, samples, lines, 0, seed, dev)
+def scene(lines, samples, seed, dtype, **hard):
+    inc, s_vv, anc = bench.make_scene(lines, samples, lines, 0, seed, dev, **hard)
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     w_abs = anc.abs().clamp(3.0, 80.0).double()
@@ -37,8 +37,8 @@ def scene(lines, samples, seed, dtype):
     return inc, s_vv, s_vh, dsig, anc
 
 
-def run(tag, lines, samples, seed, dtype=torch.float32, dual_select=False):
-    inc, s_vv, s_vh, dsig, anc = scene(lines, samples, seed, dtype)
+def run(tag, lines, samples, seed, dtype=torch.float32, dual_select=False, **hard):
+    inc, s_vv, s_vh, dsig, anc = scene(lines, samples, seed, dtype, **hard)
     cdt = torch.complex64 if dtype == torch.float32 else torch.complex128
     xdt = _lib.XSW_F32 if dtype == torch.float32 else _lib.XSW_F64
     outs = {}
@@ -64,4 +64,12 @@ total = 0
 total += run("dual f32 seed 31", 12000, 6000, 31)
 total += run("dual f32 seed 32, fused select", 12000, 6000, 32, dual_select=True)
 total += run("dual f64 seed 33", 8000, 6000, 33, dtype=torch.float64)
+# round 5: the scenes on which the dual instantiation runs the stage-1 live arc, the crowd rule, k_invert_band2's refinement and the
+# quarter bound of k_invert_blocks (a-priori wind far from the sigma0 contour, near-range incidences, sigma0 outliers)
+total += run("dual f32 a-priori x 0.3", 3000, 6000, 34, anc_scale=0.3)
+total += run("dual f32 a-priori x 0.6, fused select", 3000, 6000, 35, dual_select=True, anc_scale=0.6)
+total += run("dual f32 a-priori x 1.6, inc 17-33", 3000, 6000, 36, anc_scale=1.6, inc_range=(17.0, 33.0))
+total += run("dual f32 a-priori x 2.5", 3000, 6000, 37, anc_scale=2.5)
+total += run("dual f32 outliers 5 %, fused select", 3000, 6000, 38, dual_select=True, outlier_frac=0.05)
+total += run("dual f64 a-priori x 0.6", 2000, 6000, 39, dtype=torch.float64, anc_scale=0.6)
 print("TOTAL differing pixels:", total)

@@ -45,6 +45,9 @@ namespace xsw {
 #ifndef XSW_JOINT_ROUNDS
 #define XSW_JOINT_ROUNDS 2
 #endif
+#ifndef XSW_JOINT_ROUNDS_EASY
+#define XSW_JOINT_ROUNDS_EASY 0  // joint-shrink rounds of the waves that are not refined (band and chord of the record's own bound only)
+#endif
 #ifndef XSW_B2_ROWS_MAX
 #define XSW_B2_ROWS_MAX 4096  // rows (candidates) the live arc may hold after step B: beyond, the pixel is k_invert_blocks's (environment XSW_B2_ROWS_MAX)
 #endif
@@ -579,7 +582,7 @@ __device__ __forceinline__ void band2_run(const DevTables &L, const KArgs &A, co
             constexpr int S = decltype(seg)::value, K = decltype(kk)::value;
             for (int p = 0; p < ncls[c]; p += 64 / S) {
                 co_band2_pass<S, K>(L, A.dsig_co, A.inv_dsig_co, lane, slots, res_, first[c] + p, min(64 / S, ncls[c] - p), cand, A.stats != nullptr,
-                                    refine_wave ? XSW_JOINT_ROUNDS : 0);
+                                    refine_wave ? XSW_JOINT_ROUNDS : XSW_JOINT_ROUNDS_EASY);
             }
         };
 #define XSW_B2_RUN(c) run(std::integral_constant<int, b2_seg(c)>{}, std::integral_constant<int, b2_dirs(c)>{}, c)
