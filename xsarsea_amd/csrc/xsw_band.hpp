@@ -160,7 +160,7 @@ __device__ __forceinline__ unsigned window_arc(const unsigned short *__restrict_
     for (int k = 0; k < ngroups; ++k) {
         const int gp = g0 + k * G;
         const bool gact = on && gp < ip_end;
-        const int gc = gact ? gp : 0;  // (phi_pad is a multiple of 8: the group's read stays inside the padded row)
+        const int gc = gact ? gp : 0;  // (a group may reach up to 7 entries past the row's last direction: into the row's pad, the next row, or the 64 bytes of slack every table is allocated with -- masked below)
         unsigned wa[G / 2], wb[G / 2];
         if constexpr (G == 8) {
             const uint4 qa = *(const uint4 *)(inv_a + gc), qb = *(const uint4 *)(inv_b + gc);

@@ -276,7 +276,7 @@ __device__ __forceinline__ void live_arc(const DevTables &L, bool on, int i_inc,
     // EIGHT directions per trip from ONE 16-byte read of each table row: the kernel is bound by the texture addresser (85 % busy, 557
     // cache-line accesses per record: every lane is another record, so every load touches 64 lines) -- a 2-byte read per direction
     // walked the same two table rows line by line, eight accesses where one does.  The walk starts at the aligned group of eight
-    // that holds the window's first direction (phi_pad is a multiple of 8; the pad entries and the directions outside the window
+    // that holds the window's first direction (a group may reach up to 7 entries past the row's last direction -- the row's pad, the next row, or the 64 bytes of slack every table is allocated with; those entries and the directions outside the window
     // are masked).
     constexpr int G = 8;
     const float inf = __builtin_inff();
@@ -299,7 +299,7 @@ __device__ __forceinline__ void live_arc(const DevTables &L, bool on, int i_inc,
     for (int k = 0; k < ngroups; ++k) {
         const int gp = g0 + k * G;
         const bool gact = on && gp < ip_end;
-        const int gc = gact ? gp : 0;  // (phi_pad >= the group's end: the tables are padded to a multiple of 8 directions... see below)
+        const int gc = gact ? gp : 0;  // (see above: reads past the row's end stay inside the table's allocation)
         const uint4 qa = *(const uint4 *)(inv_a + gc), qb = *(const uint4 *)(inv_b + gc);
         const unsigned wa[4] = {qa.x, qa.y, qa.z, qa.w}, wb[4] = {qb.x, qb.y, qb.z, qb.w};
         float4 c4[G / 2];
