@@ -177,14 +177,15 @@ int xsw_lut_upload(xsw_ctx *ctx, const xsw_lut *co, const xsw_lut *cr);
  * when mem == XSW_MEM_DEVICE; synchronous (returns with outputs filled) for host memory.
  * XSW_ALGO_PRUNED on a LUT whose columns rise monotonically with wind speed (every built-in GMF over most of its rows) runs
  * as FOUR launches on one stream:
- *   k_invert_band    decides the pixels its band rule can (windows inside the monotone rows, short runs of band rows); hands the
+ *   k_invert_band    decides the pixels its band rule can (windows inside the monotone rows, short runs of band rows; wide windows
+ *                    narrowed to the directions in which the band can meet the disc, from the inverse-row table); hands the
  *                    pixels whose band holds a long run of rows along the a-priori direction (XSW_LONG_RUN = 5 or more), or a
  *                    window that reaches past the monotone rows by a tail it can sweep, to list B as 48-byte records;
  *   k_invert_band2   list B: per record a bound from the sigma0 contour itself (inverse-row table), the live arc of directions,
  *                    per direction the joint shrink of band and chord, batched sweep;
  *   k_invert_blocks  list C: the finite pixels the band rule is not for (windows past the monotone rows, bands of thousands of
- *                    candidates, sigma0 outliers): branch-and-bound over min / max tables of LUT blocks, both cost terms bound
- *                    together, four pixels per wave;
+ *                    candidates, sigma0 outliers): branch-and-bound over min / max tables of LUT cells (32 x 32 candidates), blocks
+ *                    (4 x 16) and quarter blocks (4 x 4), both cost terms bound together, four pixels per wave;
  *   k_invert_list    list G: the rest (non-finite inputs, near-ties, whatever overflowed), the general algorithm.
  * The work lists are owned by the context and sized by the largest raster seen (n pixels): list G n/8 entries, lists B and C
  * n/2 entries each (4 bytes per entry), list B's records 48 bytes x n/2, two strip masks of one bit per pixel -- 28.8 bytes per
@@ -229,7 +230,7 @@ int xsw_stats_enable(xsw_ctx *ctx, int on);
 int xsw_stats_read(xsw_ctx *ctx, xsw_stats *out);
 typedef struct {
     uint64_t cand_band2;      /* candidates scored by k_invert_band2 (after contour bound and joint shrink)          */
-    uint64_t cand_blocks;     /* candidates scored by k_invert_blocks (64 per swept block)                            */
+    uint64_t cand_blocks;     /* candidates scored by k_invert_blocks (16 per swept quarter block)                    */
     uint64_t cand_list;       /* candidates scored by k_invert_list                                                   */
     uint64_t pixels_refined;  /* list-B records k_invert_band2 put through its refinement (contour bound, live arc)  */
 } xsw_chain_stats;
