@@ -413,6 +413,7 @@ def test_joint_rows_keep_every_candidate_under_the_bound(seed):
     w_ax = np.linspace(0.4, 32.2, n_w)
     wh = 0.5 * w_ax
     w0, inv_wstep = w_ax[0], (n_w - 1) / (w_ax[-1] - w_ax[0])
+    n_dead = 0
     for case in range(400):
         col = np.cumsum(rng.uniform(0.0, 0.3, n_w)) - 30.0
         if case % 5 == 0:
@@ -442,7 +443,9 @@ def test_joint_rows_keep_every_candidate_under_the_bound(seed):
         live = pm.direction_is_live(inv_col, tb_lo, tb_hi if tb_hi >= 0 else bins, bins, j_ub, uh, m2, wh[0], wh[1] - wh[0], int(w_lo), int(w_hi))
         if (J[w_lo:w_hi + 1] <= j_ub).any():
             assert live, (case, "live arc", tb_lo, tb_hi)
+        n_dead += 0 if live else 1
         thr_lo, thr_hi = s - rng.uniform(0, 2), s + rng.uniform(0, 2)
         b_lo, b_hi = pm.table_bins_margin(grid[0], grid[2], bins, thr_lo, thr_hi)
         assert b_lo == 0 or b_lo * width + grid[0] <= thr_lo
         assert b_hi == bins or b_hi * width + grid[0] > thr_hi
+    assert n_dead > 40, n_dead  # (the test has teeth: a good part of the random directions IS declared dead)
