@@ -793,6 +793,8 @@ def main():
     l0, l1 = multi_gpu.tile_bounds(total_lines, world, rank)  # this rank's row tile (windspeed.py:356-364: row blocks)
     lines = l1 - l0
     inc, s_vv, anc = make_scene(lines, samples, total_lines, l0, 20260320 + 2 + rank, device)
+    torch.cuda.synchronize()
+    scene_sum0 = int(s_vv.view(torch.int32).to(torch.int64).sum().item())  # (--verify-gather checks that nothing wrote into the inputs since)
     if mode == "detrend":
         if rank == 0:
             d = detrend_figures(args, ctx, stream, s_vv, lines, samples)
@@ -943,16 +945,32 @@ def main():
         kernel_ms_max = kernel_ms
 
     gather_ok = None
-    if args.verify_gather and world > 1 and rank == 0:
-        parts = [make_scene(b1 - b0, samples, total_lines, b0, 20260320 + 2 + r, device)
-                 for r, (b0, b1) in enumerate(multi_gpu.tile_bounds(total_lines, world, r) for r in range(world))]
-        w_inc, w_s, w_anc = (torch.cat([p[i] for p in parts]) for i in range(3))
-        w_vh = w_dsig = w_dual = None
+    w_inc = w_s = w_anc = w_vh = w_dsig = None
+    if args.verify_gather and world > 1:
+        # the rasters the ranks have ACTUALLY been inverting, gathered on rank 0 (every rank takes part): the comparison below then checks
+        # the pipeline and nothing else -- a regenerated scene would also have to trust the generator to reproduce itself call to call
+        def gathered(t):
+            full_t = torch.empty((total_lines, samples), dtype=t.dtype, device=device) if rank == 0 else None
+            if not (backend == "nccl"):
+                torch.cuda.synchronize()
+            for q in multi_gpu.gather_chunk_async(t, total_lines, 0, 1, dst=0, out=full_t):
+                q.wait()
+            torch.cuda.synchronize()
+            return full_t
+        w_inc, w_s, w_anc = gathered(inc), gathered(s_vv), gathered(anc)
         if mode == "dual":
-            cps = [make_crosspol(p[0], p[2], 777 + r, device) for r, p in enumerate(parts)]
-            w_vh, w_dsig = torch.cat([c[0] for c in cps]), torch.cat([c[1] for c in cps])
-            w_dual = torch.empty((total_lines, samples), dtype=torch.complex64, device=device)
-        del parts
+            w_vh, w_dsig = gathered(s_vh), gathered(dsig)
+    if args.verify_gather and world > 1 and rank == 0:
+        w_dual = torch.empty((total_lines, samples), dtype=torch.complex64, device=device) if mode == "dual" else None
+        # diagnostic: does the generator reproduce rank 0's tile?  (bit for bit, same seed; a difference is the generator's, not the pipeline's)
+        again = make_scene(l1 - l0, samples, total_lines, l0, 20260320 + 2, device)
+        torch.cuda.synchronize()
+        if not bool(torch.equal(again[1].view(torch.int32), s_vv.view(torch.int32))):
+            rr = (again[1].view(torch.int32) != s_vv.view(torch.int32)).any(dim=1).nonzero().flatten()
+            print(f"bench.py: --verify-gather: note: the scene generator did not reproduce rank 0's tile bit for bit (sigma0 checksum at start {scene_sum0}, now "
+                  f"{int(s_vv.view(torch.int32).to(torch.int64).sum().item())}; lines {rr[:3].tolist()}..{rr[-2:].tolist()}); the check below uses the gathered inputs",
+                  file=sys.stderr)
+        del again
         w_out = torch.empty((total_lines, samples), dtype=torch.complex64, device=device)
         ctx.invert_raw(total_lines, samples, _lib.XSW_F32, _lib.XSW_F32, _lib.MEM_DEVICE, w_inc.data_ptr(), w_s.data_ptr(),
                        w_vh.data_ptr() if mode == "dual" else None, w_dsig.data_ptr() if mode == "dual" else None,
@@ -963,6 +981,19 @@ def main():
         gather_ok = bool(torch.equal(bits(w_out), bits(pipe.full)))
         if mode == "dual":
             gather_ok = gather_ok and bool(torch.equal(bits(w_dual), bits(pipe.full_dual)))
+        if not gather_ok:  # where: which rank's tile, which chunk of it
+            bad = (bits(w_out) != bits(pipe.full)).any(dim=-1)
+            rows = bad.any(dim=1).nonzero().flatten()
+            print(f"bench.py: --verify-gather: {int(bad.sum().item())} pixels differ in {int(rows.numel())} lines; first lines {rows[:8].tolist()}, "
+                  f"last {rows[-3:].tolist()}; tiles {[multi_gpu.tile_bounds(total_lines, world, r) for r in range(world)]}", file=sys.stderr)
+            ij = bad.nonzero()[:4].tolist()
+            print("bench.py: --verify-gather: (line, sample, one launch, gathered, code): " +
+                  "; ".join(f"({l}, {c}, {complex(w_out[l, c].item()):.4f}, {complex(pipe.full[l, c].item()):.4f}, 0x{int(pipe.full_codes[l, c].item()) & 0xffffffff:08x})"
+                            for l, c in ij), file=sys.stderr)
+            ctx.expand_codes_on_stream(stream.cuda_stream, total_lines * samples, _lib.XSW_F32, pipe.full_codes.data_ptr(), None, w_out.data_ptr(), None)
+            torch.cuda.synchronize()  # (w_out now = the gathered CODES expanded once more: equal to pipe.full unless the expansion raced)
+            print(f"bench.py: --verify-gather: the gathered codes expanded once more differ from the gathered winds in "
+                  f"{int((bits(w_out) != bits(pipe.full)).any(dim=-1).sum().item())} pixels", file=sys.stderr)
         del w_inc, w_s, w_anc, w_out, w_vh, w_dsig, w_dual
 
     if rank == 0:
