@@ -721,8 +721,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the detrend / dB-parity / exhaustive side figures")
     ap.add_argument("--verify-gather", action="store_true",
-                    help="N > 1: rank 0 rebuilds every rank's input tile, inverts the whole raster in ONE launch and compares "
-                         "it bit for bit with the gathered raster (exit code 3 on a mismatch)")
+                    help="N > 1: the ranks' input tiles are gathered on rank 0, which inverts the whole raster in ONE launch and "
+                         "compares it bit for bit with the gathered result (exit code 3 on a mismatch)")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
